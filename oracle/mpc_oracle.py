@@ -1,0 +1,312 @@
+"""oracle/mpc_oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+numpy/scipy restatement of the reference's control chain (utils.py:21-285,
+env.py:344-424): ZOH discretisation, dlqr, calc_MC, dmom, setup_OSQP, plus the two
+things the reference delegates to the absent third-party `osqp` package
+(PyPI `osqp`, version unpinned by the reference -- README.md:11):
+
+  * `admm_osqp_style`  -- the published OSQP ADMM iteration (Stellato et al. 2020,
+    Algorithm 1) in the reduced dense form, with the fixed deterministic settings of
+    SURVEY.md 8(d) config 4.  This is what the HIP QP kernel is compared with
+    iterate-for-iterate.
+  * `qp_exact`         -- the unique minimiser of the strictly convex QP by an
+    active-set KKT solve seeded from a tight ADMM run and verified through the
+    KKT conditions.  MPC outputs are judged against this ("parity unpinned" at the
+    OSQP boundary: no reference test asserts anything about OSQP's output).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+scipy's cont2discrete / solve_discrete_are / solve_discrete_lyapunov ARE the
+reference's arithmetic for those steps (env.py:46,50,351; utils.py:100,242) and
+are called directly.
+"""
+import ctypes
+import os
+
+import numpy as np
+import scipy.linalg
+from scipy.signal import cont2discrete
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# parameters.py:134-137,158-183,198-210 (index maps + MPC bound vectors)
+OBS_X_IDX = [2, 3, 4, 7, 8, 9, 10, 11, 16, 17]
+MPC_X_IDX = [3, 4, 7, 8, 9, 10, 11, 17, 16]
+MPC_U_IN_X_IDX = [13, 14, 15]
+MPC_U_IDX = [1, 2, 3]
+INF = np.inf
+MPC_X_LB = np.array([-INF, -INF, -20., -30., -300., -100., -50., -INF, 0.])
+MPC_X_UB = np.array([INF, INF, 90., 30., 300., 100., 50., INF, 25.])
+MPC_U_LB = np.array([-25., -21.5, -30.])
+MPC_U_UB = np.array([25., 21.5, 30.])
+MPC_UDOT_LB = np.array([-60., -80., -120.])
+MPC_UDOT_UB = np.array([60., 80., 120.])
+
+
+# --------------------------------------------------------------- C oracle
+class COracle:
+    """ctypes view of oracle/libf16_oracle.so (build: `make -C oracle`)."""
+
+    def __init__(self, path=None):
+        path = path or os.path.join(HERE, "libf16_oracle.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path}: run `make -C oracle` (or __graft_entry__.build())")
+        L = self.lib = ctypes.CDLL(path)
+        dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+        d, i, l = ctypes.c_double, ctypes.c_int, ctypes.c_long
+        L.f16o_init.restype = None
+        L.f16o_table.restype = d
+        L.f16o_table.argtypes = [i, d, d, d]
+        L.f16o_lofi.argtypes = [i, d, d, d, dp]
+        L.f16o_nlplant.argtypes = [dp, dp, i, d]
+        L.f16o_calc_xdot.argtypes = [dp, dp, dp, i, d]
+        L.f16o_calc_xdot_na.argtypes = [dp, dp, dp, dp, i, d]
+        L.f16o_step.argtypes = [dp, dp, d, i, d]
+        L.f16o_step.restype = i
+        L.f16o_linearise_na.argtypes = [dp, dp, dp, d, dp, dp, dp, dp, i, d]
+        L.f16o_linearise_full.argtypes = [dp, dp, d, dp, dp, dp, dp, i, d]
+        L.f16o_xdot_batch.argtypes = [dp, dp, dp, l, i, d, i]
+        L.f16o_rollout.argtypes = [dp, dp, l, i, d, i, d, dp, ip, i]
+        L.f16o_set_xcg.argtypes = [d]
+        L.f16o_last_status.restype = i
+        L.atmos.argtypes = [d, d, dp]
+        L.f16o_init()
+
+    @staticmethod
+    def _p(a):
+        return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+    def table(self, tid, alpha, beta=0.0, el=0.0):
+        return self.lib.f16o_table(int(tid), float(alpha), float(beta), float(el))
+
+    def lofi(self, which, alpha, beta, el):
+        out = np.zeros(9)
+        self.lib.f16o_lofi(which, alpha, beta, el, self._p(out))
+        return out
+
+    def atmos(self, alt, vt):
+        out = np.zeros(3)
+        self.lib.atmos(alt, vt, self._p(out))
+        return out
+
+    def nlplant(self, xu, fi_flag=1, xcg=0.25):
+        xu = np.ascontiguousarray(xu, dtype=np.float64)
+        xdot = np.zeros(18)
+        self.lib.f16o_nlplant(self._p(xu), self._p(xdot), fi_flag, xcg)
+        return xdot
+
+    def calc_xdot(self, x, u, fi_flag=1, xcg=0.25):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        xdot = np.zeros(18)
+        self.lib.f16o_calc_xdot(self._p(x), self._p(u), self._p(xdot), fi_flag, xcg)
+        return xdot
+
+    def calc_xdot_na(self, x_full, x9, u3, fi_flag=1, xcg=0.25):
+        x_full = np.ascontiguousarray(x_full, dtype=np.float64)
+        x9 = np.ascontiguousarray(x9, dtype=np.float64)
+        u3 = np.ascontiguousarray(u3, dtype=np.float64)
+        out = np.zeros(9)
+        self.lib.f16o_calc_xdot_na(self._p(x_full), self._p(x9), self._p(u3), self._p(out), fi_flag, xcg)
+        return out
+
+    def xdot_batch(self, x, u, fi_flag=1, xcg=0.25, nthreads=1):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        out = np.zeros_like(x)
+        self.lib.f16o_xdot_batch(self._p(x), self._p(u), self._p(out), x.shape[0], fi_flag, xcg, nthreads)
+        return out
+
+    def rollout(self, x0, u, T, dt=0.001, fi_flag=1, xcg=0.25, store=True, nthreads=1):
+        """x0 [B,18], u [B,4] -> (x_final [B,18], traj [T,B,18] or None, status [B])."""
+        x = np.array(x0, dtype=np.float64, order="C")
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        B = x.shape[0]
+        traj = np.zeros((T, B, 18)) if store else None
+        status = np.zeros(B, dtype=np.int32)
+        self.lib.f16o_rollout(self._p(x), self._p(u), B, T, dt, fi_flag, xcg,
+                              self._p(traj) if store else None,
+                              status.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), nthreads)
+        return x, traj, status
+
+    def linearise_na(self, x_full, x9=None, u3=None, eps=1e-5, fi_flag=1, xcg=0.25):
+        x_full = np.ascontiguousarray(x_full, dtype=np.float64)
+        x9 = np.ascontiguousarray(x_full[MPC_X_IDX] if x9 is None else x9, dtype=np.float64)
+        u3 = np.ascontiguousarray(x_full[MPC_U_IN_X_IDX] if u3 is None else u3, dtype=np.float64)
+        A, B, C, D = np.zeros((9, 9)), np.zeros((9, 3)), np.zeros((9, 9)), np.zeros((9, 3))
+        self.lib.f16o_linearise_na(self._p(x_full), self._p(x9), self._p(u3), eps,
+                                   self._p(A), self._p(B), self._p(C), self._p(D), fi_flag, xcg)
+        return A, B, C, D
+
+    def linearise_full(self, x, u, eps=1e-5, fi_flag=1, xcg=0.25):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        A, B, C, D = np.zeros((18, 18)), np.zeros((18, 4)), np.zeros((10, 18)), np.zeros((10, 4))
+        self.lib.f16o_linearise_full(self._p(x), self._p(u), eps, self._p(A), self._p(B), self._p(C), self._p(D),
+                                     fi_flag, xcg)
+        return A, B, C, D
+
+
+# ------------------------------------------------------- control chain
+def c2d(A, B, C, D, dt):
+    """env.py:46,50,351 -- scipy.signal.cont2discrete, default method zoh."""
+    return cont2discrete((A, B, C, D), dt)[0:4]
+
+
+def dlqr(A, B, Q, R):
+    """utils.py:219-245."""
+    P = np.array(scipy.linalg.solve_discrete_are(A, B, Q, R))
+    return np.array(scipy.linalg.inv(B.T @ P @ B + R) @ (B.T @ P @ A))
+
+
+def calc_MC(A, B, dt, hzn):
+    """utils.py:171-197: MM[i] = A^(i+1), CC[i,j] = A^(i-j) B (i>=j)."""
+    ns, ni = A.shape[0], B.shape[1]
+    CC = np.zeros((ns * hzn, ni * hzn))
+    MM = np.zeros((ns * hzn, ns))
+    for i in range(hzn):
+        MM[ns * i:ns * (i + 1), :] = np.linalg.matrix_power(A, i + 1)
+        for j in range(i + 1):
+            CC[ns * i:ns * (i + 1), ni * j:ni * (j + 1)] = np.linalg.matrix_power(A, i - j) @ B
+    return MM, CC
+
+
+def dmom(mat, num):
+    """utils.py:270-285: block-diagonal replication."""
+    r, c = mat.shape
+    out = np.zeros((r * num, c * num))
+    for i in range(num):
+        out[r * i:r * (i + 1), c * i:c * (i + 1)] = mat
+    return out
+
+
+def lqr_gain_from_linearisation(Ac, Bc, Cc, Dc, dt):
+    """env.py:344-358 after the linearise call: K = -dlqr(Ad, Bd, Cd'Cd, I)."""
+    A, B, C, D = c2d(Ac, Bc, Cc, Dc, dt)
+    return -dlqr(A, B, C.T @ C, np.eye(B.shape[1]))
+
+
+def lqr_action(p_dem, q_dem, r_dem, K, x, u0):
+    """env.py:360-371."""
+    x_ref = np.copy(x)
+    x_ref[4], x_ref[5], x_ref[6] = p_dem, q_dem, r_dem
+    return -K @ (x_ref - x) + u0
+
+
+def setup_OSQP(x_ref, A, B, Q, R, hzn, dt, x, act_states,
+               x_lb=MPC_X_LB, x_ub=MPC_X_UB, u_lb=MPC_U_LB, u_ub=MPC_U_UB,
+               udot_lb=MPC_UDOT_LB, udot_ub=MPC_UDOT_UB):
+    """utils.py:21-167.  Returns P, q, A, l, u with 1-D q/l/u."""
+    m, n = len(x), len(act_states)
+    xr = np.tile(x_ref, hzn)
+    MM, CC = calc_MC(A, B, dt, hzn)
+    K = -dlqr(A, B, Q, R)
+    Q_bar = scipy.linalg.solve_discrete_lyapunov((A + B @ K).T, Q + K.T @ R @ K)
+    QQ = dmom(Q, hzn)
+    QQ[-m:, -m:] = Q_bar
+    RR = dmom(R, hzn)
+    P = 2 * (CC.T @ QQ @ CC + RR)
+    q = -2 * ((xr - MM @ x) @ QQ @ CC)
+    sl = np.tile(x_lb, hzn) - MM @ x
+    su = np.tile(x_ub, hzn) - MM @ x
+    cl, cu = np.tile(u_lb, hzn), np.tile(u_ub, hzn)
+    rl = np.concatenate((act_states + udot_lb * dt, np.tile(udot_lb, hzn - 1)))
+    ru = np.concatenate((act_states + udot_ub * dt, np.tile(udot_ub, hzn - 1)))
+    Dm = np.eye(n * hzn)
+    for i in range(n, n * hzn):
+        Dm[i, i - n] = -1
+    Ac = np.concatenate((CC, np.eye(n * hzn), Dm), axis=0)
+    return P, q, Ac, np.concatenate((sl, cl, rl)), np.concatenate((su, cu, ru))
+
+
+def mpc_qp(x_full, Ad, Bd, Cd, hzn, dt, p_dem=0.0, q_dem=0.0, r_dem=0.0):
+    """env.py:373-416: QP data for one aircraft state (demands land in x_ref[5:8] -- quirk 8-Q.4)."""
+    x = np.asarray(x_full)[MPC_X_IDX]
+    act = np.asarray(x_full)[MPC_U_IN_X_IDX]
+    x_ref = np.copy(x)
+    x_ref[5:8] = [p_dem, q_dem, r_dem]
+    Q = Cd.T @ Cd
+    R = np.eye(3)
+    return setup_OSQP(x_ref, Ad, Bd, Q, R, hzn, dt, x, act)
+
+
+# ------------------------------------------------------------- QP solvers
+ADMM_DEFAULTS = dict(rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3,
+                     check_every=25, rho_every=100, max_iter=40000, adaptive_rho=True)
+
+
+def admm_osqp_style(P, q, A, l, u, **kw):
+    """OSQP Algorithm 1 in reduced dense form, deterministic:
+    rows with l=-inf and u=+inf are dropped (they can never bind; OSQP gives them rho_min),
+    no Ruiz scaling, termination checked every `check_every` iterations with OSQP's criteria,
+    rho re-estimated every `rho_every` iterations (OSQP's interval when built without timers)
+    and applied when it moves by more than 5x.  Returns dict(x, y, z, iters, r_prim, r_dual, rho)."""
+    o = dict(ADMM_DEFAULTS)
+    o.update(kw)
+    keep = ~(np.isneginf(l) & np.isposinf(u))
+    A, l, u = A[keep], l[keep], u[keep]
+    n, mrow = P.shape[0], A.shape[0]
+    rho, sigma, alpha = o["rho"], o["sigma"], o["alpha"]
+    AtA = A.T @ A
+    cho = scipy.linalg.cho_factor(P + sigma * np.eye(n) + rho * AtA)
+    x, z, y = np.zeros(n), np.zeros(mrow), np.zeros(mrow)
+    it, rp, rd = 0, np.inf, np.inf
+    for it in range(1, o["max_iter"] + 1):
+        xt = scipy.linalg.cho_solve(cho, sigma * x - q + A.T @ (rho * z - y))
+        zt = A @ xt
+        x = alpha * xt + (1 - alpha) * x
+        zr = alpha * zt + (1 - alpha) * z
+        z_new = np.clip(zr + y / rho, l, u)
+        y = y + rho * (zr - z_new)
+        z = z_new
+        if it % o["check_every"] == 0:
+            Ax, Px, Aty = A @ x, P @ x, A.T @ y
+            rp = np.abs(Ax - z).max()
+            rd = np.abs(Px + q + Aty).max()
+            np_ = max(np.abs(Ax).max(), np.abs(z).max())
+            nd_ = max(np.abs(Px).max(), np.abs(Aty).max(), np.abs(q).max())
+            if rp <= o["eps_abs"] + o["eps_rel"] * np_ and rd <= o["eps_abs"] + o["eps_rel"] * nd_:
+                break
+            if o["adaptive_rho"] and it % o["rho_every"] == 0:
+                new = rho * np.sqrt((rp / max(np_, 1e-10)) / max(rd / max(nd_, 1e-10), 1e-10))
+                new = min(max(new, 1e-6), 1e6)
+                if new > 5 * rho or new < rho / 5:
+                    rho = new
+                    cho = scipy.linalg.cho_factor(P + sigma * np.eye(n) + rho * AtA)
+    yfull = np.zeros(keep.size)
+    yfull[keep] = y
+    return dict(x=x, y=yfull, z=z, iters=it, r_prim=rp, r_dual=rd, rho=rho)
+
+
+def qp_exact(P, q, A, l, u, tol=1e-9, max_rounds=50):
+    """Exact minimiser of  1/2 x'Px + q'x  s.t. l <= Ax <= u  (P > 0) by primal-dual active-set
+    iteration on the KKT system, seeded from a tight ADMM run; raises if KKT is not met."""
+    n = P.shape[0]
+    seed = admm_osqp_style(P, q, A, l, u, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000)
+    x, y = seed["x"], seed["y"]
+    Ax = A @ x
+    act_lo = (Ax - l < 1e-6) & (y < -1e-9) & np.isfinite(l)
+    act_hi = (u - Ax < 1e-6) & (y > 1e-9) & np.isfinite(u)
+    for _ in range(max_rounds):
+        idx = np.nonzero(act_lo | act_hi)[0]
+        b = np.where(act_lo[idx], l[idx], u[idx])
+        Aa = A[idx]
+        k = len(idx)
+        KKT = np.block([[P, Aa.T], [Aa, np.zeros((k, k))]])
+        sol = np.linalg.lstsq(KKT, np.concatenate((-q, b)), rcond=None)[0] if k else np.linalg.solve(P, -q)
+        x = sol[:n]
+        lam = np.zeros(A.shape[0])
+        if k:
+            lam[idx] = sol[n:]
+        Ax = A @ x
+        viol_lo = (Ax < l - tol) & ~act_lo
+        viol_hi = (Ax > u + tol) & ~act_hi
+        wrong_lo = act_lo & (lam > tol)
+        wrong_hi = act_hi & (lam < -tol)
+        if not (viol_lo.any() or viol_hi.any() or wrong_lo.any() or wrong_hi.any()):
+            stat = np.abs(P @ x + q + A.T @ lam).max()
+            if stat > 1e-7 * max(1.0, np.abs(q).max()):
+                raise RuntimeError(f"qp_exact: stationarity {stat}")
+            return x, lam
+        act_lo = (act_lo | viol_lo) & ~wrong_lo
+        act_hi = (act_hi | viol_hi) & ~wrong_hi
+    raise RuntimeError("qp_exact: active set did not settle")

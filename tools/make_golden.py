@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE.
+
+Build-container only.  It (a) loads the reference's prebuilt C/nlplant_xcg25.so and
+C/nlplant_xcg35.so with ctypes (CWD must be the reference root because the C opens
+"C/<table>.dat" by relative path, hifi_F16_AeroData.c:8), and (b) imports the reference's
+env.py / utils.py / parameters.py under empty stub modules for the five packages that are
+absent offline (gym, ursina, progressbar, osqp, control.matlab) with np.infty restored
+(parameters.py:122 uses it; NumPy 2 removed it).  Nothing of the reference is copied: only
+inputs and the outputs it computed are stored.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py
+"""
+import ctypes
+import os
+import sys
+import types
+
+import numpy as np
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+REF = os.environ.get("F16_REFERENCE", "/root/reference")
+OUT = os.path.join(REPO, "tests", "golden")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+
+TABLE_FNS = [  # reference symbol per table id (same order as tools/pack_tables.py HIFI)
+    "_Cx", "_Cz", "_Cm", "_Cn", "_Cl", "_Cy", "_Cy_r30", "_Cn_r30", "_Cl_r30", "_Cy_a20", "_Cn_a20", "_Cl_a20",
+    "_Cx_lef", "_Cz_lef", "_Cm_lef", "_Cy_lef", "_Cn_lef", "_Cl_lef", "_Cy_a20_lef", "_Cn_a20_lef", "_Cl_a20_lef",
+    "_CXq", "_CYr", "_CYp", "_CZq", "_CLr", "_CLp", "_CMq", "_CNr", "_CNp", "_delta_CNbeta", "_delta_CLbeta",
+    "_delta_Cm", "_delta_CXq_lef", "_delta_CYr_lef", "_delta_CYp_lef", "_delta_CZq_lef", "_delta_CLr_lef",
+    "_delta_CLp_lef", "_delta_CMq_lef", "_delta_CNr_lef", "_delta_CNp_lef", "_eta_el"]
+TABLE_NARGS = [3] * 5 + [2] * 16 + [1] * 22
+ALPHA1 = np.array([-20, -15, -10, -5, 0, 5, 10, 15, 20, 25, 30, 35, 40, 45, 50, 55, 60, 70, 80, 90.])
+BETA1 = np.array([-30, -25, -20, -15, -10, -8, -6, -4, -2, 0, 2, 4, 6, 8, 10, 15, 20, 25, 30.])
+DH1 = np.array([-25, -10, 0, 10, 25.])
+
+
+def import_reference():
+    os.chdir(REF)
+    for name in ("gym", "ursina", "progressbar", "osqp", "control", "control.matlab"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["gym"].Env = type("Env", (), {})
+    sys.modules["gym"].spaces = types.ModuleType("gym.spaces")
+    sys.modules["gym.spaces"] = sys.modules["gym"].spaces
+    sys.modules["control"].matlab = sys.modules["control.matlab"]
+    if not hasattr(np, "infty"):
+        np.infty = np.inf
+    sys.path.insert(0, REF)
+    import parameters  # noqa
+    import env  # noqa
+    import utils  # noqa
+    return parameters, env, utils
+
+
+def dptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def random_states(rng, n, lofi=False):
+    """In-grid xu[18] samples (units of parameters.py:119)."""
+    x = np.zeros((n, 18))
+    x[:, 0:2] = rng.uniform(-1e3, 1e3, (n, 2))
+    x[:, 2] = rng.uniform(0, 4e4, n)
+    x[:, 3:6] = rng.uniform(-1, 1, (n, 3))
+    x[:, 6] = rng.uniform(200, 900, n)
+    x[:, 7] = np.deg2rad(rng.uniform(-9.5 if lofi else -19, 44, n))
+    x[:, 8] = np.deg2rad(rng.uniform(-29, 29, n))
+    x[:, 9:12] = rng.uniform(-1, 1, (n, 3))
+    x[:, 12] = rng.uniform(1000, 19000, n)
+    x[:, 13] = rng.uniform(-24.5, 24.5, n)
+    x[:, 14] = rng.uniform(-21, 21, n)
+    x[:, 15] = rng.uniform(-29, 29, n)
+    x[:, 16] = rng.uniform(0, 25, n)
+    x[:, 17] = rng.uniform(-20, 5, n)
+    # exact-node cases: beta = 0, el in {0, +-10, 25}, alpha = 0 (exact zeros survive the rad->deg product)
+    k = n // 8
+    x[:k, 8] = 0.0
+    x[k:2 * k, 13] = rng.choice([0.0, -10.0, 10.0, 25.0, -25.0], k)
+    x[2 * k:2 * k + k // 2, 7] = 0.0
+    x[2 * k + k // 2:3 * k, [7, 8, 13]] = 0.0
+    return x
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    parameters, env, utils = import_reference()
+    from oracle import mpc_oracle as mo
+
+    libs = {25: ctypes.CDLL(os.path.join(REF, "C", "nlplant_xcg25.so")),
+            35: ctypes.CDLL(os.path.join(REF, "C", "nlplant_xcg35.so"))}
+    rng = np.random.default_rng(20261003)
+
+    # ---------------- G1: every table function
+    lib = libs[25]
+    pts_all, vals_all = [], []
+    for tid, (fn, na) in enumerate(zip(TABLE_FNS, TABLE_NARGS)):
+        f = getattr(lib, fn)
+        f.restype = ctypes.c_double
+        f.argtypes = [ctypes.c_double] * na
+        amax = 45.0 if "lef" in fn else 90.0
+        n = 64
+        a = rng.uniform(-20, amax, n)
+        b = rng.uniform(-30, 30, n)
+        e = rng.uniform(-25, 25, n)
+        a[:8] = rng.choice(ALPHA1[ALPHA1 <= amax], 8)          # nodes
+        b[4:12] = rng.choice(BETA1, 8)
+        e[8:16] = rng.choice(DH1, 8)
+        a[16], a[17] = -20.0, amax                              # grid edges
+        b[18], b[19] = -30.0, 30.0
+        e[20], e[21] = -25.0, 25.0
+        if fn == "_eta_el":
+            vals = [f(e[i]) for i in range(n)]
+        elif na == 1:
+            vals = [f(a[i]) for i in range(n)]
+        elif na == 2:
+            vals = [f(a[i], b[i]) for i in range(n)]
+        else:
+            if fn in ("_Cn", "_Cl"):
+                pass  # DH2 grid {-25,0,25}: DH1 nodes +-10 are interior points there
+            vals = [f(a[i], b[i], e[i]) for i in range(n)]
+        pts_all.append(np.stack([a, b, e], 1))
+        vals_all.append(np.array(vals))
+    np.savez_compressed(os.path.join(OUT, "g1_tables.npz"), pts=np.array(pts_all), vals=np.array(vals_all),
+                        names=np.array(TABLE_FNS))
+
+    # ---------------- G2: Nlplant + atmos
+    def nlplant(lib, xu, fi):
+        out = np.zeros((len(xu), 18))
+        for i in range(len(xu)):
+            row = np.ascontiguousarray(xu[i])
+            lib.Nlplant(dptr(row), dptr(out[i]), ctypes.c_int(fi))
+        return out
+    xu_h = random_states(rng, 1000)
+    xu_l = random_states(rng, 400, lofi=True)
+    x0 = np.copy(parameters.x0)
+    xu_h[0] = x0
+    xu_l[0] = x0
+    alt = rng.uniform(0, 6e4, 64)
+    vt = rng.uniform(0.01, 1500, 64)
+    alt[0], vt[0] = 35000.0, 500.0
+    atm = np.zeros((64, 3))
+    for i in range(64):
+        libs[25].atmos(ctypes.c_double(alt[i]), ctypes.c_double(vt[i]), dptr(atm[i]))
+    np.savez_compressed(os.path.join(OUT, "g2_nlplant.npz"), xu_hifi=xu_h, xu_lofi=xu_l,
+                        xdot_hifi_xcg25=nlplant(libs[25], xu_h, 1), xdot_hifi_xcg35=nlplant(libs[35], xu_h, 1),
+                        xdot_lofi_xcg25=nlplant(libs[25], xu_l, 0), xdot_lofi_xcg35=nlplant(libs[35], xu_l, 0),
+                        atmos_in=np.stack([alt, vt], 1), atmos_out=atm)
+
+    # ---------------- reference F16 objects (trim + linearise at construction, env.py:31-60)
+    def make_f16(stab):
+        P = parameters
+        sv = P.stateVector(P.states, np.copy(P.x0), P.x_units, P.x_ub, P.x_lb, np.copy(P.x0), P.observed_states,
+                           P.mpc_states, P.mpc_inputs, P.mpc_controlled_states)
+        iv = P.inputVector(P.inputs, np.copy(P.u0), P.u_units, P.u_ub, P.u_lb, P.udot_ub, P.udot_lb, np.copy(P.u0),
+                           P.mpc_inputs)
+        sp = P.simulationParameters(P.dt, P.time_start, P.time_end, stab, 1)
+        ss = P.stateSpace(*[np.zeros((1, 1))] * 8)
+        return env.F16(sv, iv, sp, ss, libs[35 if stab else 25])
+    f16 = {25: make_f16(0), 35: make_f16(1)}
+
+    # ---------------- G5/G6/G7: trim, linearisations, discretisation, LQR gain
+    g567 = {}
+    for k, f in f16.items():
+        g567[f"trim_x_xcg{k}"] = np.copy(f.x.initial_condition)
+        g567[f"A18_xcg{k}"], g567[f"B18_xcg{k}"] = f.ss.Ac, f.ss.Bc
+        g567[f"C18_xcg{k}"], g567[f"D18_xcg{k}"] = f.ss.Cc, f.ss.Dc
+        g567[f"Ad18_xcg{k}"], g567[f"Bd18_xcg{k}"] = f.ss.Ad, f.ss.Bd
+        for nm in ("Ac", "Bc", "Cc", "Dc", "Ad", "Bd", "Cd", "Dd"):
+            g567[f"ssr_{nm}_xcg{k}"] = getattr(f.ssr, nm)
+        g567[f"K_lqr_xcg{k}"] = f._calc_LQR_gain()
+    # LQR action sample (env.py:360-371)
+    f = f16[25]
+    x9 = f.x._get_mpc_x() + rng.uniform(-0.01, 0.01, 9)
+    g567["lqr_action_x9"] = x9
+    g567["lqr_action_u"] = f._calc_LQR_action(0.1, -0.05, 0.02, g567["K_lqr_xcg25"], x9, f.u.initial_condition[1:])
+    np.savez_compressed(os.path.join(OUT, "g567_trim_lin_lqr.npz"), **g567)
+
+    # ---------------- G3: _calc_xdot / _calc_xdot_na through the reference Python
+    xs = random_states(rng, 256)
+    us = np.stack([rng.uniform(0, 20000, 256), rng.uniform(-30, 30, 256), rng.uniform(-25, 25, 256),
+                   rng.uniform(-35, 35, 256)], 1)
+    us[:64] = xs[:64, 12:16] + rng.uniform(-1, 1, (64, 4))       # unsaturated rates
+    g3 = dict(x=xs, u=us)
+    for k, f in f16.items():
+        g3[f"xdot_xcg{k}"] = np.array([f._calc_xdot(xs[i], us[i]) for i in range(256)])
+        x_full = np.copy(f.x.values)
+        x9s = xs[:, mo.MPC_X_IDX]
+        u3s = xs[:, mo.MPC_U_IN_X_IDX]
+        g3[f"na_x_full_xcg{k}"] = x_full
+        g3[f"xdot_na_xcg{k}"] = np.array([f._calc_xdot_na(x9s[i], u3s[i]) for i in range(256)])
+    g3["na_x9"], g3["na_u3"] = x9s, u3s
+    np.savez_compressed(os.path.join(OUT, "g3_calc_xdot.npz"), **g3)
+
+    # ---------------- G4: Euler rollouts through F16.step (env.py:105-130)
+    g4 = {}
+    for k, f in f16.items():
+        f.reset()
+        u = np.copy(f.u.values)
+        traj = []
+        for t in range(1000):
+            f.step(u)
+            if (t + 1) % 50 == 0:
+                traj.append(np.copy(f.x.values))
+        g4[f"trim_traj_xcg{k}"] = np.array(traj)
+        g4[f"trim_u_xcg{k}"] = u
+        # perturbed starts + stepped commands
+        starts, trajs, ucmd = [], [], []
+        for j in range(8):
+            f.reset()
+            xs0 = np.copy(f.x.values)
+            xs0[2] += rng.uniform(-3000, 8000)
+            xs0[6] += rng.uniform(-150, 150)
+            xs0[3:6] += rng.uniform(-0.15, 0.15, 3)
+            xs0[7] += rng.uniform(-0.03, 0.12)
+            xs0[8] += rng.uniform(-0.05, 0.05)
+            xs0[9:12] += rng.uniform(-0.2, 0.2, 3)
+            f.x.values = np.copy(xs0)
+            u = np.copy(f.u.initial_condition) + np.array([rng.uniform(-500, 3000), rng.uniform(-3, 3),
+                                                           rng.uniform(-5, 5), rng.uniform(-5, 5)])
+            tr = []
+            for t in range(300):
+                f.step(u)
+                if (t + 1) % 25 == 0:
+                    tr.append(np.copy(f.x.values))
+            starts.append(xs0), trajs.append(np.array(tr)), ucmd.append(u)
+        g4[f"pert_x0_xcg{k}"], g4[f"pert_traj_xcg{k}"], g4[f"pert_u_xcg{k}"] = map(np.array, (starts, trajs, ucmd))
+        f.reset()
+    np.savez_compressed(os.path.join(OUT, "g4_rollout.npz"), **g4)
+
+    # ---------------- G8/G9: MPC matrices + QP data + exact minimisers
+    g8 = {}
+    # Cannon C21 toy system used by notes_examples/example_2_1.py:28-49
+    At, Bt, Ct = np.array([[1.1, 2], [0, 0.95]]), np.array([[0], [0.0787]]), np.array([[-1.0, 1.0]])
+    MMt, CCt = utils.calc_MC(At, Bt, 1, 4)
+    Qt, Rt = Ct.T @ Ct, np.eye(1) * 0.01
+    g8["toy_MM"], g8["toy_CC"] = MMt, CCt
+    g8["toy_H"] = CCt.T @ utils.dmom(Qt, 4) @ CCt + utils.dmom(Rt, 4)
+    g8["toy_K"] = utils.dlqr(At, Bt, Qt, Rt)
+    for k, f in f16.items():
+        f.reset()
+        for N in (4, 10, 30):
+            x = f.x._get_mpc_x()
+            act = f.x._get_mpc_act_states()
+            x_ref = np.copy(x)
+            x_ref[5:8] = [0.0, 0.0, 0.0]
+            A, B, C = f.ssr.Ad, f.ssr.Bd, f.ssr.Cd
+            Pm, q, Ac, l, u = utils.setup_OSQP(x_ref, A, B, C.T @ C, np.eye(3), N, f.paras.dt, x, act,
+                                               f.x._vec_mpc_x_lb, f.x._vec_mpc_x_ub, f.u._vec_mpc_u_lb,
+                                               f.u._vec_mpc_u_ub, f.u._vec_mpc_udot_lb, f.u._vec_mpc_udot_ub)
+            tag = f"xcg{k}_N{N}"
+            g8[f"P_{tag}"], g8[f"q_{tag}"], g8[f"A_{tag}"] = Pm, q.ravel(), Ac
+            g8[f"l_{tag}"], g8[f"u_{tag}"] = l.ravel(), u.ravel()
+            xs_, lam = mo.qp_exact(Pm, q.ravel(), Ac, l.ravel(), u.ravel())
+            g8[f"xstar_{tag}"], g8[f"lam_{tag}"] = xs_, lam
+        MM, CC = utils.calc_MC(f.ssr.Ad, f.ssr.Bd, f.paras.dt, 10)
+        g8[f"MM10_xcg{k}"], g8[f"CC10_xcg{k}"] = MM, CC
+    # drop the big dense constraint matrices' redundancy: A is rebuilt from CC in tests for N=30
+    np.savez_compressed(os.path.join(OUT, "g8_mpc_qp.npz"), **g8)
+    for fn in sorted(os.listdir(OUT)):
+        print(fn, os.path.getsize(os.path.join(OUT, fn)))
+
+
+if __name__ == "__main__":
+    main()
