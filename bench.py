@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on MI355X: F-16 env steps/s (+ MPC solves/s), batch 4096, hifi model.
+
+One bench "step" = one pass of the hot path over one batch: a 1000-Euler-step open-loop rollout of
+B = 4096 hifi aircraft per GPU with every state stored (BASELINE config 2; [1000,18,4096] fp64 trajectory),
+i.e. 4,096,000 aircraft-steps per launch.  value = aircraft-steps/s over all ranks.  Inputs are resident in HBM
+before the timed region.  Multi-GPU: aircraft are independent, so ranks own disjoint batch shards (weak scaling,
+no data-path collective); the max-over-ranks time is taken with one scalar all-reduce.
+
+Extra keys on the same JSON line: "roofline" (dominant kernel k_rollout, HBM-bound by SURVEY 8(d) accounting,
+timed with HIP events on the launch stream), "cpu_baseline" (the C oracle on the host cores, bounded sample),
+"mpc" (batched calc_MPC_action throughput, N=30, xcg 0.35 -- BASELINE config 4).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
+BYTES_PER_STORED_STEP = 144           # 18 doubles written per stored trajectory sample
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="aircraft per GPU")
+    ap.add_argument("--euler-steps", type=int, default=1000)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-mpc", action="store_true")
+    ap.add_argument("--mpc-hzn", type=int, default=30)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from f16_mpc_oop_py_amd import F16Batch
+    from f16_mpc_oop_py_amd.workload import config2_states
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    B, T = args.batch, args.euler_steps
+    x0_all, u0_all = config2_states(B * world)        # global batch, contiguous shards
+    x0, u0 = x0_all[rank * B:(rank + 1) * B], u0_all[rank * B:(rank + 1) * B]
+    env = F16Batch(x0, u0, device=dev)
+    traj = torch.empty((T, 18, B), dtype=torch.float64, device=dev)
+
+    import ctypes
+    from f16_mpc_oop_py_amd.env import _vp
+
+    def one_pass():
+        env._x.copy_(env._x_init)
+        rc = env.lib.f16_rollout(env.ctx.handle, _vp(env._x), _vp(env._u), _vp(traj), _vp(env.status), B, B, T, 1,
+                                 env.dt, env.xcg, env.fi_flag, env.flags, env._stream)
+        assert rc == 0
+
+    for _ in range(args.warmup):
+        one_pass()
+    barrier()
+    # per-launch kernel time with HIP events on the stream the kernel is launched on (torch's current stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for s, e in ev:
+        env._x.copy_(env._x_init)
+        s.record()
+        rc = env.lib.f16_rollout(env.ctx.handle, _vp(env._x), _vp(env._u), _vp(traj), _vp(env.status), B, B, T, 1,
+                                 env.dt, env.xcg, env.fi_flag, env.flags, env._stream)
+        e.record()
+        assert rc == 0
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    assert int(env.status.max()) == 0, "an aircraft left the envelope"
+    assert bool(torch.isfinite(traj[-1]).all())
+
+    steps_total = world * B * T * args.steps
+    value = steps_total / elapsed
+    achieved = B * T * BYTES_PER_STORED_STEP / (kern_ms * 1e-3) / 1e9
+    out = {
+        "metric": "F16 env steps/sec (hifi Nguyen model, explicit Euler dt=1ms, batch 4096 per GPU)",
+        "value": value, "unit": "aircraft-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 2: open-loop {T}-step rollout, B={B}/GPU, hifi, xcg=0.25, "
+                               f"trajectory [T,18,B] stored every step", "batch_per_gpu": B, "euler_steps": T,
+                   "parallelism": f"batch-sharded x{world}, no collective in the timed region"},
+        "roofline": {"bound": "hbm", "kernel": "k_rollout<64>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel_ms": kern_ms, "bytes_per_launch": B * T * BYTES_PER_STORED_STEP,
+                     "note": "B=4096 is 64 wavefronts on 1024 SIMDs: latency/issue-bound, see DESIGN.md"},
+    }
+
+    if rank == 0 and world == 1 and not args.no_mpc and hasattr(env.lib, "f16_mpc_batch"):
+        out["mpc"] = bench_mpc(args, dev)
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(x0, u0, T)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_mpc(args, dev):
+    """BASELINE config 4: B=4096, xcg=0.35, N=30, one calc_MPC_action per aircraft (linearised at its own state)."""
+    import torch
+    from f16_mpc_oop_py_amd import F16Batch
+    from f16_mpc_oop_py_amd.workload import config2_states
+    x0, u0 = config2_states(args.batch, seed=4)
+    env = F16Batch(x0, u0, xcg=0.35, device=dev)
+    env.build_ssr()
+    env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn)
+    torch.cuda.synchronize()
+    n = 5
+    t0 = time.perf_counter()
+    for _ in range(n):
+        u, info = env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn, return_info=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    it = info["iters"].cpu().numpy()
+    return {"metric": "MPC solves/sec (calc_MPC_action, N=%d, batch %d, xcg=0.35)" % (args.mpc_hzn, args.batch),
+            "value": args.batch / dt, "unit": "solves/s", "ms_per_batch": dt * 1e3,
+            "admm_iters": {"min": float(it.min()), "median": float(np.median(it)), "max": float(it.max())}}
+
+
+def cpu_baseline(x0, u0, T):
+    """The C restatement of the reference path (oracle/, kind 'port') on the host cores: bounded sample of the same
+    workload (first n aircraft x T steps), single thread and all cores."""
+    from oracle import mpc_oracle as mo
+    ora = mo.COracle()
+    cores = os.cpu_count() or 1
+    n1 = 256
+    t0 = time.perf_counter()
+    ora.rollout(x0[:n1], u0[:n1], T, store=True, nthreads=1)
+    t1 = time.perf_counter() - t0
+    nall = min(len(x0), 256 * cores)
+    t0 = time.perf_counter()
+    ora.rollout(x0[:nall], u0[:nall], T, store=True, nthreads=cores)
+    tall = time.perf_counter() - t0
+    return {"value": nall * T / tall, "unit": "aircraft-steps/s", "cores": cores, "kind": "port",
+            "single_thread_value": n1 * T / t1,
+            "sample": f"first {nall} aircraft x {T} steps of the same workload on {cores} threads "
+                      f"(single-thread figure: first {n1} aircraft); oracle/libf16_oracle.so (C restatement)"}
+
+
+if __name__ == "__main__":
+    main()

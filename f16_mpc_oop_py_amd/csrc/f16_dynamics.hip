@@ -1,0 +1,232 @@
+// f16_dynamics.hip -- batched F-16 dynamics kernels for gfx950 + their C-ABI launchers.
+//
+//   k_xdot      env.py:65-103 _calc_xdot for B aircraft                (f16_xdot_batch)
+//   k_nlplant   C/nlplant.c:23-457 incl. accels outputs                (f16_nlplant_batch, drop-in Nlplant)
+//   k_rollout   env.py:105-130 step x nsteps, state in registers       (f16_rollout)
+//   k_xdot_na   env.py:152-193                                         (f16_xdot_na_batch)
+//
+// Mapping: one lane = one aircraft; state-major [k][ld] arrays so a wave's 64 lanes read 512 contiguous
+// bytes per state component.  Every workgroup first copies the 112,928-byte fp64 table image from
+// global memory (L2-resident after the first block) into LDS with 16-byte loads; all 168 table-vertex
+// fetches of an evaluation are then LDS reads.  The kernels are bound by fp64 VALU issue and, at the
+// reference's batch of 4096 (= 64 wavefronts), by single-wave latency; algorithmic HBM traffic is
+// 320 B per aircraft-step for the state-resident step and 144 B per stored trajectory sample.
+#include <hip/hip_runtime.h>
+
+#include "../../include/f16_hip.h"
+#include "f16_ctx.h"
+#include "f16_plant.hpp"
+
+namespace f16 {
+
+struct DynArgs {
+  const double *tab;    // hifi image, global
+  const double *lofi;   // lofi image, global
+  const double *x;      // [18][ld] (or x_full for xdot_na)
+  const double *u;      // [4][ld]  (x9 for xdot_na)
+  const double *u3;     // xdot_na only
+  double *out;          // xdot / x (rollout: in place) / xdot9
+  double *traj;
+  int32_t *status;
+  long B, ld;
+  int nsteps, traj_every;
+  double dt, xcg;
+  int fi;
+  unsigned flags;
+};
+
+// Cooperative copy of the table image into LDS (16 B per lane per load).
+__device__ __forceinline__ void stage_tables(double *lds, const double *__restrict__ g) {
+  const double2 *src = reinterpret_cast<const double2 *>(g);
+  double2 *dst = reinterpret_cast<double2 *>(lds);
+  for (int i = threadIdx.x; i < TABLE_IMAGE_DOUBLES / 2; i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_xdot(DynArgs a) {
+  __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
+  if (a.fi == 1) stage_tables(tab, a.tab);
+  for (long b = (long)blockIdx.x * BLOCK + threadIdx.x; b < a.B; b += (long)gridDim.x * BLOCK) {
+    double x[18], u[4], xd[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) x[k] = a.x[k * a.ld + b];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = a.u[k * a.ld + b];
+    int st = 0;
+    calc_xdot((const double *)tab, a.lofi, x, u, xd, a.xcg, a.fi, a.flags, st);
+#pragma unroll
+    for (int k = 0; k < 18; ++k) a.out[k * a.ld + b] = xd[k];
+    if (a.status) a.status[b] |= st;
+  }
+}
+
+// Nlplant proper.  TAB_LDS=false reads the image straight from global/L2: used for tiny batches (the
+// single-aircraft drop-in call), where staging 113 KB would cost more than the ~170 gathers it saves.
+template <int BLOCK, bool TAB_LDS>
+__global__ __launch_bounds__(BLOCK) void k_nlplant(DynArgs a) {
+  __shared__ __attribute__((aligned(16))) double tab[TAB_LDS ? TABLE_IMAGE_DOUBLES : 2];
+  if (TAB_LDS && a.fi == 1) stage_tables(tab, a.tab);
+  const double *T = TAB_LDS ? (const double *)tab : a.tab;
+  for (long b = (long)blockIdx.x * BLOCK + threadIdx.x; b < a.B; b += (long)gridDim.x * BLOCK) {
+    double x[17], xd[18], qbar, ps;
+#pragma unroll
+    for (int k = 0; k < 17; ++k) x[k] = a.x[k * a.ld + b];
+    int st = 0;
+    plant<true>(T, a.lofi, x, xd, a.xcg, a.fi, a.flags, st, qbar, ps);
+#pragma unroll
+    for (int k = 0; k < 18; ++k) a.out[k * a.ld + b] = xd[k];
+    if (a.status) a.status[b] |= st;
+  }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_rollout(DynArgs a) {
+  __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
+  if (a.fi == 1) stage_tables(tab, a.tab);
+  for (long b = (long)blockIdx.x * BLOCK + threadIdx.x; b < a.B; b += (long)gridDim.x * BLOCK) {
+    double x[18], u[4];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) x[k] = a.out[k * a.ld + b];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = a.u[k * a.ld + b];
+    int st = a.status ? a.status[b] : 0;
+    double *tr = a.traj ? a.traj + b : nullptr;
+    int until_store = a.traj_every;
+    for (int t = 0; t < a.nsteps; ++t) {
+      // env.py:117-124: the reference exit()s; here the aircraft is frozen and flagged
+      if (!(a.flags & FLAG_NO_ENVELOPE) && outside_envelope(x)) st |= ST_ENVELOPE;
+      if (!(st & ST_ENVELOPE)) {
+        double xd[18];
+        calc_xdot((const double *)tab, a.lofi, x, u, xd, a.xcg, a.fi, a.flags, st);
+#pragma unroll
+        for (int k = 0; k < 18; ++k) x[k] += xd[k] * a.dt;   // env.py:126
+      }
+      if (tr && --until_store == 0) {
+        until_store = a.traj_every;
+#pragma unroll
+        for (int k = 0; k < 18; ++k) __builtin_nontemporal_store(x[k], tr + k * a.ld);
+        tr += 18 * a.ld;
+      }
+    }
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) finite = finite && isfinite(x[k]);
+    if (!finite) st |= ST_NONFINITE;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) a.out[k * a.ld + b] = x[k];
+    if (a.status) a.status[b] = st;
+  }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_xdot_na(DynArgs a) {
+  __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
+  if (a.fi == 1) stage_tables(tab, a.tab);
+  for (long b = (long)blockIdx.x * BLOCK + threadIdx.x; b < a.B; b += (long)gridDim.x * BLOCK) {
+    double sv[18], xd9[9];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) sv[k] = a.x[k * a.ld + b];
+    // env.py:172-177: scatter x9 -> mpc_x_idx [3,4,7,8,9,10,11,17,16], u3 -> [13,14,15]
+    sv[3] = a.u[0 * a.ld + b]; sv[4] = a.u[1 * a.ld + b]; sv[7] = a.u[2 * a.ld + b]; sv[8] = a.u[3 * a.ld + b];
+    sv[9] = a.u[4 * a.ld + b]; sv[10] = a.u[5 * a.ld + b]; sv[11] = a.u[6 * a.ld + b];
+    sv[17] = a.u[7 * a.ld + b]; sv[16] = a.u[8 * a.ld + b];
+    sv[13] = a.u3[0 * a.ld + b]; sv[14] = a.u3[1 * a.ld + b]; sv[15] = a.u3[2 * a.ld + b];
+    int st = 0;
+    calc_xdot_na((const double *)tab, a.lofi, sv, xd9, a.xcg, a.fi, a.flags, st);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a.out[k * a.ld + b] = xd9[k];
+    if (a.status) a.status[b] |= st;
+  }
+}
+
+// ------------------------------------------------------------------------------------ launchers
+// One lane per aircraft; with the table image in LDS a CU holds one workgroup, so small batches use
+// one-wave workgroups spread over as many CUs as possible and large batches 256-CU persistent grids.
+struct Geometry { int block, grid; };
+static Geometry geometry(long B) {
+  Geometry g;
+  if (B <= 64L * 256) g.block = 64;          // <= 256 one-wave workgroups: one per CU
+  else if (B <= 256L * 256) g.block = 256;   // one wave per SIMD
+  else g.block = 512;                        // two waves per SIMD (the plant needs ~256 VGPRs: no third)
+  long blocks = (B + g.block - 1) / g.block;
+  g.grid = (int)(blocks < 256 ? blocks : 256);
+  return g;
+}
+
+#define LAUNCH_BY_BLOCK(KERN, g, stream, args)                                       \
+  do {                                                                               \
+    if ((g).block == 64) hipLaunchKernelGGL(KERN<64>, dim3((g).grid), dim3(64), 0, stream, args);        \
+    else if ((g).block == 256) hipLaunchKernelGGL(KERN<256>, dim3((g).grid), dim3(256), 0, stream, args); \
+    else hipLaunchKernelGGL(KERN<512>, dim3((g).grid), dim3(512), 0, stream, args);                       \
+  } while (0)
+
+static int check_common(f16_ctx *ctx, const void *p0, const void *p1, long B, long ld) {
+  if (!ctx || !p0 || !p1 || B < 0 || ld < B) return set_error(F16_EINVAL, "bad argument (NULL pointer, B < 0 or ld < B)");
+  return F16_OK;
+}
+
+}  // namespace f16
+
+using namespace f16;
+
+extern "C" int f16_xdot_batch(f16_ctx *ctx, const double *x, const double *u, double *xdot, int32_t *status, long B,
+                              long ld, double xcg, int fi_flag, unsigned flags, void *stream) {
+  if (int rc = check_common(ctx, x, xdot, B, ld)) return rc;
+  if (!u) return set_error(F16_EINVAL, "u is NULL");
+  if (B == 0) return F16_OK;
+  DynArgs a{};
+  a.tab = ctx->d_tab; a.lofi = ctx->d_lofi; a.x = x; a.u = u; a.out = xdot; a.status = status;
+  a.B = B; a.ld = ld; a.xcg = xcg; a.fi = fi_flag; a.flags = flags;
+  Geometry g = geometry(B);
+  LAUNCH_BY_BLOCK(k_xdot, g, (hipStream_t)stream, a);
+  return hip_check(hipGetLastError(), "f16_xdot_batch launch");
+}
+
+extern "C" int f16_nlplant_batch(f16_ctx *ctx, const double *xu, double *xdot, int32_t *status, long B, long ld,
+                                 double xcg, int fi_flag, unsigned flags, void *stream) {
+  if (int rc = check_common(ctx, xu, xdot, B, ld)) return rc;
+  if (B == 0) return F16_OK;
+  DynArgs a{};
+  a.tab = ctx->d_tab; a.lofi = ctx->d_lofi; a.x = xu; a.out = xdot; a.status = status;
+  a.B = B; a.ld = ld; a.xcg = xcg; a.fi = fi_flag; a.flags = flags;
+  if (B <= 256) {
+    hipLaunchKernelGGL((k_nlplant<64, false>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
+  } else {
+    Geometry g = geometry(B);
+    if (g.block == 64) hipLaunchKernelGGL((k_nlplant<64, true>), dim3(g.grid), dim3(64), 0, (hipStream_t)stream, a);
+    else if (g.block == 256) hipLaunchKernelGGL((k_nlplant<256, true>), dim3(g.grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_nlplant<512, true>), dim3(g.grid), dim3(512), 0, (hipStream_t)stream, a);
+  }
+  return hip_check(hipGetLastError(), "f16_nlplant_batch launch");
+}
+
+extern "C" int f16_rollout(f16_ctx *ctx, double *x, const double *u, double *traj, int32_t *status, long B, long ld,
+                           int nsteps, int traj_every, double dt, double xcg, int fi_flag, unsigned flags,
+                           void *stream) {
+  if (int rc = check_common(ctx, x, u, B, ld)) return rc;
+  if (nsteps < 0 || (traj && (traj_every < 1 || nsteps % traj_every != 0)))
+    return set_error(F16_EINVAL, "nsteps must be >= 0 and a multiple of traj_every >= 1 when traj is given");
+  if (B == 0 || nsteps == 0) return F16_OK;
+  DynArgs a{};
+  a.tab = ctx->d_tab; a.lofi = ctx->d_lofi; a.u = u; a.out = x; a.traj = traj; a.status = status;
+  a.B = B; a.ld = ld; a.nsteps = nsteps; a.traj_every = traj ? traj_every : nsteps + 1;
+  a.dt = dt; a.xcg = xcg; a.fi = fi_flag; a.flags = flags;
+  Geometry g = geometry(B);
+  LAUNCH_BY_BLOCK(k_rollout, g, (hipStream_t)stream, a);
+  return hip_check(hipGetLastError(), "f16_rollout launch");
+}
+
+extern "C" int f16_xdot_na_batch(f16_ctx *ctx, const double *x_full, const double *x9, const double *u3, double *xdot9,
+                                 int32_t *status, long B, long ld, double xcg, int fi_flag, unsigned flags,
+                                 void *stream) {
+  if (int rc = check_common(ctx, x_full, xdot9, B, ld)) return rc;
+  if (!x9 || !u3) return set_error(F16_EINVAL, "x9/u3 is NULL");
+  if (B == 0) return F16_OK;
+  DynArgs a{};
+  a.tab = ctx->d_tab; a.lofi = ctx->d_lofi; a.x = x_full; a.u = x9; a.u3 = u3; a.out = xdot9; a.status = status;
+  a.B = B; a.ld = ld; a.xcg = xcg; a.fi = fi_flag; a.flags = flags;
+  Geometry g = geometry(B);
+  LAUNCH_BY_BLOCK(k_xdot_na, g, (hipStream_t)stream, a);
+  return hip_check(hipGetLastError(), "f16_xdot_na_batch launch");
+}

@@ -1,0 +1,484 @@
+// f16_plant.hpp -- device-side F-16 plant for gfx950: one wavefront lane = one aircraft.
+//
+// What it computes (same arithmetic, expression by expression, as the reference CPU path):
+//   plant<>()      C/nlplant.c:23-457 Nlplant (hifi: C/hifi_F16_AeroData.c:1871-1934 group functions over
+//                  C/mexndinterp.c:97-265 interpolation; lofi: C/lofi_F16_AeroData.c:12-368)
+//   atmos_dev()    C/nlplant.c:467-490
+//   actuators      utils.py:289-330 (upd_thrust/dstab/ail/rud/lef)
+//   calc_xdot()    env.py:65-103          calc_xdot_na(): env.py:152-193
+// How it differs structurally from the reference (results are unchanged):
+//   * the 5 axis brackets (alpha on ALPHA1/ALPHA2, beta, el on DH1/DH2) are found once and shared by
+//     all lookups; the reference searches them again inside each of its 58 interpn() calls;
+//   * 58 interpn() calls collapse to 48 distinct evaluations on node-major table groups staged in LDS
+//     (f16_tables.h); `_Cy` x4, `_Cn/_Cl(..,0)` x3 are evaluated once;
+//   * an exact grid-node hit needs no special case: lambda is exactly 0 (or 1), and
+//     lambda*f2 + (1-lambda)*f1 then returns f1 (or f2) exactly -- the value the reference's
+//     degenerate-axis rule (mexndinterp.c:126-133,195-200) produces;
+//   * no malloc, no file I/O, sin/cos evaluated once per angle (accels() re-evaluates the same
+//     arguments, C/nlplant.c:525-545).
+// Off-grid coordinates (UB in the reference) are clamped to the grid edge and flagged.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "f16_tables.h"
+
+namespace f16 {
+
+constexpr int ST_ALPHA1 = 1, ST_ALPHA2 = 2, ST_BETA = 4, ST_EL = 8, ST_ENVELOPE = 16, ST_NONFINITE = 32;
+constexpr unsigned FLAG_FIX_CLR = 1u, FLAG_NO_ENVELOPE = 2u;
+
+#define F16_DEV __device__ __forceinline__
+
+struct Axis {
+  int j;       // lower node of the bracketing cell, 0 .. n-2
+  double l;    // lambda = (v - X[j]) / (X[j+1] - X[j])     (mexndinterp.c:196)
+  double m;    // 1 - lambda
+};
+
+F16_DEV double lerp(double f1, double f2, const Axis &a) { return a.l * f2 + a.m * f1; }  // mexndinterp.c:197
+
+// Bracket v on breakpoints X[0..n-1] (monotone).  `guess` may be off by one or two cells.
+template <typename TP>
+F16_DEV Axis bracket(TP X, int n, double v, int guess, bool &off) {
+  const double lo = X[0], hi = X[n - 1];
+  off = !(v >= lo && v <= hi);
+  v = fmin(fmax(v, lo), hi);
+  int j = min(max(guess, 0), n - 2);
+  j -= (j > 0 && v < X[j]);
+  j -= (j > 0 && v < X[j]);
+  j += (j < n - 2 && v >= X[j + 1]);
+  j += (j < n - 2 && v >= X[j + 1]);
+  const double x0 = X[j], x1 = X[j + 1];
+  Axis a;
+  a.j = j;
+  a.l = (v - x0) / (x1 - x0);
+  a.m = 1 - a.l;
+  return a;
+}
+
+// C/nlplant.c:467-490
+F16_DEV void atmos_dev(double alt, double vt, double &mach, double &qbar, double &ps) {
+  const double rho0 = 2.377e-3;
+  const double tfac = 1 - .703e-5 * alt;
+  double temp = 519.0 * tfac;
+  if (alt >= 35000.0) temp = 390;
+  const double rho = rho0 * pow(tfac, 4.14);
+  mach = vt / sqrt(1.4 * 1716.3 * temp);
+  qbar = .5 * rho * (vt * vt);
+  ps = 1715.0 * rho * temp;
+  if (ps == 0) ps = 1715;
+}
+
+struct Aero {  // everything C/nlplant.c:185-240 (or :245-323) hands to the coefficient build-up
+  double Cx, Cz, Cm, Cy, Cn, Cl;
+  double Cxq, Cyr, Cyp, Czq, Clr, Clp, Cmq, Cnr, Cnp;
+  double dCx_lef, dCz_lef, dCm_lef, dCy_lef, dCn_lef, dCl_lef;
+  double dCxq_lef, dCyr_lef, dCyp_lef, dCzq_lef, dClr_lef, dClp_lef, dCmq_lef, dCnr_lef, dCnp_lef;
+  double dCy_r30, dCn_r30, dCl_r30;
+  double dCy_a20, dCy_a20_lef, dCn_a20, dCn_a20_lef, dCl_a20, dCl_a20_lef;
+  double dCnbeta, dClbeta, dCm, eta_el;
+};
+
+// 2-D bilinear on a node-major group: alpha collapsed first, then beta (mexndinterp.c:178-209).
+template <typename TP>
+F16_DEV double bil(TP p, int sa, int sb, const Axis &a, const Axis &b) {
+  const double t0 = lerp(p[0], p[sa], a);
+  const double t1 = lerp(p[sb], p[sb + sa], a);
+  return lerp(t0, t1, b);
+}
+
+// hifi lookups: hifi_C, hifi_damping, hifi_C_lef, hifi_damping_lef, hifi_rudder, hifi_ailerons,
+// hifi_other_coeffs (C/hifi_F16_AeroData.c:1871-1934) fused.  T = table image (LDS or global).
+template <typename TP>
+F16_DEV void aero_hifi(TP T, double alpha, double beta, double el, unsigned flags, Aero &c, int &status) {
+  bool off;
+  // alpha on ALPHA1: 5-degree spacing up to 60, then 70, 80, 90
+  const Axis a1 = bracket(T + OFF_BP_A1, N_A1, alpha, (int)((fmin(fmax(alpha, -20.0), 90.0) + 20.0) * 0.2), off);
+  if (off) status |= ST_ALPHA1;
+  // ALPHA2 is the first 14 nodes of ALPHA1 (checked when the image is built): same cell, or -- from
+  // 45 degrees up -- the last ALPHA2 cell with lambda = 1 (the 45-degree node; beyond it: clamped + flagged)
+  Axis a2 = a1;
+  if (off) status |= ST_ALPHA2;
+  if (a1.j > N_A2 - 2) {
+    if (alpha > T[OFF_BP_A1 + N_A2 - 1]) status |= ST_ALPHA2;
+    a2.j = N_A2 - 2;
+    a2.l = 1.0;
+    a2.m = 0.0;
+  }
+  const double bc = fmin(fmax(beta, -30.0), 30.0);
+  const int gb = bc < -10.0 ? (int)((bc + 30.0) * 0.2) : (bc < 10.0 ? 4 + (int)((bc + 10.0) * 0.5) : 14 + (int)((bc - 10.0) * 0.2));
+  const Axis b = bracket(T + OFF_BP_B1, N_B1, beta, gb, off);
+  if (off) status |= ST_BETA;
+  const Axis d1 = bracket(T + OFF_BP_D1, N_D1, el, (el >= -10.0) + (el >= 0.0) + (el >= 10.0), off);
+  if (off) status |= ST_EL;
+  bool off2;
+  const Axis d2 = bracket(T + OFF_BP_D2, N_D2, el, (int)(el >= 0.0), off2);
+
+  const int n1 = b.j * N_A1 + a1.j;   // cell corner on ALPHA1 x BETA1
+  const int n2 = b.j * N_A2 + a2.j;   // cell corner on ALPHA2 x BETA1
+
+  // ---- G3A: Cx, Cz, Cm at (alpha,beta,el) and on the el = 0 plane
+  {
+    constexpr int SA = S_G3A, SB = S_G3A * N_A1, SD = S_G3A * N_A1 * N_B1;
+    TP p = T + OFF_G3A + n1 * SA;
+    TP plo = p + d1.j * SD;
+    TP p0 = p + D1_ZERO_NODE * SD;
+    double v[3], v0[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double r0 = bil(plo + k, SA, SB, a1, b);
+      const double r1 = bil(plo + SD + k, SA, SB, a1, b);
+      v[k] = lerp(r0, r1, d1);
+      v0[k] = bil(p0 + k, SA, SB, a1, b);
+    }
+    c.Cx = v[0]; c.Cz = v[1]; c.Cm = v[2];
+    c.dCx_lef = v0[0]; c.dCz_lef = v0[1]; c.dCm_lef = v0[2];   // finished below: lef table - this
+  }
+  // ---- G3B: Cn, Cl at (alpha,beta,el) and on the el = 0 plane
+  double Cn0, Cl0;
+  {
+    constexpr int SA = S_G3B, SB = S_G3B * N_A1, SD = S_G3B * N_A1 * N_B1;
+    TP p = T + OFF_G3B + n1 * SA;
+    TP plo = p + d2.j * SD;
+    TP p0 = p + D2_ZERO_NODE * SD;
+    double v[2], v0[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double r0 = bil(plo + k, SA, SB, a1, b);
+      const double r1 = bil(plo + SD + k, SA, SB, a1, b);
+      v[k] = lerp(r0, r1, d2);
+      v0[k] = bil(p0 + k, SA, SB, a1, b);
+    }
+    c.Cn = v[0]; c.Cl = v[1];
+    Cn0 = v0[0]; Cl0 = v0[1];
+  }
+  // ---- G2A: Cy, r30 and a20 increments on ALPHA1 x BETA1
+  double Cy_r30, Cn_r30, Cl_r30, Cy_a20, Cn_a20, Cl_a20;
+  {
+    constexpr int SA = S_G2A, SB = S_G2A * N_A1;
+    TP p = T + OFF_G2A + n1 * SA;
+    c.Cy = bil(p + 0, SA, SB, a1, b);
+    Cy_r30 = bil(p + 1, SA, SB, a1, b);
+    Cn_r30 = bil(p + 2, SA, SB, a1, b);
+    Cl_r30 = bil(p + 3, SA, SB, a1, b);
+    Cy_a20 = bil(p + 4, SA, SB, a1, b);
+    Cn_a20 = bil(p + 5, SA, SB, a1, b);
+    Cl_a20 = bil(p + 6, SA, SB, a1, b);
+  }
+  // ---- G2B: lef tables on ALPHA2 x BETA1
+  double Cy_lef, Cn_lef, Cl_lef;
+  {
+    constexpr int SA = S_G2B, SB = S_G2B * N_A2;
+    TP p = T + OFF_G2B + n2 * SA;
+    const double Cx_lef = bil(p + 0, SA, SB, a2, b);
+    const double Cz_lef = bil(p + 1, SA, SB, a2, b);
+    const double Cm_lef = bil(p + 2, SA, SB, a2, b);
+    Cy_lef = bil(p + 3, SA, SB, a2, b);
+    Cn_lef = bil(p + 4, SA, SB, a2, b);
+    Cl_lef = bil(p + 5, SA, SB, a2, b);
+    const double Cy_a20_lef = bil(p + 6, SA, SB, a2, b);
+    const double Cn_a20_lef = bil(p + 7, SA, SB, a2, b);
+    const double Cl_a20_lef = bil(p + 8, SA, SB, a2, b);
+    // hifi_C_lef :1892-1899
+    c.dCx_lef = Cx_lef - c.dCx_lef;
+    c.dCz_lef = Cz_lef - c.dCz_lef;
+    c.dCm_lef = Cm_lef - c.dCm_lef;
+    c.dCy_lef = Cy_lef - c.Cy;
+    c.dCn_lef = Cn_lef - Cn0;
+    c.dCl_lef = Cl_lef - Cl0;
+    // hifi_rudder :1913-1917
+    c.dCy_r30 = Cy_r30 - c.Cy;
+    c.dCn_r30 = Cn_r30 - Cn0;
+    c.dCl_r30 = Cl_r30 - Cl0;
+    // hifi_ailerons :1919-1926
+    c.dCy_a20 = Cy_a20 - c.Cy;
+    c.dCy_a20_lef = Cy_a20_lef - Cy_lef - c.dCy_a20;
+    c.dCn_a20 = Cn_a20 - Cn0;
+    c.dCn_a20_lef = Cn_a20_lef - Cn_lef - c.dCn_a20;
+    c.dCl_a20 = Cl_a20 - Cl0;
+    c.dCl_a20_lef = Cl_a20_lef - Cl_lef - c.dCl_a20;
+  }
+  // ---- G1A: damping derivatives + brett corrections on ALPHA1
+  {
+    TP p = T + OFF_G1A + a1.j * S_G1A;
+    c.Cxq = lerp(p[0], p[S_G1A + 0], a1);
+    c.Cyr = lerp(p[1], p[S_G1A + 1], a1);
+    c.Cyp = lerp(p[2], p[S_G1A + 2], a1);
+    c.Czq = lerp(p[3], p[S_G1A + 3], a1);
+    // reference defect kept by default: _CLr's table is never read from disk
+    // (C/hifi_F16_AeroData.c:964-972: the fscanf loop is the body of `if(fp==NULL)`), so the
+    // reference interpolates uninitialised heap memory (observed ~1e-310) == 0 numerically.
+    c.Clr = (flags & FLAG_FIX_CLR) ? lerp(p[4], p[S_G1A + 4], a1) : 0.0;
+    c.Clp = lerp(p[5], p[S_G1A + 5], a1);
+    c.Cmq = lerp(p[6], p[S_G1A + 6], a1);
+    c.Cnr = lerp(p[7], p[S_G1A + 7], a1);
+    c.Cnp = lerp(p[8], p[S_G1A + 8], a1);
+    c.dCnbeta = lerp(p[9], p[S_G1A + 9], a1);
+    c.dClbeta = lerp(p[10], p[S_G1A + 10], a1);
+    c.dCm = lerp(p[11], p[S_G1A + 11], a1);
+  }
+  // ---- G1B: lef damping increments on ALPHA2
+  {
+    TP p = T + OFF_G1B + a2.j * S_G1B;
+    c.dCxq_lef = lerp(p[0], p[S_G1B + 0], a2);
+    c.dCyr_lef = lerp(p[1], p[S_G1B + 1], a2);
+    c.dCyp_lef = lerp(p[2], p[S_G1B + 2], a2);
+    c.dCzq_lef = lerp(p[3], p[S_G1B + 3], a2);
+    c.dClr_lef = lerp(p[4], p[S_G1B + 4], a2);
+    c.dClp_lef = lerp(p[5], p[S_G1B + 5], a2);
+    c.dCmq_lef = lerp(p[6], p[S_G1B + 6], a2);
+    c.dCnr_lef = lerp(p[7], p[S_G1B + 7], a2);
+    c.dCnp_lef = lerp(p[8], p[S_G1B + 8], a2);
+  }
+  c.eta_el = lerp(T[OFF_ETA + d1.j], T[OFF_ETA + d1.j + 1], d1);
+}
+
+// ---- lofi (C/lofi_F16_AeroData.c), tables in global/constant memory ---------------------------
+F16_DEV int sgn_i(double v) { return (v > 0) - (v < 0); }
+F16_DEV int fix_i(double v) { return (int)trunc(v); }
+
+struct LofiAlpha { int k, L; double da; };
+F16_DEV LofiAlpha lofi_alpha(double alpha) {   // :31-45
+  const double s = .2 * alpha;
+  int k = fix_i(s);
+  if (k <= -2) k = -1; else if (k >= 9) k = 8;
+  LofiAlpha r;
+  r.da = s - k;
+  r.L = k + fix_i(1.1 * sgn_i(r.da)) + 3;
+  r.k = k + 3;
+  return r;
+}
+F16_DEV double lofi_bilin(const double *T, int m, int n, const LofiAlpha &a, double db) {
+  const double t = T[(m - 1) * 12 + a.k - 1], u = T[(n - 1) * 12 + a.k - 1];
+  const double v = t + fabs(a.da) * (T[(m - 1) * 12 + a.L - 1] - t);
+  const double w = u + fabs(a.da) * (T[(n - 1) * 12 + a.L - 1] - u);
+  return v + (w - v) * db;
+}
+
+F16_DEV void aero_lofi(const double *__restrict__ LT, double alpha, double beta, double el, double dail, double drud,
+                       Aero &c, int &status) {
+  // off-table guard: the reference indexes outside its arrays for alpha < -10, alpha > 45, |beta| >= 30
+  if (!(alpha >= -10.0 && alpha <= 45.0)) status |= ST_ALPHA1;
+  if (!(fabs(beta) < 30.0)) status |= ST_BETA;
+  if (!(fabs(el) <= 25.0)) status |= ST_EL;
+  alpha = fmin(fmax(alpha, -10.0), 45.0);
+  const LofiAlpha a = lofi_alpha(alpha);
+  {  // damping :12-56
+    const double *A = LT + LOFI_DAMP;
+    double d[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d[i] = A[i * 12 + a.k - 1] + fabs(a.da) * (A[i * 12 + a.L - 1] - A[i * 12 + a.k - 1]);
+    c.Cxq = d[0]; c.Cyr = d[1]; c.Cyp = d[2]; c.Czq = d[3]; c.Clr = d[4]; c.Clp = d[5]; c.Cmq = d[6]; c.Cnr = d[7]; c.Cnp = d[8];
+  }
+  {  // dmomdcon :59-183
+    const double s = 0.2 * fabs(beta);
+    int m = fix_i(s);
+    if (m >= 7) m = 6;
+    const double db = s - m;
+    int n = m + 1;
+    m = m + 1; n = n + 1;
+    if (n > 7) n = 7;
+    c.dCl_a20 = lofi_bilin(LT + LOFI_DLDA, m, n, a, db);
+    c.dCl_r30 = lofi_bilin(LT + LOFI_DLDR, m, n, a, db);
+    c.dCn_a20 = lofi_bilin(LT + LOFI_DNDA, m, n, a, db);
+    c.dCn_r30 = lofi_bilin(LT + LOFI_DNDR, m, n, a, db);
+  }
+  {  // clcn :185-262
+    const double s = .2 * fabs(beta);
+    int m = fix_i(s);
+    if (m == 0) m = 1; else if (m >= 6) m = 5;
+    const double db = s - m;
+    int n = m + fix_i(1.1 * sgn_i(db));
+    m = m + 1; n = n + 1;
+    c.Cl = lofi_bilin(LT + LOFI_CL, m, n, a, fabs(db)) * sgn_i(beta);
+    c.Cn = lofi_bilin(LT + LOFI_CN, m, n, a, fabs(db)) * sgn_i(beta);
+  }
+  {  // cxcm :265-336
+    const double s = el / 12.0;
+    int m = fix_i(s);
+    if (m <= -2) m = -1; else if (m >= 2) m = 1;
+    const double de = s - m;
+    int n = m + fix_i(1.1 * sgn_i(de));
+    m = m + 3; n = n + 3;
+    n = min(max(n, 1), 5);
+    c.Cx = lofi_bilin(LT + LOFI_CX, m, n, a, fabs(de));
+    c.Cm = lofi_bilin(LT + LOFI_CM, m, n, a, fabs(de));
+  }
+  c.Cy = -.02 * beta + .021 * dail + .086 * drud;   // nlplant.c:283
+  {  // cz :339-368
+    const double *A = LT + LOFI_CZ;
+    const double s = A[a.k - 1] + fabs(a.da) * (A[a.L - 1] - A[a.k - 1]);
+    const double b573 = beta / 57.3;
+    c.Cz = s * (1 - b573 * b573) - .19 * (el) / 25;
+  }
+  // nlplant.c:295-319
+  c.dCx_lef = c.dCz_lef = c.dCm_lef = c.dCy_lef = c.dCn_lef = c.dCl_lef = 0.0;
+  c.dCxq_lef = c.dCyr_lef = c.dCyp_lef = c.dCzq_lef = c.dClr_lef = c.dClp_lef = c.dCmq_lef = c.dCnr_lef = c.dCnp_lef = 0.0;
+  c.dCy_r30 = c.dCy_a20 = c.dCy_a20_lef = c.dCn_a20_lef = c.dCl_a20_lef = 0.0;
+  c.dCnbeta = c.dClbeta = c.dCm = 0.0;
+  c.eta_el = 1.0;
+}
+
+// C/nlplant.c:23-457.  xu[0..16] in, xdot[0..11] out (+ xdot[12..17] = nx,ny,nz,mach,qbar,ps when
+// OUTPUTS).  Returns mach/qbar/ps of the clamped-vt atmosphere call for reuse by the lef model.
+template <bool OUTPUTS, typename TP>
+F16_DEV void plant(TP T, const double *__restrict__ LT, const double *xu, double *xdot, double xcg, int fi_flag,
+                   unsigned flags, int &status, double &qbar_out, double &ps_out) {
+  const double g = 32.17, m = 636.94, B = 30.0, S = 300.0, cbar = 11.32, xcgr = 0.35;
+  const double Heng = 0.0;
+  const double Jy = 55814.0, Jxz = 982.0, Jz = 63100.0, Jx = 9496.0;
+  const double r2d = 180.0 / 3.141592653589793;   // 180.0/acos(-1)
+
+  const double alt = xu[2], phi = xu[3], theta = xu[4], psi = xu[5];
+  double vt = xu[6];
+  const double alpha = xu[7] * r2d, beta = xu[8] * r2d;
+  const double P = xu[9], Q = xu[10], R = xu[11];
+  double sa, ca, sb, cb, st, ct, sphi, cphi, spsi, cpsi;
+  sincos(xu[7], &sa, &ca);
+  sincos(xu[8], &sb, &cb);
+  sincos(theta, &st, &ct);
+  sincos(phi, &sphi, &cphi);
+  sincos(psi, &spsi, &cpsi);
+  const double tt = tan(theta);
+  if (vt <= 0.01) vt = 0.01;
+
+  const double Thr = xu[12], el = xu[13], ail = xu[14], rud = xu[15], lef = xu[16];
+  const double dail = ail / 21.5;
+  const double drud = rud / 30.0;
+  double dlef = (1 - lef / 25.0);
+
+  double mach, qbar, ps;
+  atmos_dev(alt, vt, mach, qbar, ps);
+  qbar_out = qbar; ps_out = ps;
+
+  const double U = vt * ca * cb, V = vt * sb, W = vt * sa * cb;
+  xdot[0] = U * (ct * cpsi) + V * (sphi * cpsi * st - cphi * spsi) + W * (cphi * st * cpsi + sphi * spsi);
+  xdot[1] = U * (ct * spsi) + V * (sphi * spsi * st + cphi * cpsi) + W * (cphi * st * spsi - sphi * cpsi);
+  xdot[2] = U * st - V * (sphi * ct) - W * (cphi * ct);
+  xdot[3] = P + tt * (Q * sphi + R * cphi);
+  xdot[4] = Q * cphi - R * sphi;
+  xdot[5] = (Q * sphi + R * cphi) / ct;
+
+  Aero c;
+  if (fi_flag == 1) {
+    aero_hifi(T, alpha, beta, el, flags, c, status);
+  } else {
+    dlef = 0.0;
+    aero_lofi(LT, alpha, beta, el, dail, drud, c, status);
+  }
+
+  // totals, C/nlplant.c:333-377 (dZdQ uses delta_Cz_lef, as the reference does)
+  const double dXdQ = (cbar / (2 * vt)) * (c.Cxq + c.dCxq_lef * dlef);
+  const double Cx_tot = c.Cx + c.dCx_lef * dlef + dXdQ * Q;
+  const double dZdQ = (cbar / (2 * vt)) * (c.Czq + c.dCz_lef * dlef);
+  const double Cz_tot = c.Cz + c.dCz_lef * dlef + dZdQ * Q;
+  const double dMdQ = (cbar / (2 * vt)) * (c.Cmq + c.dCmq_lef * dlef);
+  const double Cm_tot = c.Cm * c.eta_el + Cz_tot * (xcgr - xcg) + c.dCm_lef * dlef + dMdQ * Q + c.dCm;
+  const double dYdail = c.dCy_a20 + c.dCy_a20_lef * dlef;
+  const double dYdR = (B / (2 * vt)) * (c.Cyr + c.dCyr_lef * dlef);
+  const double dYdP = (B / (2 * vt)) * (c.Cyp + c.dCyp_lef * dlef);
+  const double Cy_tot = c.Cy + c.dCy_lef * dlef + dYdail * dail + c.dCy_r30 * drud + dYdR * R + dYdP * P;
+  const double dNdail = c.dCn_a20 + c.dCn_a20_lef * dlef;
+  const double dNdR = (B / (2 * vt)) * (c.Cnr + c.dCnr_lef * dlef);
+  const double dNdP = (B / (2 * vt)) * (c.Cnp + c.dCnp_lef * dlef);
+  const double Cn_tot = c.Cn + c.dCn_lef * dlef - Cy_tot * (xcgr - xcg) * (cbar / B) + dNdail * dail + c.dCn_r30 * drud +
+                        dNdR * R + dNdP * P + c.dCnbeta * beta;
+  const double dLdail = c.dCl_a20 + c.dCl_a20_lef * dlef;
+  const double dLdR = (B / (2 * vt)) * (c.Clr + c.dClr_lef * dlef);
+  const double dLdP = (B / (2 * vt)) * (c.Clp + c.dClp_lef * dlef);
+  const double Cl_tot = c.Cl + c.dCl_lef * dlef + dLdail * dail + c.dCl_r30 * drud + dLdR * R + dLdP * P + c.dClbeta * beta;
+
+  const double Udot = R * V - Q * W - g * st + qbar * S * Cx_tot / m + Thr / m;
+  const double Vdot = P * W - R * U + g * ct * sphi + qbar * S * Cy_tot / m;
+  const double Wdot = Q * U - P * V + g * ct * cphi + qbar * S * Cz_tot / m;
+  xdot[6] = (U * Udot + V * Vdot + W * Wdot) / vt;
+  xdot[7] = (U * Wdot - W * Udot) / (U * U + W * W);
+  xdot[8] = (Vdot * vt - V * xdot[6]) / (vt * vt * cb);
+
+  const double L_tot = Cl_tot * qbar * S * B;
+  const double M_tot = Cm_tot * qbar * S * cbar;
+  const double N_tot = Cn_tot * qbar * S * B;
+  const double denom = Jx * Jz - Jxz * Jxz;
+  xdot[9] = (Jz * L_tot + Jxz * N_tot - (Jz * (Jz - Jy) + Jxz * Jxz) * Q * R + Jxz * (Jx - Jy + Jz) * P * Q + Jxz * Q * Heng) / denom;
+  xdot[10] = (M_tot + (Jz - Jx) * P * R - Jxz * (P * P - R * R) - R * Heng) / Jy;
+  xdot[11] = (Jx * N_tot + Jxz * L_tot + (Jx * (Jx - Jy) + Jxz * Jxz) * P * Q - Jxz * (Jx - Jy + Jz) * Q * R + Jx * Q * Heng) / denom;
+
+  if (OUTPUTS) {  // accels(), C/nlplant.c:512-552 (uses the UNclamped state[6])
+    const double grav = 32.174;
+    const double v6 = xu[6];
+    const double vel_u = v6 * cb * ca, vel_v = v6 * sb, vel_w = v6 * cb * sa;
+    const double u_dot = cb * ca * xdot[6] - v6 * sb * ca * xdot[8] - v6 * cb * sa * xdot[7];
+    const double v_dot = sb * xdot[6] + v6 * cb * xdot[8];
+    const double w_dot = cb * sa * xdot[6] - v6 * sb * sa * xdot[8] + v6 * cb * ca * xdot[7];
+    xdot[12] = 1.0 / grav * (u_dot + Q * vel_w - R * vel_v) + st;
+    xdot[13] = 1.0 / grav * (v_dot + R * vel_u - P * vel_w) - ct * sphi;
+    xdot[14] = -1.0 / grav * (w_dot + P * vel_v - Q * vel_u) + ct * cphi;
+    xdot[15] = mach;
+    xdot[16] = qbar;
+    xdot[17] = ps;
+  }
+}
+
+F16_DEV double clipd(double a, double lo, double hi) { return fmin(fmax(a, lo), hi); }
+
+// utils.py:289-306 -> lf1_dot (7.25*LF_err), lf2_dot (lef_err).  qbar/ps are those of atmos(h, V) with the
+// RAW V (utils.py:291); plant() evaluates atmos with vt clamped to >= 0.01, identical whenever V > 0.01.
+F16_DEV void upd_lef_dev(double h, double V, double alpha, double lf1, double lf2, double qbar_p, double ps_p,
+                         double &lf1_dot, double &lf2_dot) {
+  double qbar = qbar_p, ps = ps_p;
+  if (V <= 0.01) {
+    double mach;
+    atmos_dev(h, V, mach, qbar, ps);
+  }
+  const double atmos_out = qbar / ps * 9.05;
+  const double alpha_deg = alpha * 180 / 3.141592653589793;
+  const double LF_err = alpha_deg - (lf1 + (2 * alpha_deg));
+  const double LF_out = (lf1 + (2 * alpha_deg)) * 1.38;
+  double lef_cmd = LF_out + 1.45 - atmos_out;
+  lef_cmd = clipd(lef_cmd, 0., 25);
+  lf2_dot = clipd((1 / 0.136) * (lef_cmd - lf2), -25, 25);
+  lf1_dot = LF_err * 7.25;
+}
+
+// env.py:65-103: xdot[18] of the full actuated model.
+template <typename TP>
+F16_DEV void calc_xdot(TP T, const double *__restrict__ LT, const double *x, const double *u, double *xdot, double xcg,
+                       int fi_flag, unsigned flags, int &status) {
+  double qbar, ps;
+  plant<false>(T, LT, x, xdot, xcg, fi_flag, flags, status, qbar, ps);
+  xdot[12] = clipd(clipd(u[0], 1000, 19000) - x[12], -10000, 10000);      // utils.py:308-312
+  xdot[13] = clipd(20.2 * (clipd(u[1], -25, 25) - x[13]), -60, 60);       // :314-318
+  xdot[14] = clipd(20.2 * (clipd(u[2], -21.5, 21.5) - x[14]), -80, 80);   // :320-324
+  xdot[15] = clipd(20.2 * (clipd(u[3], -30., 30) - x[15]), -120, 120);    // :326-330
+  double lf1_dot, lf2_dot;
+  upd_lef_dev(x[2], x[6], x[7], x[17], x[16], qbar, ps, lf1_dot, lf2_dot);
+  xdot[16] = lf2_dot;   // env.py:98,102: temp[4] -> xdot[16]
+  xdot[17] = lf1_dot;
+}
+
+// env.py:152-193: sv = full state with the 9 MPC states / 3 actuator positions already scattered in.
+// Returns the 9 derivatives in MPC order {phi,theta,alpha,beta,p,q,r,lf1,lf2}; the two lef derivatives
+// land swapped exactly as in the reference (env.py:184,189 vs :98,102).
+template <typename TP>
+F16_DEV void calc_xdot_na(TP T, const double *__restrict__ LT, const double *sv, double *xdot9, double xcg, int fi_flag,
+                          unsigned flags, int &status) {
+  double xd[12], qbar, ps;
+  plant<false>(T, LT, sv, xd, xcg, fi_flag, flags, status, qbar, ps);
+  double lf1_dot, lf2_dot;
+  upd_lef_dev(sv[2], sv[6], sv[7], sv[17], sv[16], qbar, ps, lf1_dot, lf2_dot);
+  xdot9[0] = xd[3]; xdot9[1] = xd[4]; xdot9[2] = xd[7]; xdot9[3] = xd[8];
+  xdot9[4] = xd[9]; xdot9[5] = xd[10]; xdot9[6] = xd[11];
+  xdot9[7] = lf2_dot;   // state_vector_dot[17] = lf_state2_dot
+  xdot9[8] = lf1_dot;   // state_vector_dot[16] = lf_state1_dot
+}
+
+// env.py:117-124 box check (parameters.py:122-123, mixed units as in the reference)
+F16_DEV bool outside_envelope(const double *x) {
+  bool bad = x[2] < 0 || x[2] > 100000 || x[6] < 0 || x[6] > 900 || x[7] < -20. || x[7] > 90 || x[8] < -30. || x[8] > 30 ||
+             x[9] < -300 || x[9] > 300 || x[10] < -100 || x[10] > 100 || x[11] < -50 || x[11] > 50 || x[12] < 1000 ||
+             x[12] > 19000 || x[13] < -25 || x[13] > 25 || x[14] < -21.5 || x[14] > 21.5 || x[15] < -30. || x[15] > 30 ||
+             x[16] < 0. || x[16] > 25;
+  return bad;
+}
+
+}  // namespace f16

@@ -1,0 +1,246 @@
+"""Batched mirror of the reference's `F16` environment (env.py:29-436).
+
+Same method names and argument meaning as the reference class, over a leading batch dimension B:
+`step / reset / get_obs / _calc_xdot / _calc_xdot_na / linearise / _calc_LQR_gain /
+_calc_LQR_action / _calc_MPC_action (calc_MPC_action)`.  Where the reference holds one
+`x.values[18]` NumPy vector and calls `nlplant.Nlplant` through ctypes once per evaluation
+(env.py:100), this class holds the states of B aircraft resident in HBM, state-major
+([18, B] fp64, so that a wavefront's 64 lanes read contiguous memory), and calls the batched
+entry points of libf16hip.so through the same ctypes mechanism.  torch is used only to own
+device memory and streams.  There is no CPU path in this class.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from . import parameters as P
+
+
+def _vp(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class F16Batch:
+    def __init__(self, x0, u0=None, *, stab_flag=None, xcg=None, fi_flag=P.fi_flag, dt=P.dt, device="cuda:0",
+                 flags=0, context=None):
+        """x0: [B,18] (or [18]) initial states in the reference's state order/units
+        (parameters.py:116-119); u0: [B,4] inputs, default = x0[:,12:16] (env.py:43).
+        stab_flag / xcg: parameters.py:31 (1 -> 0.35) or an explicit value."""
+        if not torch.cuda.is_available():
+            raise _lib.F16HipError("F16Batch needs an AMD GPU (no CPU fallback)")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.ctx = context or _lib.Context(self.device.index or 0)
+        self.lib = self.ctx.lib
+        self.xcg = float(xcg) if xcg is not None else P.xcg_of(P.stab_flag if stab_flag is None else stab_flag)
+        self.fi_flag = int(fi_flag)
+        self.dt = float(dt)
+        self.flags = int(flags)
+        x0 = torch.as_tensor(np.atleast_2d(np.asarray(x0, dtype=np.float64)))
+        self.B = x0.shape[0]
+        assert x0.shape[1] == 18
+        u0 = x0[:, 12:16] if u0 is None else torch.as_tensor(np.atleast_2d(np.asarray(u0, dtype=np.float64)))
+        self._x_init = self._soa(x0)            # x.initial_condition
+        self._u_init = self._soa(u0)            # u.initial_condition
+        self._x = self._x_init.clone()          # x.values  [18,B]
+        self._u = self._u_init.clone()          # u.values  [4,B]
+        self.status = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        self.ssr = None                         # (Ad,Bd,Cd) per aircraft once linearised (env.py:49-60)
+
+    # ------------------------------------------------------------------ helpers
+    def _soa(self, a, rows=None):
+        """[B,k] (or [k], broadcast) host/device array -> contiguous state-major [k,B] fp64 on the GPU."""
+        t = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float64))
+        t = t.to(device=self.device, dtype=torch.float64)
+        if t.dim() == 1:
+            t = t.unsqueeze(0).expand(self.B, -1)
+        if rows is not None:
+            assert t.shape[1] == rows, (tuple(t.shape), rows)
+        return t.t().contiguous()
+
+    @property
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check(self, rc):
+        _lib.check(rc, self.lib)
+
+    # x.values / u.values as [B,18] / [B,4] views of the resident state
+    @property
+    def x_values(self):
+        return self._x.t()
+
+    @property
+    def u_values(self):
+        return self._u.t()
+
+    def set_state(self, x):
+        self._x.copy_(self._soa(x, 18))
+
+    def set_input(self, u):
+        self._u.copy_(self._soa(u, 4))
+
+    # ------------------------------------------------------------------ env.py:132-150
+    def reset(self):
+        self._x.copy_(self._x_init)
+        self._u.copy_(self._u_init)
+        self.status.zero_()
+        return self.get_obs(self._x, self._u)
+
+    def get_obs(self, x=None, u=None):
+        """Observed states x[_obs_x_idx] (parameters.py:134,160) -> [B,10]."""
+        x = self._x if x is None else x
+        return x[P.obs_x_idx].t()
+
+    def _get_obs_na(self, x9, u=None):
+        return x9
+
+    # ------------------------------------------------------------------ env.py:65-103
+    def _calc_xdot(self, x=None, u=None):
+        """xdot [B,18] for states x [B,18] and inputs u [B,4] (defaults: resident x.values/u.values)."""
+        xs = self._x if x is None else self._soa(x, 18)
+        us = self._u if u is None else self._soa(u, 4)
+        out = torch.empty_like(xs)
+        st = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        self._check(self.lib.f16_xdot_batch(self.ctx.handle, _vp(xs), _vp(us), _vp(out), _vp(st), self.B, self.B,
+                                            self.xcg, self.fi_flag, self.flags, self._stream))
+        self.last_status = st
+        return out.t()
+
+    def nlplant(self, xu):
+        """C/nlplant.c:23 for B aircraft: xu [B,>=17] -> xdot [B,18] (12..17 = nx,ny,nz,mach,qbar,ps)."""
+        xs = self._soa(torch.as_tensor(np.asarray(xu, dtype=np.float64))[:, :18] if not isinstance(xu, torch.Tensor) else xu[:, :18])
+        out = torch.empty((18, self.B), dtype=torch.float64, device=self.device)
+        st = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        self._check(self.lib.f16_nlplant_batch(self.ctx.handle, _vp(xs), _vp(out), _vp(st), self.B, self.B, self.xcg,
+                                               self.fi_flag, self.flags, self._stream))
+        self.last_status = st
+        return out.t()
+
+    # ------------------------------------------------------------------ env.py:105-130
+    def step(self, action=None):
+        """One explicit-Euler step of every aircraft (env.py:126).  Returns (obs [B,10], reward, done, info) like
+        the reference; where the reference exit()s on an envelope violation (env.py:121-124) the aircraft is frozen
+        and `done[b]` is set (status bit F16_ST_ENVELOPE)."""
+        self.rollout(1, action)
+        done = (self.status & _lib.F16_ST["ENVELOPE"]) != 0
+        reward = torch.ones(self.B, dtype=torch.float64, device=self.device)
+        info = {"fidelity": "high" if self.fi_flag == 1 else "low", "status": self.status}
+        return self.get_obs(), reward, done, info
+
+    def rollout(self, nsteps, action=None, traj_every=None):
+        """nsteps Euler steps in ONE launch with the state held in registers (the reference's
+        `for ...: self.step(u)` loops, test_env.py:456-462).  traj_every=k stores the state after every k-th
+        step and returns it as [nsteps//k, 18, B] (state-major)."""
+        us = self._u if action is None else self._soa(action, 4)
+        traj = None
+        if traj_every:
+            assert nsteps % traj_every == 0
+            traj = torch.empty((nsteps // traj_every, 18, self.B), dtype=torch.float64, device=self.device)
+        self._check(self.lib.f16_rollout(self.ctx.handle, _vp(self._x), _vp(us), _vp(traj), _vp(self.status), self.B,
+                                         self.B, int(nsteps), int(traj_every or 1), self.dt, self.xcg, self.fi_flag,
+                                         self.flags, self._stream))
+        return traj
+
+    # ------------------------------------------------------------------ env.py:152-193
+    def _get_mpc_x(self):
+        return self._x[P.mpc_x_idx].t()
+
+    def _get_mpc_u(self):
+        return self._u[P.mpc_u_idx].t()
+
+    def _get_mpc_act_states(self):
+        return self._x[P.mpc_u_states_idx].t()
+
+    def _calc_xdot_na(self, x9, u3):
+        """x9 [B,9] MPC states, u3 [B,3] actuator positions -> xdot9 [B,9] (other states from x.values)."""
+        x9s, u3s = self._soa(x9, 9), self._soa(u3, 3)
+        out = torch.empty_like(x9s)
+        st = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        self._check(self.lib.f16_xdot_na_batch(self.ctx.handle, _vp(self._x), _vp(x9s), _vp(u3s), _vp(out), _vp(st),
+                                               self.B, self.B, self.xcg, self.fi_flag, self.flags, self._stream))
+        self.last_status = st
+        return out.t()
+
+    # ------------------------------------------------------------------ env.py:294-358
+    def linearise(self, eps=1e-5):
+        """Forward-difference linearisation of the reduced (9-state) model at every aircraft's own state
+        (env.py:294-342 with _calc_xdot_na/_get_obs_na).  Returns Ac [B,9,9], Bc [B,9,3], Cc [B,9,9], Dc [B,9,3]."""
+        Ac = torch.empty((81, self.B), dtype=torch.float64, device=self.device)
+        Bc = torch.empty((27, self.B), dtype=torch.float64, device=self.device)
+        Cc = torch.empty((81, self.B), dtype=torch.float64, device=self.device)
+        st = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        self._check(self.lib.f16_linearise_batch(self.ctx.handle, _vp(self._x), _vp(Ac), _vp(Bc), _vp(Cc), _vp(st),
+                                                 self.B, self.B, eps, self.xcg, self.fi_flag, self.flags, self._stream))
+        self.last_status = st
+        self._lin = (Ac, Bc, Cc)
+        return (Ac.t().reshape(self.B, 9, 9), Bc.t().reshape(self.B, 9, 3), Cc.t().reshape(self.B, 9, 9),
+                torch.zeros((self.B, 9, 3), dtype=torch.float64, device=self.device))
+
+    def discretise(self, Ac=None, Bc=None):
+        """scipy.signal.cont2discrete(..., dt) zero-order hold (env.py:50,351) per aircraft."""
+        if Ac is None:
+            Ac, Bc, _ = self._lin
+        else:
+            Ac = Ac.reshape(self.B, 81).t().contiguous()
+            Bc = Bc.reshape(self.B, 27).t().contiguous()
+        Ad, Bd = torch.empty_like(Ac), torch.empty_like(Bc)
+        self._check(self.lib.f16_c2d_batch(self.ctx.handle, _vp(Ac), _vp(Bc), _vp(Ad), _vp(Bd), self.B, self.B, self.dt,
+                                           self._stream))
+        return Ad, Bd
+
+    def build_ssr(self, eps=1e-5):
+        """env.py:49-60: reduced discrete model per aircraft, frozen until called again."""
+        self.linearise(eps)
+        Ad, Bd = self.discretise()
+        self.ssr = (Ad, Bd, self._lin[2])
+        return self.ssr
+
+    def _calc_LQR_gain(self):
+        """env.py:344-358: linearise -> ZOH -> K = -dlqr(Ad,Bd,Cd'Cd,I).  Returns K [B,3,9]."""
+        Ad, Bd, Cd = self.build_ssr()
+        K = torch.empty((27, self.B), dtype=torch.float64, device=self.device)
+        st = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        self._check(self.lib.f16_lqr_batch(self.ctx.handle, _vp(Ad), _vp(Bd), _vp(Cd), _vp(K), None, _vp(st), self.B,
+                                           self.B, self._stream))
+        self.last_status = st
+        return K.t().reshape(self.B, 3, 9)
+
+    def _calc_LQR_action(self, p_dem, q_dem, r_dem, K, x, u0):
+        """env.py:360-371: u = -K (x_ref - x) + u0 with x_ref[4:7] = demands.  x [B,9], u0 [B,3]."""
+        x = torch.as_tensor(x, device=self.device, dtype=torch.float64)
+        u0 = torch.as_tensor(u0, device=self.device, dtype=torch.float64)
+        x_ref = x.clone()
+        x_ref[:, 4], x_ref[:, 5], x_ref[:, 6] = p_dem, q_dem, r_dem
+        return -(K @ (x_ref - x).unsqueeze(-1)).squeeze(-1) + u0
+
+    # ------------------------------------------------------------------ env.py:373-424
+    def _calc_MPC_action(self, p_dem, q_dem, r_dem, hzn, settings=None, return_info=False):
+        """First MPC move [B,3] (dh,da,dr commands) for demands p,q,r (scalars or [B]) over horizon hzn, from the
+        frozen reduced model self.ssr (env.py:385-387) and the current state.  The QP of utils.py:21-167 is solved
+        on the GPU by OSQP-style ADMM (the reference calls the `osqp` package, env.py:420-422)."""
+        if self.ssr is None:
+            self.build_ssr()
+        Ad, Bd, Cd = self.ssr
+        dem = torch.empty((3, self.B), dtype=torch.float64, device=self.device)
+        for k, v in enumerate((p_dem, q_dem, r_dem)):
+            dem[k] = torch.as_tensor(v, dtype=torch.float64, device=self.device)
+        ucmd = torch.empty((3, self.B), dtype=torch.float64, device=self.device)
+        info = torch.empty((4, self.B), dtype=torch.float64, device=self.device)
+        useq = torch.empty((3 * hzn, self.B), dtype=torch.float64, device=self.device) if return_info else None
+        st = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        s = _lib.QPSettings()
+        self.lib.f16_qp_default_settings(ctypes.byref(s))
+        for k, v in (settings or {}).items():
+            setattr(s, k, v)
+        self._check(self.lib.f16_mpc_batch(self.ctx.handle, _vp(Ad), _vp(Bd), _vp(Cd), _vp(self._x), _vp(dem), _vp(ucmd),
+                                           _vp(useq), _vp(info), _vp(st), self.B, self.B, int(hzn), self.dt,
+                                           ctypes.byref(s), self._stream))
+        self.last_status = st
+        if return_info:
+            return ucmd.t(), dict(iters=info[0], r_prim=info[1], r_dual=info[2], rho=info[3], u_seq=useq.t(), status=st)
+        return ucmd.t()
+
+    calc_MPC_action = _calc_MPC_action

@@ -1,0 +1,113 @@
+"""ctypes binding of libf16hip.so (the C-ABI declared in include/f16_hip.h).
+
+This is the same mechanism the reference uses for its plant: `ctypes.CDLL(<.so>)`
+(parameters.py:108-114).  There is no CPU fallback: if the HIP library is missing or no GPU
+is visible every entry point raises.
+"""
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO_PATH = os.path.join(HERE, "libf16hip.so")
+SOURCES = ["f16_api.hip", "f16_dynamics.hip", "f16_control.hip", "f16_tables.cpp"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-Wno-unused-result"]
+
+F16_ST = dict(ALPHA1=1, ALPHA2=2, BETA=4, EL=8, ENVELOPE=16, NONFINITE=32, QP_MAXITER=64)
+F16_FLAG_FIX_CLR = 1
+F16_FLAG_NO_ENVELOPE = 2
+
+
+class F16HipError(RuntimeError):
+    pass
+
+
+class QPSettings(ctypes.Structure):
+    _fields_ = [("rho", ctypes.c_double), ("sigma", ctypes.c_double), ("alpha", ctypes.c_double),
+                ("eps_abs", ctypes.c_double), ("eps_rel", ctypes.c_double), ("max_iter", ctypes.c_int),
+                ("check_every", ctypes.c_int), ("rho_every", ctypes.c_int), ("adaptive_rho", ctypes.c_int)]
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into the in-tree libf16hip.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".inc"))]
+    deps.append(os.path.join(HERE, "..", "include", "f16_hip.h"))
+    if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", SO_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+_LIB = None
+
+
+def load():
+    """Load libf16hip.so once.  torch is imported first so that both share ONE HIP runtime
+    (same libamdhip64 SONAME): device pointers from torch tensors are valid in our kernels."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    import torch  # noqa: F401  (must precede CDLL, see docstring)
+    if not os.path.exists(SO_PATH):
+        raise F16HipError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = ctypes.CDLL(SO_PATH)
+    vp, d, i, l, u = ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_long, ctypes.c_uint
+    L.f16_create.argtypes = [ctypes.POINTER(vp), i]
+    L.f16_destroy.argtypes = [vp]
+    L.f16_last_error.restype = ctypes.c_char_p
+    L.f16_table_image_doubles.restype = ctypes.c_size_t
+    L.f16_debug_read_tables.argtypes = [vp, vp]
+    L.Nlplant.argtypes = [vp, vp, i]
+    L.Nlplant.restype = None
+    L.atmos.argtypes = [d, d, vp]
+    L.atmos.restype = None
+    L.f16_dropin_config.argtypes = [d, u]
+    L.f16_dropin_config.restype = None
+    L.f16_xdot_batch.argtypes = [vp, vp, vp, vp, vp, l, l, d, i, u, vp]
+    L.f16_nlplant_batch.argtypes = [vp, vp, vp, vp, l, l, d, i, u, vp]
+    L.f16_rollout.argtypes = [vp, vp, vp, vp, vp, l, l, i, i, d, d, i, u, vp]
+    L.f16_xdot_na_batch.argtypes = [vp, vp, vp, vp, vp, vp, l, l, d, i, u, vp]
+    if hasattr(L, "f16_linearise_batch"):
+        L.f16_linearise_batch.argtypes = [vp, vp, vp, vp, vp, vp, l, l, d, d, i, u, vp]
+        L.f16_c2d_batch.argtypes = [vp, vp, vp, vp, vp, l, l, d, vp]
+        L.f16_lqr_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, l, l, vp]
+        L.f16_qp_default_settings.argtypes = [ctypes.POINTER(QPSettings)]
+        L.f16_qp_default_settings.restype = None
+        L.f16_mpc_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, l, l, i, d, ctypes.POINTER(QPSettings), vp]
+        L.f16_mpc_qp_debug.argtypes = [vp, vp, vp, vp, vp, vp, l, l, i, d, vp, vp, vp, vp, vp]
+    _LIB = L
+    return L
+
+
+def check(rc, L=None):
+    if rc != 0:
+        L = L or load()
+        raise F16HipError(f"libf16hip error {rc}: {L.f16_last_error().decode()}")
+
+
+class Context:
+    """Owns one f16_ctx (device table image) on one GPU."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self.handle = ctypes.c_void_p()
+        check(self.lib.f16_create(ctypes.byref(self.handle), int(device)), self.lib)
+        self.device = int(device)
+
+    def close(self):
+        if self.handle:
+            self.lib.f16_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

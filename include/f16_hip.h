@@ -1,0 +1,126 @@
+/* include/f16_hip.h -- C-ABI of libf16hip.so: the MI355X (gfx950) replacement for the reference's
+ * ctypes boundary  CDLL("C/nlplant_xcg{25,35}.so")  (parameters.py:108-114; call sites env.py:100,
+ * env.py:187, utils.py:291).
+ *
+ * Two groups of entry points:
+ *  (1) the reference's own two symbols, same signatures, host pointers, synchronous -- so an
+ *      unmodified reference-style caller keeps working when its CDLL handle points here;
+ *  (2) batched entry points over DEVICE pointers for thousands of independent aircraft per
+ *      launch.  They replace the Python loops of env.py:105-130 (step), :65-103 (_calc_xdot),
+ *      :152-193 (_calc_xdot_na), :294-342 (linearise), :344-371 (LQR), :373-424 (MPC).
+ *
+ * Conventions for group (2)
+ *  - every pointer is a device pointer unless named h_*; nothing is retained after the call
+ *  - batched vectors are state-major ("SoA"): element k of aircraft b lives at  p[k*ld + b],
+ *    ld >= B (leading dimension, in doubles).  State order x[18] and input order u[4] are the
+ *    reference's (parameters.py:116-117).
+ *  - all arithmetic fp64; xcg is a run-time argument (the reference bakes it in at compile time,
+ *    C/nlplant.c:34, and ships two binaries); fi_flag 1 = hifi Nguyen, 0 = lofi Stevens-Lewis
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous
+ *  - return value: 0 on success, negative F16_E* on a host-side error (bad argument, HIP error);
+ *    per-aircraft conditions are reported in the int32 status[] words (sticky OR of F16_ST_* bits).
+ *    The reference has no error returns: it printf()s and runs into UB off-grid
+ *    (C/mexndinterp.c:121-124) and exit()s on an envelope violation (env.py:117-124).
+ */
+#ifndef F16_HIP_H
+#define F16_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct f16_ctx f16_ctx;
+
+/* host-side error codes */
+#define F16_OK 0
+#define F16_EINVAL (-1)   /* bad argument (NULL pointer, ld < B, unsupported size) */
+#define F16_EHIP (-2)     /* a HIP runtime call failed; see f16_last_error() */
+#define F16_ENOGPU (-3)   /* no gfx950 device visible */
+
+/* per-aircraft status bits */
+#define F16_ST_ALPHA1 1     /* alpha left the ALPHA1 grid [-20,90] deg: lookup clamped        */
+#define F16_ST_ALPHA2 2     /* alpha left the ALPHA2 grid [-20,45] deg (lef tables): clamped  */
+#define F16_ST_BETA 4       /* |beta| > 30 deg: clamped                                       */
+#define F16_ST_EL 8         /* |el| > 25 deg: clamped                                         */
+#define F16_ST_ENVELOPE 16  /* env.py:117-124 box check failed: aircraft frozen from then on  */
+#define F16_ST_NONFINITE 32 /* a state became NaN/Inf                                         */
+#define F16_ST_QP_MAXITER 64 /* ADMM hit max_iter before meeting the OSQP termination test    */
+
+/* behaviour flags */
+#define F16_FLAG_FIX_CLR 1u      /* use the real CLr table (reference never loads it: hifi_F16_AeroData.c:964-972) */
+#define F16_FLAG_NO_ENVELOPE 2u  /* skip the env.py:117-124 box check in step/rollout                               */
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+/* Builds the fp64 table image (int/1e5, IEEE division) and uploads it to `device`. */
+int f16_create(f16_ctx **out, int device);
+void f16_destroy(f16_ctx *ctx);
+const char *f16_last_error(void);
+/* bytes of LDS image / number of doubles, for tests and the roofline bookkeeping */
+size_t f16_table_image_doubles(void);
+/* copy the device table image back to host (tests): n = f16_table_image_doubles() */
+int f16_debug_read_tables(f16_ctx *ctx, double *h_out);
+
+/* ---- (1) drop-in symbols of the reference .so ---------------------------------------------- */
+/* replaces C/nlplant.c:23  void Nlplant(double *xu, double *xdot, int fidelity)
+ * host pointers; reads xu[0..16], writes xdot[0..17]; runs ONE aircraft on the GPU. */
+void Nlplant(double *xu, double *xdot, int fidelity);
+/* replaces C/nlplant.c:467 void atmos(double alt, double vt, double *coeff) -> coeff[0..2]=mach,qbar,ps */
+void atmos(double alt, double vt, double *coeff);
+/* replaces the choice between nlplant_xcg25.so / nlplant_xcg35.so (parameters.py:108-111) for the two
+ * symbols above; default 0.25.  flags as F16_FLAG_*. */
+void f16_dropin_config(double xcg, unsigned flags);
+
+/* ---- (2) batched dynamics --------------------------------------------------------------- */
+/* env.py:65-103 _calc_xdot for B aircraft: xdot[18][ld] = f(x[18][ld], u[4][ld]). status may be NULL. */
+int f16_xdot_batch(f16_ctx *ctx, const double *x, const double *u, double *xdot, int32_t *status,
+                   long B, long ld, double xcg, int fi_flag, unsigned flags, void *stream);
+/* C/nlplant.c:23-457 Nlplant itself (no actuator models, outputs 12..17 = nx,ny,nz,mach,qbar,ps). */
+int f16_nlplant_batch(f16_ctx *ctx, const double *xu, double *xdot, int32_t *status,
+                      long B, long ld, double xcg, int fi_flag, unsigned flags, void *stream);
+/* env.py:105-130 step, in place: envelope check, x += xdot*dt.  nsteps Euler steps per launch with the
+ * state held in registers; traj (may be NULL) receives the state after every `traj_every`-th step as
+ * [nsteps/traj_every][18][ld]. */
+int f16_rollout(f16_ctx *ctx, double *x, const double *u, double *traj, int32_t *status,
+                long B, long ld, int nsteps, int traj_every, double dt, double xcg, int fi_flag,
+                unsigned flags, void *stream);
+/* env.py:152-193 _calc_xdot_na: x9[9][ld], u3[3][ld] scattered over x_full[18][ld] -> xdot9[9][ld] */
+int f16_xdot_na_batch(f16_ctx *ctx, const double *x_full, const double *x9, const double *u3, double *xdot9,
+                      int32_t *status, long B, long ld, double xcg, int fi_flag, unsigned flags, void *stream);
+
+/* ---- (2) batched control chain ---------------------------------------------------------- */
+/* env.py:294-342 with _calc_xdot_na/_get_obs_na at each aircraft's own state x[18][ld] (x9 = x[mpc idx],
+ * u3 = x[13:16]): Ac[81][ld] Bc[27][ld] Cc[81][ld] (row-major element index = r*ncols+c), eps = 1e-5. */
+int f16_linearise_batch(f16_ctx *ctx, const double *x, double *Ac, double *Bc, double *Cc,
+                        int32_t *status, long B, long ld, double eps, double xcg, int fi_flag,
+                        unsigned flags, void *stream);
+/* scipy.signal.cont2discrete(zoh) (env.py:50,351): Ad[81][ld], Bd[27][ld] = expm([[A,B],[0,0]] dt) blocks */
+int f16_c2d_batch(f16_ctx *ctx, const double *Ac, const double *Bc, double *Ad, double *Bd,
+                  long B, long ld, double dt, void *stream);
+/* utils.py:219-245 dlqr with Q = Cd'Cd, R = I3 (env.py:353-356): K[27][ld] = -dlqr (3x9 row-major),
+ * Pare[81][ld] = DARE solution (may be NULL). */
+int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, double *K, double *Pare,
+                  int32_t *status, long B, long ld, void *stream);
+/* env.py:373-424 _calc_MPC_action for B aircraft: per aircraft (Ad,Bd,Cd) + current state x[18][ld]
+ * + demands dem[3][ld] (p,q,r; written to x_ref[5:8] exactly as the reference does) -> first move
+ * u_cmd[3][ld].  Dense condensed QP of horizon hzn (utils.py:21-167) solved by OSQP-style ADMM with the
+ * fixed settings in f16_qp_settings.  u_seq (may be NULL) gets the full [3*hzn][ld] sequence,
+ * info (may be NULL) gets [4][ld] = iterations, r_prim, r_dual, rho. */
+typedef struct f16_qp_settings {
+  double rho, sigma, alpha, eps_abs, eps_rel;
+  int max_iter, check_every, rho_every, adaptive_rho;
+} f16_qp_settings;
+void f16_qp_default_settings(f16_qp_settings *s);
+int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
+                  const double *dem, double *u_cmd, double *u_seq, double *info, int32_t *status,
+                  long B, long ld, int hzn, double dt, const f16_qp_settings *s, void *stream);
+/* utils.py:21-167 setup_OSQP alone for aircraft b (tests): h_P[n*n] h_q[n] h_A[(m rows)*n] h_l h_u on the
+ * host, n = 3*hzn, rows = 15*hzn, reference row order. */
+int f16_mpc_qp_debug(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
+                     const double *dem, long b, long ld, int hzn, double dt,
+                     double *h_P, double *h_q, double *h_A, double *h_l, double *h_u);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
