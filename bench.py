@@ -126,8 +126,8 @@ def bench_mpc(args, dev):
     """BASELINE config 4: B=4096, xcg=0.35, N=30, one calc_MPC_action per aircraft (linearised at its own state)."""
     import torch
     from f16_mpc_oop_py_amd import F16Batch
-    from f16_mpc_oop_py_amd.workload import config2_states
-    x0, u0 = config2_states(args.batch, seed=4)
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(args.batch)
     env = F16Batch(x0, u0, xcg=0.35, device=dev)
     env.build_ssr()
     env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn)

@@ -1,0 +1,753 @@
+// f16_control.hip -- batched control chain for gfx950: linearise -> ZOH -> DARE/LQR -> condensed QP -> ADMM.
+//
+//   k_linearise   env.py:294-342 (forward differences of _calc_xdot_na, eps 1e-5)          f16_linearise_batch
+//   k_c2d         scipy.signal.cont2discrete zoh = expm([[A,B],[0,0]] dt) (env.py:50,351)  f16_c2d_batch
+//   k_lqr         utils.py:219-245 dlqr (DARE + gain), Q = Cd'Cd, R = I (env.py:353-356)   f16_lqr_batch
+//   k_mpc         utils.py:21-167 setup_OSQP + the OSQP solve of env.py:420-424            f16_mpc_batch
+//
+// Mapping.  k_linearise: one lane per (aircraft, perturbed column), tables in LDS as in the dynamics kernels.
+// The other three: ONE WAVEFRONT PER AIRCRAFT (workgroup = 64 lanes); all per-aircraft matrices live in LDS:
+// 9x9 blocks row-major, the 3N x 3N KKT inverse as a packed lower triangle (conflict-free row reads, see
+// f16_smallmat.hpp).  The 9N x 3N prediction matrix CC of utils.py:171-197 is never formed: CC[i,j] = A^(i-j) B,
+// so CC*U and CC'*v are causal (adjoint) convolutions with the N blocks G_k = A^k B, and CC'QQ CC is built by a
+// diagonal recursion over the same blocks (DESIGN.md "QP build").
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include <mutex>
+#include <vector>
+
+#include "../../include/f16_hip.h"
+#include "f16_ctx.h"
+#include "f16_plant.hpp"
+#include "f16_smallmat.hpp"
+
+namespace f16 {
+
+// ------------------------------------------------------------------------------------ linearise
+struct LinArgs {
+  const double *tab, *lofi, *x, *u;
+  double *Ac, *Bc, *Cc;
+  int32_t *status;
+  long B, ld;
+  double eps, xcg;
+  int fi;
+  unsigned flags;
+};
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_linearise(LinArgs a) {
+  __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
+  if (a.fi == 1) {
+    const double2 *src = reinterpret_cast<const double2 *>(a.tab);
+    double2 *dst = reinterpret_cast<double2 *>(tab);
+    for (int i = threadIdx.x; i < TABLE_IMAGE_DOUBLES / 2; i += BLOCK) dst[i] = src[i];
+    __syncthreads();
+  }
+  const long total = a.B * 12;
+  for (long e = (long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long)gridDim.x * BLOCK) {
+    const int c = (int)(e / a.B);          // perturbed column: 0..8 MPC states, 9..11 inputs
+    const long b = e - (long)c * a.B;
+    double sv[18], svp[18], f0[9], f1[9];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) sv[k] = a.x[k * a.ld + b];
+    // env.py:175-177: the three MPC inputs (u.values[1:4]) overwrite the actuator positions
+    sv[13] = a.u[1 * a.ld + b]; sv[14] = a.u[2 * a.ld + b]; sv[15] = a.u[3 * a.ld + b];
+    // column -> full-state index: mpc_x_idx = [3,4,7,8,9,10,11,17,16], inputs -> [13,14,15]
+    const int idx = c == 0 ? 3 : c == 1 ? 4 : c == 2 ? 7 : c == 3 ? 8 : c == 4 ? 9 : c == 5 ? 10 : c == 6 ? 11
+                  : c == 7 ? 17 : c == 8 ? 16 : 13 + (c - 9);
+    double base = 0.0, pert = 0.0;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+      svp[k] = sv[k] + (k == idx ? a.eps : 0.0);      // x + dx with dx = eps*e_c (env.py:327-330)
+      if (k == idx) { base = sv[k]; pert = svp[k]; }
+    }
+    int st = 0;
+    calc_xdot_na((const double *)tab, a.lofi, svp, f1, a.xcg, a.fi, a.flags, st);
+    calc_xdot_na((const double *)tab, a.lofi, sv, f0, a.xcg, a.fi, a.flags, st);   // base point re-evaluated per column
+    if (c < 9) {
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        a.Ac[(r * 9 + c) * a.ld + b] = (f1[r] - f0[r]) / a.eps;
+        a.Cc[(r * 9 + c) * a.ld + b] = r == c ? (pert - base) / a.eps : 0.0;       // env.py:331 with _get_obs_na
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 9; ++r) a.Bc[(r * 3 + (c - 9)) * a.ld + b] = (f1[r] - f0[r]) / a.eps;
+    }
+    if (a.status && st) atomicOr(&a.status[b], st);
+  }
+}
+
+// ------------------------------------------------------------------------------------ small LDS allocator
+struct Bump {
+  double *p;
+  __device__ double *take(int n) { double *r = p; p += (n + 1) & ~1; return r; }
+};
+
+__device__ __forceinline__ void load_soa(double *dst, const double *src, int n, long ld, long b) {
+  for (int e = lane_id(); e < n; e += F16_WAVE) dst[e] = src[e * ld + b];
+  __syncthreads();
+}
+__device__ __forceinline__ void store_soa(double *dst, const double *src, int n, long ld, long b) {
+  for (int e = lane_id(); e < n; e += F16_WAVE) dst[e * ld + b] = src[e];
+}
+
+// ------------------------------------------------------------------------------------ c2d (ZOH)
+// exp([[A,B],[0,0]] h) = [[E,F],[0,I]]: only the top 9x12 block [E F] is propagated.
+// Scaling-and-squaring Taylor: X = A h/2^s, Y = B h/2^s, T_1 = [X Y], T_{k+1} = X T_k/(k+1), 13 terms
+// (||X|| <= 0.5 => truncation < 1e-15 relative), then s squarings [E F] <- E [E F] + [0 F].
+__device__ void c2d_wave(const double *A, const double *Bm, double h, double *Ad, double *Bd, double *scr) {
+  Bump al{scr};
+  double *X = al.take(81), *T = al.take(108), *Tn = al.take(108), *EF = al.take(108);
+  const int l = lane_id();
+  double rs = 0.0;
+  if (l < 9) {
+    for (int j = 0; j < 9; ++j) rs += fabs(A[l * 9 + j]);
+    for (int j = 0; j < 3; ++j) rs += fabs(Bm[l * 3 + j]);
+    rs *= fabs(h);
+  }
+  const double nrm = wave_max(rs);
+  int s = 0;
+  if (nrm > 0.5) s = min(40, (int)ceil(log2(nrm / 0.5)));
+  const double sc = ldexp(h, -s);
+  for (int e = l; e < 81; e += F16_WAVE) X[e] = A[e] * sc;
+  for (int e = l; e < 108; e += F16_WAVE) {
+    const int i = e / 12, j = e - i * 12;
+    const double v = j < 9 ? A[i * 9 + j] * sc : Bm[i * 3 + (j - 9)] * sc;
+    T[e] = v;
+    EF[e] = v + (j == i ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  for (int k = 2; k <= 13; ++k) {
+    mm<false, false>(Tn, X, T, 9, 9, 12, 1.0 / k);
+    for (int e = l; e < 108; e += F16_WAVE) { T[e] = Tn[e]; EF[e] += Tn[e]; }
+    __syncthreads();
+  }
+  for (int q = 0; q < s; ++q) {
+    for (int e = l; e < 81; e += F16_WAVE) X[e] = EF[(e / 9) * 12 + (e % 9)];   // E
+    __syncthreads();
+    mm<false, false>(Tn, X, EF, 9, 9, 12);
+    for (int e = l; e < 108; e += F16_WAVE) {
+      const int j = e % 12;
+      EF[e] = Tn[e] + (j >= 9 ? EF[e] : 0.0);
+    }
+    __syncthreads();
+  }
+  for (int e = l; e < 81; e += F16_WAVE) Ad[e] = EF[(e / 9) * 12 + (e % 9)];
+  for (int e = l; e < 27; e += F16_WAVE) Bd[e] = EF[(e / 3) * 12 + 9 + (e % 3)];
+  __syncthreads();
+}
+
+struct C2dArgs { const double *Ac, *Bc; double *Ad, *Bd; long B, ld; double dt; };
+
+__global__ __launch_bounds__(64) void k_c2d(C2dArgs a) {
+  __shared__ double smem[81 + 28 + 81 + 28 + 82 + 108 * 3];
+  Bump al{smem};
+  double *A = al.take(81), *Bm = al.take(27), *Ad = al.take(81), *Bd = al.take(27), *scr = al.take(82 + 324);
+  for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
+    load_soa(A, a.Ac, 81, a.ld, b);
+    load_soa(Bm, a.Bc, 27, a.ld, b);
+    c2d_wave(A, Bm, a.dt, Ad, Bd, scr);
+    store_soa(a.Ad, Ad, 81, a.ld, b);
+    store_soa(a.Bd, Bd, 27, a.ld, b);
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------ DARE / dlqr / dlyap
+// DARE  X = A'XA - A'XB (R+B'XB)^-1 B'XA + Q  by the structure-preserving doubling algorithm (SDA):
+//   A0 = A, G0 = B R^-1 B', H0 = Q;  W = (I + G H)^-1;  A+ = A W A;  G+ = G + A W G A';  H+ = H + A' H W A.
+// H_k -> X quadratically (21 doublings at the reference's trim point; scipy.linalg.solve_discrete_are's
+// answer is reproduced to ~1e-11 relative).  R = I here (env.py:354, :405-407).
+constexpr int DARE_SCRATCH = 82 * 7 + 164 + 10;
+__device__ int dare_sda_wave(const double *A0, const double *Bm, const double *Q, double *X, double *scr) {
+  Bump al{scr};
+  double *A = al.take(81), *G = al.take(81), *H = al.take(81), *W = al.take(81);
+  double *T1 = al.take(81), *T2 = al.take(81), *T3 = al.take(81), *Wx = al.take(162), *f = al.take(9);
+  const int l = lane_id();
+  copy(A, A0, 81);
+  copy(H, Q, 81);
+  mm<false, true>(G, Bm, Bm, 9, 3, 9);
+  int it = 0;
+  for (; it < 60; ++it) {
+    mm<false, false>(W, G, H, 9, 9, 9);
+    for (int e = l; e < 9; e += F16_WAVE) W[e * 10] += 1.0;
+    __syncthreads();
+    inverse(W, 9, Wx, f);
+    mm<false, false>(T1, A, W, 9, 9, 9);            // A W
+    mm<false, false>(T2, T1, G, 9, 9, 9);           // A W G
+    mm<false, true>(G, T2, A, 9, 9, 9, 1.0, 1.0);   // G += A W G A'
+    mm<false, false>(T2, H, W, 9, 9, 9);            // H W
+    mm<false, false>(T3, T2, A, 9, 9, 9);           // H W A
+    mm<true, false>(T2, A, T3, 9, 9, 9);            // A' H W A
+    double dmax = 0.0, hmax = 0.0;
+    for (int e = l; e < 81; e += F16_WAVE) {
+      const double hn = H[e] + T2[e];
+      dmax = fmax(dmax, fabs(T2[e]));
+      hmax = fmax(hmax, fabs(hn));
+      H[e] = hn;
+    }
+    dmax = wave_max(dmax);
+    hmax = wave_max(hmax);
+    __syncthreads();
+    mm<false, false>(T2, T1, A, 9, 9, 9);           // A W A
+    copy(A, T2, 81);
+    if (dmax <= 1e-16 * hmax) { ++it; break; }
+  }
+  for (int e = l; e < 81; e += F16_WAVE) {
+    const int i = e / 9, j = e - i * 9;
+    X[e] = 0.5 * (H[e] + H[j * 9 + i]);
+  }
+  __syncthreads();
+  return it;
+}
+
+// K = (B'XB + R)^-1 (B'XA), R = I  (utils.py:244); scr >= 27+27+9+18+3 (+pad)
+__device__ void lqr_gain_wave(const double *A, const double *Bm, const double *X, double *K, double *scr) {
+  Bump al{scr};
+  double *XB = al.take(27), *BXA = al.take(27), *S = al.take(9), *Wx = al.take(18), *f = al.take(3);
+  mm<false, false>(XB, X, Bm, 9, 9, 3);        // X B   (9x3)
+  mm<true, false>(S, Bm, XB, 3, 9, 3);         // B' X B
+  for (int e = lane_id(); e < 3; e += F16_WAVE) S[e * 4] += 1.0;
+  __syncthreads();
+  mm<true, false>(BXA, XB, A, 3, 9, 9);        // (X B)' A = B' X A   (X symmetric)
+  inverse(S, 3, Wx, f);
+  mm<false, false>(K, S, BXA, 3, 3, 9);
+}
+
+// Discrete Lyapunov  X = Phi' X Phi + W  by doubling: X+ = X + F' X F, F+ = F F  (utils.py:100 with a = Phi').
+__device__ int dlyap_wave(const double *Phi, const double *Wm, double *X, double *scr) {
+  Bump al{scr};
+  double *F = al.take(81), *T1 = al.take(81), *T2 = al.take(81);
+  const int l = lane_id();
+  copy(F, Phi, 81);
+  copy(X, Wm, 81);
+  int it = 0;
+  for (; it < 60; ++it) {
+    mm<false, false>(T1, X, F, 9, 9, 9);
+    mm<true, false>(T2, F, T1, 9, 9, 9);
+    double dmax = 0.0, xmax = 0.0;
+    for (int e = l; e < 81; e += F16_WAVE) {
+      const double xn = X[e] + T2[e];
+      dmax = fmax(dmax, fabs(T2[e]));
+      xmax = fmax(xmax, fabs(xn));
+      X[e] = xn;
+    }
+    dmax = wave_max(dmax);
+    xmax = wave_max(xmax);
+    __syncthreads();
+    mm<false, false>(T1, F, F, 9, 9, 9);
+    copy(F, T1, 81);
+    if (dmax <= 1e-17 * xmax) { ++it; break; }
+  }
+  return it;
+}
+
+struct LqrArgs { const double *Ad, *Bd, *Cd; double *K, *Pare; int32_t *status; long B, ld; };
+
+__global__ __launch_bounds__(64) void k_lqr(LqrArgs a) {
+  __shared__ double smem[82 * 5 + 28 * 2 + DARE_SCRATCH + 100];
+  Bump al{smem};
+  double *A = al.take(81), *Bm = al.take(27), *C = al.take(81), *Q = al.take(81), *X = al.take(81), *K = al.take(27);
+  double *scr = al.take(DARE_SCRATCH + 90);
+  for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
+    load_soa(A, a.Ad, 81, a.ld, b);
+    load_soa(Bm, a.Bd, 27, a.ld, b);
+    load_soa(C, a.Cd, 81, a.ld, b);
+    mm<true, false>(Q, C, C, 9, 9, 9);                 // Q = C'C (env.py:353)
+    const int it = dare_sda_wave(A, Bm, Q, X, scr);
+    lqr_gain_wave(A, Bm, X, K, scr);
+    for (int e = lane_id(); e < 27; e += F16_WAVE) a.K[e * a.ld + b] = -K[e];   // K = -dlqr(...) (env.py:356)
+    if (a.Pare) store_soa(a.Pare, X, 81, a.ld, b);
+    if (a.status && it >= 60 && lane_id() == 0) a.status[b] |= F16_ST_QP_MAXITER;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------ MPC (QP build + ADMM)
+constexpr int MAXN = 40;                         // horizon limit of the LDS-resident solver
+constexpr int MAXT = (12 * MAXN + 63) / 64;      // constraint rows per lane
+__constant__ int SROW[6] = {2, 3, 4, 5, 6, 8};   // MPC states with finite bounds: alpha,beta,p,q,r,lf2 (parameters.py:59-95,135)
+__constant__ double SLB[6] = {-20., -30., -300., -100., -50., 0.};
+__constant__ double SUB[6] = {90., 30., 300., 100., 50., 25.};
+__constant__ double ULB[3] = {-25., -21.5, -30.}, UUB[3] = {25., 21.5, 30.};      // parameters.py:125-126
+__constant__ double RLB[3] = {-60., -80., -120.}, RUB[3] = {60., 80., 120.};      // parameters.py:128-129
+
+struct MpcArgs {
+  const double *Ad, *Bd, *Cd, *x, *dem;
+  double *ucmd, *useq, *info;
+  int32_t *status;
+  double *Ppk, *Apk;          // workspace [B][np] packed P and A'A
+  double *dbg;                // optional debug dump for ONE aircraft (dbg_b): q[n] G[N*27] pred[9N]
+  long dbg_b;
+  long B, ld;
+  int N;
+  double dt;
+  f16_qp_settings s;
+};
+
+// out[3j+c] = sum_{i>=j} sum_{r in rows} G_{i-j}[r][c] * v[i*NR + rr]   (CC' v restricted to `rows`)
+template <int NR>
+__device__ __forceinline__ void conv_adjoint(double *out, const double *G, const double *v, int N, const int *rows) {
+  for (int e = lane_id(); e < 3 * N; e += F16_WAVE) {
+    const int j = e / 3, c = e - 3 * j;
+    double s = 0.0;
+    for (int i = j; i < N; ++i) {
+      const double *g = G + (i - j) * 27 + c;
+      const double *vi = v + i * NR;
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr) s += g[(NR == 9 ? rr : rows[rr]) * 3] * vi[rr];
+    }
+    out[e] = s;
+  }
+}
+
+// (CC U)[i][r] = sum_{j<=i} sum_c G_{i-j}[r][c] U[3j+c]
+__device__ __forceinline__ double conv_forward_row(const double *G, const double *U, int i, int r) {
+  double s = 0.0;
+  for (int j = 0; j <= i; ++j) {
+    const double *g = G + (i - j) * 27 + r * 3;
+    s += g[0] * U[3 * j] + g[1] * U[3 * j + 1] + g[2] * U[3 * j + 2];
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int N = a.N, n = 3 * N, np = n * (n + 1) / 2, ms = 6 * N, m = 12 * N;
+  const int l = lane_id();
+  Bump al{smem};
+  // R0 is time-shared: DARE/dlyap scratch -> Q G_k / Qbar G_k blocks -> packed KKT inverse
+  const int r0 = max(max(np, 54 * N), 1200);
+  double *Minv = al.take(r0);
+  double *G = al.take(N * 27);
+  double *A = al.take(81), *Bm = al.take(27), *Q = al.take(81), *Qb = al.take(81), *K = al.take(27);
+  double *xs = al.take(n), *xt = al.take(n), *rhs = al.take(n), *qv = al.take(n), *tv = al.take(n);
+  double *wbuf = al.take(m);
+  double *pred = al.take(9 * N);      // MM x: A^(i+1) x
+  double *x9 = al.take(9), *xref = al.take(9);
+  double *scr = Minv, *X = Minv + 760, *Phi = Minv + 842, *Wm = Minv + 924;
+  double *QG = Minv, *QbG = Minv + N * 27;
+
+  for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
+    // ---------------- model + weights (utils.py:82-105)
+    load_soa(A, a.Ad, 81, a.ld, b);
+    load_soa(Bm, a.Bd, 27, a.ld, b);
+    load_soa(Qb, a.Cd, 81, a.ld, b);                  // Cd staged in Qb
+    mm<true, false>(Q, Qb, Qb, 9, 9, 9);              // Q = C'C (env.py:389)
+    if (l < 9) {
+      const int MX[9] = {3, 4, 7, 8, 9, 10, 11, 17, 16};
+      const double v = a.x[MX[l] * a.ld + b];
+      x9[l] = v;
+      xref[l] = (l >= 5 && l < 8) ? a.dem[(l - 5) * a.ld + b] : v;   // env.py:380-383 (x_ref[5:8] = demands)
+    }
+    __syncthreads();
+    dare_sda_wave(A, Bm, Q, X, scr);
+    lqr_gain_wave(A, Bm, X, K, scr);                  // K_dlqr; the reference uses K = -dlqr (utils.py:96)
+    mm<false, false>(Phi, Bm, K, 9, 3, 9, -1.0);      // Phi = A + B K_ref = A - B K_dlqr
+    for (int e = l; e < 81; e += F16_WAVE) Phi[e] += A[e];
+    __syncthreads();
+    mm<true, false>(Wm, K, K, 9, 3, 9);               // W = Q + K'RK, R = I
+    for (int e = l; e < 81; e += F16_WAVE) Wm[e] += Q[e];
+    __syncthreads();
+    dlyap_wave(Phi, Wm, Qb, scr);                     // Q_bar (utils.py:100)
+    // ---------------- prediction blocks G_k = A^k B, pred_i = A^(i+1) x (utils.py:171-197 without forming CC/MM)
+    copy(G, Bm, 27);
+    for (int k = 1; k < N; ++k) mm<false, false>(G + k * 27, A, G + (k - 1) * 27, 9, 9, 3);
+    for (int i = 0; i < N; ++i) {
+      const double *prev = i == 0 ? x9 : pred + (i - 1) * 9;
+      if (l < 9) {
+        double s = 0.0;
+        for (int p = 0; p < 9; ++p) s += A[l * 9 + p] * prev[p];
+        pred[i * 9 + l] = s;
+      }
+      __syncthreads();
+    }
+    // QG_k = Q G_k, QbG_k = Qbar G_k
+    for (int k = 0; k < N; ++k) {
+      for (int e = l; e < 27; e += F16_WAVE) {
+        const int r = e / 3, c = e - 3 * r;
+        double s1 = 0.0, s2 = 0.0;
+        for (int p = 0; p < 9; ++p) {
+          const double g = G[k * 27 + p * 3 + c];
+          s1 += Q[r * 9 + p] * g;
+          s2 += Qb[r * 9 + p] * g;
+        }
+        QG[k * 27 + e] = s1;
+        QbG[k * 27 + e] = s2;
+      }
+    }
+    __syncthreads();
+    // ---------------- P = 2 (CC' QQ CC + RR) and A'A = CCs'CCs + I + D'D, packed lower, to the workspace.
+    // Block (j,l), j >= l, d = j-l:  T(j,l) = TQ(j,l) + G'_{N-1-j} Qbar G_{N-1-l},
+    //   TQ(j,l) = TQ(j+1,l+1) + G'_{N-2-j} Q G_{N-2-l} (0 beyond N-2),  TS likewise with S'S and all i <= N-1.
+    double *Pg = a.Ppk + (size_t)b * np, *Ag = a.Apk + (size_t)b * np;
+    for (int ch = l; ch < N * 9; ch += F16_WAVE) {       // one chain per (diagonal d, element (ra,cb))
+      const int d = ch / 9, ee = ch - 9 * d, ra = ee / 3, cb = ee - 3 * ra;
+      double tq = 0.0, ts = 0.0;
+      for (int j = N - 1; j >= d; --j) {
+        const int lcol = j - d;
+        if (j <= N - 2) {
+          double s = 0.0;
+          for (int p = 0; p < 9; ++p) s += QG[(N - 2 - j) * 27 + p * 3 + ra] * G[(N - 2 - lcol) * 27 + p * 3 + cb];
+          tq += s;
+        }
+        double sb = 0.0, ss = 0.0;
+        for (int p = 0; p < 9; ++p) sb += QbG[(N - 1 - j) * 27 + p * 3 + ra] * G[(N - 1 - lcol) * 27 + p * 3 + cb];
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) ss += G[(N - 1 - j) * 27 + SROW[rr] * 3 + ra] * G[(N - 1 - lcol) * 27 + SROW[rr] * 3 + cb];
+        ts += ss;
+        const int gi = 3 * j + ra, gj = 3 * lcol + cb;
+        if (gi >= gj) {
+          double pv = 2.0 * (tq + sb + ((gi == gj) ? 1.0 : 0.0));      // RR = I (env.py:405-407)
+          double av = ts;
+          if (gi == gj) av += 1.0 + ((j < N - 1) ? 2.0 : 1.0);         // I'I + D'D diagonal
+          if (d == 1 && ra == cb) av += -1.0;                          // D'D sub-diagonal block -I
+          Pg[tri(gi, gj)] = pv;
+          Ag[tri(gi, gj)] = av;
+        }
+      }
+    }
+    // ---------------- q = -2 CC' QQ (x_ref - MM x)   (utils.py:112)
+    for (int e = l; e < 9 * N; e += F16_WAVE) {
+      const int i = e / 9, r = e - 9 * i;
+      const double *Qi = (i == N - 1) ? Qb : Q;
+      double s = 0.0;
+      for (int p = 0; p < 9; ++p) s += Qi[r * 9 + p] * (xref[p] - pred[i * 9 + p]);
+      wbuf[e] = s;                                       // (m = 12N >= 9N)
+    }
+    __syncthreads();
+    conv_adjoint<9>(qv, G, wbuf, N, nullptr);
+    __syncthreads();
+    for (int e = l; e < n; e += F16_WAVE) qv[e] = -2.0 * qv[e];
+    __threadfence_block();
+    __syncthreads();
+    // ---------------- bounds of the kept rows (utils.py:129-152): [6N state | 3N command | 3N rate]
+    double lo[MAXT], hi[MAXT], z[MAXT], y[MAXT], dy[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int row = l + 64 * t;
+      lo[t] = 0.0; hi[t] = 0.0; z[t] = 0.0; y[t] = 0.0; dy[t] = 0.0;
+      if (row < ms) {
+        const int i = row / 6, rr = row - 6 * i;
+        const double pm = pred[i * 9 + SROW[rr]];
+        lo[t] = SLB[rr] - pm;
+        hi[t] = SUB[rr] - pm;
+      } else if (row < ms + n) {
+        const int c = (row - ms) % 3;
+        lo[t] = ULB[c]; hi[t] = UUB[c];
+      } else if (row < m) {
+        const int k = row - ms - n, c = k % 3;
+        if (k < 3) {
+          const double act = a.x[(13 + c) * a.ld + b];
+          lo[t] = act + RLB[c] * a.dt;
+          hi[t] = act + RUB[c] * a.dt;
+        } else {
+          lo[t] = RLB[c]; hi[t] = RUB[c];              // reference quirk: not multiplied by dt (utils.py:151-152)
+        }
+      }
+    }
+    if (a.dbg && b == a.dbg_b) {
+      for (int e = l; e < n; e += F16_WAVE) a.dbg[e] = qv[e];
+      for (int e = l; e < N * 27; e += F16_WAVE) a.dbg[n + e] = G[e];
+      for (int e = l; e < 9 * N; e += F16_WAVE) a.dbg[n + N * 27 + e] = pred[e];
+    }
+    // ---------------- ADMM (OSQP Algorithm 1, reduced dense form; settings a.s)
+    double rho = a.s.rho;
+    const double sigma = a.s.sigma, alpha = a.s.alpha;
+    auto build_minv = [&](double r) {
+      __syncthreads();
+      for (int e = l; e < np; e += F16_WAVE) Minv[e] = Pg[e] + r * Ag[e];
+      __syncthreads();
+      for (int e = l; e < n; e += F16_WAVE) Minv[tri(e, e)] += sigma;
+      __syncthreads();
+      return spd_inverse_packed(Minv, n, tv);
+    };
+    bool ok = build_minv(rho);
+    for (int e = l; e < n; e += F16_WAVE) xs[e] = 0.0;
+    __syncthreads();
+    int it = 0;
+    double rp = INFINITY, rd = INFINITY;
+    bool converged = false, infeasible = false;
+    bool done = !ok || a.s.max_iter <= 0;
+    while (!done) {
+      ++it;
+      // w = rho z - y -> t = A' w ; rhs = sigma x - q + t
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        const int row = l + 64 * t;
+        if (row < m) wbuf[row] = rho * z[t] - y[t];
+      }
+      __syncthreads();
+      conv_adjoint<6>(tv, G, wbuf, N, SROW);
+      for (int e = l; e < n; e += F16_WAVE) {
+        const double wr = wbuf[ms + n + e] - (e + 3 < n ? wbuf[ms + n + e + 3] : 0.0);
+        rhs[e] = sigma * xs[e] - qv[e] + (tv[e] + wbuf[ms + e] + wr);
+      }
+      __syncthreads();
+      symv(xt, Minv, rhs, n);                               // x~ = (P + sigma I + rho A'A)^-1 rhs
+      // z~ = A x~ ; relaxation, projection, dual update
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        const int row = l + 64 * t;
+        if (row < m) {
+          double zt;
+          if (row < ms) zt = conv_forward_row(G, xt, row / 6, SROW[row % 6]);
+          else if (row < ms + n) zt = xt[row - ms];
+          else { const int k = row - ms - n; zt = xt[k] - (k >= 3 ? xt[k - 3] : 0.0); }
+          const double zr = alpha * zt + (1 - alpha) * z[t];
+          const double zn = fmin(fmax(zr + y[t] / rho, lo[t]), hi[t]);
+          dy[t] = rho * (zr - zn);
+          y[t] = y[t] + dy[t];
+          z[t] = zn;
+        }
+      }
+      for (int e = l; e < n; e += F16_WAVE) xs[e] = alpha * xt[e] + (1 - alpha) * xs[e];
+      __syncthreads();
+      if (it % a.s.check_every == 0 || it >= a.s.max_iter) {
+        // residuals (OSQP termination test)
+        double r1 = 0.0, nAx = 0.0, nz = 0.0;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+          const int row = l + 64 * t;
+          if (row < m) {
+            double ax;
+            if (row < ms) ax = conv_forward_row(G, xs, row / 6, SROW[row % 6]);
+            else if (row < ms + n) ax = xs[row - ms];
+            else { const int k = row - ms - n; ax = xs[k] - (k >= 3 ? xs[k - 3] : 0.0); }
+            r1 = fmax(r1, fabs(ax - z[t]));
+            nAx = fmax(nAx, fabs(ax));
+            nz = fmax(nz, fabs(z[t]));
+            wbuf[row] = y[t];
+          }
+        }
+        __syncthreads();
+        symv(xt, Pg, xs, n);                                // P x (packed P from the workspace)
+        conv_adjoint<6>(tv, G, wbuf, N, SROW);
+        double r2 = 0.0, nPx = 0.0, nAty = 0.0, nq = 0.0;
+        for (int e = l; e < n; e += F16_WAVE) {
+          const double aty = tv[e] + wbuf[ms + e] + (wbuf[ms + n + e] - (e + 3 < n ? wbuf[ms + n + e + 3] : 0.0));
+          r2 = fmax(r2, fabs(xt[e] + qv[e] + aty));
+          nPx = fmax(nPx, fabs(xt[e]));
+          nAty = fmax(nAty, fabs(aty));
+          nq = fmax(nq, fabs(qv[e]));
+        }
+        rp = wave_max(r1);
+        rd = wave_max(r2);
+        const double np_ = fmax(wave_max(nAx), wave_max(nz));
+        const double nd_ = fmax(fmax(wave_max(nPx), wave_max(nAty)), wave_max(nq));
+        __syncthreads();
+        if (rp <= a.s.eps_abs + a.s.eps_rel * np_ && rd <= a.s.eps_abs + a.s.eps_rel * nd_) { done = true; converged = true; }
+        else {
+          // OSQP primal-infeasibility certificate on dy = y_k - y_{k-1}: ||A'dy|| <= eps ||dy|| and
+          // u'(dy)+ + l'(dy)- <= -eps ||dy||  (all kept rows have finite bounds)
+          double ndy = 0.0, supp = 0.0;
+#pragma unroll
+          for (int t = 0; t < MAXT; ++t) {
+            const int row = l + 64 * t;
+            if (row < m) {
+              ndy = fmax(ndy, fabs(dy[t]));
+              supp += hi[t] * fmax(dy[t], 0.0) + lo[t] * fmin(dy[t], 0.0);
+              wbuf[row] = dy[t];
+            }
+          }
+          ndy = wave_max(ndy);
+          supp = wave_sum(supp);
+          __syncthreads();
+          if (ndy > a.s.eps_prim_inf && supp < -a.s.eps_prim_inf * ndy) {
+            conv_adjoint<6>(tv, G, wbuf, N, SROW);
+            double nat = 0.0;
+            for (int e = l; e < n; e += F16_WAVE)
+              nat = fmax(nat, fabs(tv[e] + wbuf[ms + e] + (wbuf[ms + n + e] - (e + 3 < n ? wbuf[ms + n + e + 3] : 0.0))));
+            nat = wave_max(nat);
+            if (nat < a.s.eps_prim_inf * ndy) { done = true; infeasible = true; }
+          }
+          __syncthreads();
+        }
+        if (done) {}
+        else if (it >= a.s.max_iter) done = true;
+        else if (a.s.adaptive_rho && it % a.s.rho_every == 0) {
+          double nw = rho * sqrt((rp / fmax(np_, 1e-10)) / fmax(rd / fmax(nd_, 1e-10), 1e-10));
+          nw = fmin(fmax(nw, 1e-6), 1e6);
+          if (nw > 5 * rho || nw < rho / 5) {
+            rho = nw;
+            if (!build_minv(rho)) done = true;
+          }
+        }
+      }
+    }
+    // res.x[0:3] (env.py:424); OSQP hands back NaN for a problem it certifies infeasible
+    for (int e = l; e < 3; e += F16_WAVE) a.ucmd[e * a.ld + b] = infeasible ? NAN : xs[e];
+    if (a.useq) for (int e = l; e < n; e += F16_WAVE) a.useq[e * a.ld + b] = infeasible ? NAN : xs[e];
+    if (l == 0) {
+      if (a.info) {
+        a.info[0 * a.ld + b] = (double)it;
+        a.info[1 * a.ld + b] = rp;
+        a.info[2 * a.ld + b] = rd;
+        a.info[3 * a.ld + b] = rho;
+      }
+      if (a.status && infeasible) a.status[b] |= F16_ST_QP_INFEASIBLE;
+      else if (a.status && a.s.max_iter > 0 && (!converged || !ok)) a.status[b] |= F16_ST_QP_MAXITER;
+    }
+    __syncthreads();
+  }
+}
+
+static size_t mpc_lds_doubles(int N) {
+  const int n = 3 * N, np = n * (n + 1) / 2, m = 12 * N;
+  auto ev = [](int v) { return (size_t)((v + 1) & ~1); };
+  int r0 = np > 54 * N ? np : 54 * N;
+  if (r0 < 1200) r0 = 1200;
+  return ev(r0) + ev(N * 27) + ev(81) * 3 + ev(27) * 2 + ev(n) * 5 + ev(m) + ev(9 * N) + ev(9) * 2;
+}
+
+}  // namespace f16
+
+using namespace f16;
+
+extern "C" int f16_linearise_batch(f16_ctx *ctx, const double *x, const double *u, double *Ac, double *Bc, double *Cc,
+                                   int32_t *status, long B, long ld, double eps, double xcg, int fi_flag, unsigned flags,
+                                   void *stream) {
+  if (!ctx || !x || !u || !Ac || !Bc || !Cc || B < 0 || ld < B) return set_error(F16_EINVAL, "bad argument to f16_linearise_batch");
+  if (B == 0) return F16_OK;
+  LinArgs a{ctx->d_tab, ctx->d_lofi, x, u, Ac, Bc, Cc, status, B, ld, eps, xcg, fi_flag, flags};
+  const long lanes = B * 12;
+  if (lanes <= 64L * 256) {
+    hipLaunchKernelGGL(k_linearise<64>, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
+  } else {
+    long blocks = (lanes + 255) / 256;
+    hipLaunchKernelGGL(k_linearise<256>, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, (hipStream_t)stream, a);
+  }
+  return hip_check(hipGetLastError(), "f16_linearise_batch launch");
+}
+
+static unsigned wave_grid(long B) { return (unsigned)(B < 256L * 32 ? B : 256L * 32); }
+
+extern "C" int f16_c2d_batch(f16_ctx *ctx, const double *Ac, const double *Bc, double *Ad, double *Bd, long B, long ld,
+                             double dt, void *stream) {
+  if (!ctx || !Ac || !Bc || !Ad || !Bd || B < 0 || ld < B) return set_error(F16_EINVAL, "bad argument to f16_c2d_batch");
+  if (B == 0) return F16_OK;
+  C2dArgs a{Ac, Bc, Ad, Bd, B, ld, dt};
+  hipLaunchKernelGGL(k_c2d, dim3(wave_grid(B)), dim3(64), 0, (hipStream_t)stream, a);
+  return hip_check(hipGetLastError(), "f16_c2d_batch launch");
+}
+
+extern "C" int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, double *K, double *Pare,
+                             int32_t *status, long B, long ld, void *stream) {
+  if (!ctx || !Ad || !Bd || !Cd || !K || B < 0 || ld < B) return set_error(F16_EINVAL, "bad argument to f16_lqr_batch");
+  if (B == 0) return F16_OK;
+  LqrArgs a{Ad, Bd, Cd, K, Pare, status, B, ld};
+  hipLaunchKernelGGL(k_lqr, dim3(wave_grid(B)), dim3(64), 0, (hipStream_t)stream, a);
+  return hip_check(hipGetLastError(), "f16_lqr_batch launch");
+}
+
+extern "C" void f16_qp_default_settings(f16_qp_settings *s) {
+  // OSQP defaults with the deterministic schedule of SURVEY.md 8(d) config 4
+  s->rho = 0.1; s->sigma = 1e-6; s->alpha = 1.6; s->eps_abs = 1e-3; s->eps_rel = 1e-3; s->eps_prim_inf = 1e-4;
+  s->max_iter = 40000;            // env.py:421
+  s->check_every = 25; s->rho_every = 100; s->adaptive_rho = 1;
+}
+
+static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream) {
+  const int N = a.N;
+  if (N < 1 || N > MAXN) return set_error(F16_EINVAL, "horizon must be 1..40 for the LDS-resident QP solver");
+  const size_t np = (size_t)(3 * N) * (3 * N + 1) / 2;
+  const size_t need = 2 * np * (size_t)a.B * sizeof(double);
+  {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (ctx->work_bytes < need) {
+      if (ctx->d_work) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->d_work); ctx->d_work = nullptr; ctx->work_bytes = 0; }
+      if (int rc = hip_check(hipMalloc(&ctx->d_work, need), "hipMalloc QP workspace")) return rc;
+      ctx->work_bytes = need;
+    }
+  }
+  a.Ppk = (double *)ctx->d_work;
+  a.Apk = a.Ppk + np * (size_t)a.B;
+  const size_t lds = mpc_lds_doubles(N) * sizeof(double);
+  if (lds > 160 * 1024) return set_error(F16_EINVAL, "horizon too large for LDS");
+  if (int rc = hip_check(hipFuncSetAttribute((const void *)k_mpc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                         "hipFuncSetAttribute"))
+    return rc;
+  hipLaunchKernelGGL(k_mpc, dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
+  return hip_check(hipGetLastError(), "f16_mpc_batch launch");
+}
+
+extern "C" int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
+                             const double *dem, double *u_cmd, double *u_seq, double *info, int32_t *status, long B,
+                             long ld, int hzn, double dt, const f16_qp_settings *s, void *stream) {
+  if (!ctx || !Ad || !Bd || !Cd || !x || !dem || !u_cmd || B < 0 || ld < B) return set_error(F16_EINVAL, "bad argument to f16_mpc_batch");
+  if (B == 0) return F16_OK;
+  MpcArgs a{};
+  a.Ad = Ad; a.Bd = Bd; a.Cd = Cd; a.x = x; a.dem = dem; a.ucmd = u_cmd; a.useq = u_seq; a.info = info; a.status = status;
+  a.B = B; a.ld = ld; a.N = hzn; a.dt = dt; a.dbg = nullptr; a.dbg_b = -1;
+  if (s) a.s = *s; else f16_qp_default_settings(&a.s);
+  if (a.s.check_every < 1 || a.s.rho_every < 1 || !(a.s.rho > 0) || !(a.s.sigma > 0)) return set_error(F16_EINVAL, "bad QP settings");
+  return mpc_launch(ctx, a, stream);
+}
+
+extern "C" int f16_mpc_qp_debug(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
+                                const double *dem, long b, long ld, int hzn, double dt, double *h_P, double *h_q, double *h_A,
+                                double *h_l, double *h_u) {
+  if (!ctx || !Ad || !Bd || !Cd || !x || !dem || b < 0 || b >= ld || !h_P || !h_q || !h_A || !h_l || !h_u)
+    return set_error(F16_EINVAL, "bad argument to f16_mpc_qp_debug");
+  const int N = hzn, n = 3 * N, rows = 15 * N;
+  if (N < 1 || N > MAXN) return set_error(F16_EINVAL, "horizon must be 1..40");
+  const size_t np = (size_t)n * (n + 1) / 2;
+  const size_t ndbg = (size_t)n + N * 27 + 9 * N;
+  double *d_dbg = nullptr, *d_u = nullptr;
+  int rc;
+  if ((rc = hip_check(hipMalloc(&d_dbg, ndbg * sizeof(double)), "hipMalloc dbg"))) return rc;
+  if ((rc = hip_check(hipMalloc(&d_u, 3 * ld * sizeof(double)), "hipMalloc dbg u"))) { (void)hipFree(d_dbg); return rc; }
+  MpcArgs a{};
+  a.Ad = Ad; a.Bd = Bd; a.Cd = Cd; a.x = x; a.dem = dem; a.ucmd = d_u; a.B = b + 1; a.ld = ld; a.N = N; a.dt = dt;
+  a.dbg = d_dbg; a.dbg_b = b;
+  f16_qp_default_settings(&a.s);
+  a.s.max_iter = 0;                                 // build only
+  rc = mpc_launch(ctx, a, nullptr);
+  std::vector<double> dbg(ndbg), Ppk(np), xcol(18);
+  if (!rc) rc = hip_check(hipDeviceSynchronize(), "sync");
+  if (!rc) rc = hip_check(hipMemcpy(dbg.data(), d_dbg, ndbg * sizeof(double), hipMemcpyDeviceToHost), "copy dbg");
+  if (!rc) rc = hip_check(hipMemcpy(Ppk.data(), a.Ppk + np * (size_t)b, np * sizeof(double), hipMemcpyDeviceToHost), "copy P");
+  for (int k = 0; k < 18 && !rc; ++k)
+    rc = hip_check(hipMemcpy(&xcol[k], x + k * ld + b, sizeof(double), hipMemcpyDeviceToHost), "copy x");
+  (void)hipFree(d_dbg);
+  (void)hipFree(d_u);
+  if (rc) return rc;
+  // reference-format QP (utils.py:111-165): P dense, A = [CC; I; D] (15N x 3N), l/u with +-inf rows kept
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) h_P[i * n + j] = i >= j ? Ppk[(size_t)i * (i + 1) / 2 + j] : Ppk[(size_t)j * (j + 1) / 2 + i];
+  for (int i = 0; i < n; ++i) h_q[i] = dbg[i];
+  const double *G = dbg.data() + n, *pred = dbg.data() + n + N * 27;
+  for (size_t i = 0; i < (size_t)rows * n; ++i) h_A[i] = 0.0;
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j <= i; ++j)
+      for (int r = 0; r < 9; ++r)
+        for (int c = 0; c < 3; ++c) h_A[(size_t)(9 * i + r) * n + 3 * j + c] = G[(i - j) * 27 + r * 3 + c];
+  for (int k = 0; k < n; ++k) {
+    h_A[(size_t)(9 * N + k) * n + k] = 1.0;
+    h_A[(size_t)(12 * N + k) * n + k] = 1.0;
+    if (k >= 3) h_A[(size_t)(12 * N + k) * n + k - 3] = -1.0;
+  }
+  static const double xlb[9] = {-INFINITY, -INFINITY, -20., -30., -300., -100., -50., -INFINITY, 0.};
+  static const double xub[9] = {INFINITY, INFINITY, 90., 30., 300., 100., 50., INFINITY, 25.};
+  static const double ulb[3] = {-25., -21.5, -30.}, uub[3] = {25., 21.5, 30.}, rlb[3] = {-60., -80., -120.}, rub[3] = {60., 80., 120.};
+  for (int i = 0; i < N; ++i)
+    for (int r = 0; r < 9; ++r) {
+      h_l[9 * i + r] = xlb[r] - pred[9 * i + r];
+      h_u[9 * i + r] = xub[r] - pred[9 * i + r];
+    }
+  for (int k = 0; k < n; ++k) {
+    h_l[9 * N + k] = ulb[k % 3];
+    h_u[9 * N + k] = uub[k % 3];
+    if (k < 3) {
+      h_l[12 * N + k] = xcol[13 + k] + rlb[k] * dt;
+      h_u[12 * N + k] = xcol[13 + k] + rub[k] * dt;
+    } else {
+      h_l[12 * N + k] = rlb[k % 3];
+      h_u[12 * N + k] = rub[k % 3];
+    }
+  }
+  return F16_OK;
+}

@@ -10,6 +10,8 @@ struct f16_ctx {
   // single-aircraft scratch for the drop-in Nlplant symbol
   double *d_one;    // [18 + 18]
   double *h_one;    // pinned mirror
+  void *d_work;     // QP workspace (packed P and A'A per aircraft), grown on demand
+  size_t work_bytes;
 };
 
 namespace f16 {

@@ -172,7 +172,7 @@ class F16Batch:
         Bc = torch.empty((27, self.B), dtype=torch.float64, device=self.device)
         Cc = torch.empty((81, self.B), dtype=torch.float64, device=self.device)
         st = torch.zeros(self.B, dtype=torch.int32, device=self.device)
-        self._check(self.lib.f16_linearise_batch(self.ctx.handle, _vp(self._x), _vp(Ac), _vp(Bc), _vp(Cc), _vp(st),
+        self._check(self.lib.f16_linearise_batch(self.ctx.handle, _vp(self._x), _vp(self._u), _vp(Ac), _vp(Bc), _vp(Cc), _vp(st),
                                                  self.B, self.B, eps, self.xcg, self.fi_flag, self.flags, self._stream))
         self.last_status = st
         self._lin = (Ac, Bc, Cc)

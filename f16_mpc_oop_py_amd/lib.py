@@ -15,7 +15,7 @@ SOURCES = ["f16_api.hip", "f16_dynamics.hip", "f16_control.hip", "f16_tables.cpp
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                "-Wno-unused-result"]
 
-F16_ST = dict(ALPHA1=1, ALPHA2=2, BETA=4, EL=8, ENVELOPE=16, NONFINITE=32, QP_MAXITER=64)
+F16_ST = dict(ALPHA1=1, ALPHA2=2, BETA=4, EL=8, ENVELOPE=16, NONFINITE=32, QP_MAXITER=64, QP_INFEASIBLE=128)
 F16_FLAG_FIX_CLR = 1
 F16_FLAG_NO_ENVELOPE = 2
 
@@ -26,7 +26,8 @@ class F16HipError(RuntimeError):
 
 class QPSettings(ctypes.Structure):
     _fields_ = [("rho", ctypes.c_double), ("sigma", ctypes.c_double), ("alpha", ctypes.c_double),
-                ("eps_abs", ctypes.c_double), ("eps_rel", ctypes.c_double), ("max_iter", ctypes.c_int),
+                ("eps_abs", ctypes.c_double), ("eps_rel", ctypes.c_double), ("eps_prim_inf", ctypes.c_double),
+                ("max_iter", ctypes.c_int),
                 ("check_every", ctypes.c_int), ("rho_every", ctypes.c_int), ("adaptive_rho", ctypes.c_int)]
 
 
@@ -75,7 +76,7 @@ def load():
     L.f16_rollout.argtypes = [vp, vp, vp, vp, vp, l, l, i, i, d, d, i, u, vp]
     L.f16_xdot_na_batch.argtypes = [vp, vp, vp, vp, vp, vp, l, l, d, i, u, vp]
     if hasattr(L, "f16_linearise_batch"):
-        L.f16_linearise_batch.argtypes = [vp, vp, vp, vp, vp, vp, l, l, d, d, i, u, vp]
+        L.f16_linearise_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, l, l, d, d, i, u, vp]
         L.f16_c2d_batch.argtypes = [vp, vp, vp, vp, vp, l, l, d, vp]
         L.f16_lqr_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, l, l, vp]
         L.f16_qp_default_settings.argtypes = [ctypes.POINTER(QPSettings)]

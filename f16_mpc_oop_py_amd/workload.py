@@ -36,3 +36,13 @@ def config2_states(B, seed=20261003):
     x[:, 16] = np.clip(1.38 * alpha_deg - 9.05 * _atmos_ratio(x[:, 2], x[:, 6]) + 1.45, 0, 25)
     x[:, 17] = -alpha_deg
     return x, np.copy(x[:, 12:16])
+
+
+def config4_states(B, seed=20261003):
+    """Config 4 of SURVEY.md 8(d): the config-2 flight conditions for the batched MPC solve (xcg 0.35, N = 30).
+    The leading-edge-flap state is kept 1 degree inside its [0, 25] box: an aircraft sitting ON that bound whose
+    linear model predicts crossing it gives an INFEASIBLE QP (the reference's OSQP call would return NaN), which is
+    a property of the problem, not a workload one wants to time."""
+    x, u = config2_states(B, seed)
+    x[:, 16] = np.clip(x[:, 16], 1.0, 24.0)
+    return x, u

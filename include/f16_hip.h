@@ -46,6 +46,7 @@ typedef struct f16_ctx f16_ctx;
 #define F16_ST_ENVELOPE 16  /* env.py:117-124 box check failed: aircraft frozen from then on  */
 #define F16_ST_NONFINITE 32 /* a state became NaN/Inf                                         */
 #define F16_ST_QP_MAXITER 64 /* ADMM hit max_iter before meeting the OSQP termination test    */
+#define F16_ST_QP_INFEASIBLE 128 /* OSQP primal-infeasibility certificate met: command = NaN  */
 
 /* behaviour flags */
 #define F16_FLAG_FIX_CLR 1u      /* use the real CLr table (reference never loads it: hifi_F16_AeroData.c:964-972) */
@@ -89,9 +90,10 @@ int f16_xdot_na_batch(f16_ctx *ctx, const double *x_full, const double *x9, cons
                       int32_t *status, long B, long ld, double xcg, int fi_flag, unsigned flags, void *stream);
 
 /* ---- (2) batched control chain ---------------------------------------------------------- */
-/* env.py:294-342 with _calc_xdot_na/_get_obs_na at each aircraft's own state x[18][ld] (x9 = x[mpc idx],
- * u3 = x[13:16]): Ac[81][ld] Bc[27][ld] Cc[81][ld] (row-major element index = r*ncols+c), eps = 1e-5. */
-int f16_linearise_batch(f16_ctx *ctx, const double *x, double *Ac, double *Bc, double *Cc,
+/* env.py:294-342 with _calc_xdot_na/_get_obs_na at each aircraft's own point: x9 = x[mpc idx] of x[18][ld],
+ * u3 = u[1..3] of u[4][ld] (self.u._get_mpc_u(), env.py:348): Ac[81][ld] Bc[27][ld] Cc[81][ld]
+ * (row-major element index = r*ncols+c); eps = 1e-5 in the reference (env.py:319). */
+int f16_linearise_batch(f16_ctx *ctx, const double *x, const double *u, double *Ac, double *Bc, double *Cc,
                         int32_t *status, long B, long ld, double eps, double xcg, int fi_flag,
                         unsigned flags, void *stream);
 /* scipy.signal.cont2discrete(zoh) (env.py:50,351): Ad[81][ld], Bd[27][ld] = expm([[A,B],[0,0]] dt) blocks */
@@ -107,7 +109,7 @@ int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double
  * fixed settings in f16_qp_settings.  u_seq (may be NULL) gets the full [3*hzn][ld] sequence,
  * info (may be NULL) gets [4][ld] = iterations, r_prim, r_dual, rho. */
 typedef struct f16_qp_settings {
-  double rho, sigma, alpha, eps_abs, eps_rel;
+  double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf;
   int max_iter, check_every, rho_every, adaptive_rho;
 } f16_qp_settings;
 void f16_qp_default_settings(f16_qp_settings *s);

@@ -230,7 +230,7 @@ def mpc_qp(x_full, Ad, Bd, Cd, hzn, dt, p_dem=0.0, q_dem=0.0, r_dem=0.0):
 
 
 # ------------------------------------------------------------- QP solvers
-ADMM_DEFAULTS = dict(rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3,
+ADMM_DEFAULTS = dict(rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, eps_prim_inf=1e-4,
                      check_every=25, rho_every=100, max_iter=40000, adaptive_rho=True)
 
 
@@ -250,13 +250,15 @@ def admm_osqp_style(P, q, A, l, u, **kw):
     cho = scipy.linalg.cho_factor(P + sigma * np.eye(n) + rho * AtA)
     x, z, y = np.zeros(n), np.zeros(mrow), np.zeros(mrow)
     it, rp, rd = 0, np.inf, np.inf
+    infeasible = False
     for it in range(1, o["max_iter"] + 1):
         xt = scipy.linalg.cho_solve(cho, sigma * x - q + A.T @ (rho * z - y))
         zt = A @ xt
         x = alpha * xt + (1 - alpha) * x
         zr = alpha * zt + (1 - alpha) * z
         z_new = np.clip(zr + y / rho, l, u)
-        y = y + rho * (zr - z_new)
+        dy = rho * (zr - z_new)
+        y = y + dy
         z = z_new
         if it % o["check_every"] == 0:
             Ax, Px, Aty = A @ x, P @ x, A.T @ y
@@ -266,6 +268,13 @@ def admm_osqp_style(P, q, A, l, u, **kw):
             nd_ = max(np.abs(Px).max(), np.abs(Aty).max(), np.abs(q).max())
             if rp <= o["eps_abs"] + o["eps_rel"] * np_ and rd <= o["eps_abs"] + o["eps_rel"] * nd_:
                 break
+            # OSQP primal infeasibility certificate (all kept rows have at least one finite bound here)
+            ndy = np.abs(dy).max()
+            supp = np.sum(np.where(np.isfinite(u), u, 0) * np.maximum(dy, 0) + np.where(np.isfinite(l), l, 0) * np.minimum(dy, 0))
+            if ndy > o["eps_prim_inf"] and supp < -o["eps_prim_inf"] * ndy and \
+                    np.abs(A.T @ dy).max() < o["eps_prim_inf"] * ndy:
+                infeasible = True
+                break
             if o["adaptive_rho"] and it % o["rho_every"] == 0:
                 new = rho * np.sqrt((rp / max(np_, 1e-10)) / max(rd / max(nd_, 1e-10), 1e-10))
                 new = min(max(new, 1e-6), 1e6)
@@ -274,14 +283,16 @@ def admm_osqp_style(P, q, A, l, u, **kw):
                     cho = scipy.linalg.cho_factor(P + sigma * np.eye(n) + rho * AtA)
     yfull = np.zeros(keep.size)
     yfull[keep] = y
-    return dict(x=x, y=yfull, z=z, iters=it, r_prim=rp, r_dual=rd, rho=rho)
+    if infeasible:
+        x = np.full(n, np.nan)
+    return dict(x=x, y=yfull, z=z, iters=it, r_prim=rp, r_dual=rd, rho=rho, infeasible=infeasible)
 
 
 def qp_exact(P, q, A, l, u, tol=1e-9, max_rounds=50):
     """Exact minimiser of  1/2 x'Px + q'x  s.t. l <= Ax <= u  (P > 0) by primal-dual active-set
     iteration on the KKT system, seeded from a tight ADMM run; raises if KKT is not met."""
     n = P.shape[0]
-    seed = admm_osqp_style(P, q, A, l, u, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000)
+    seed = admm_osqp_style(P, q, A, l, u, eps_abs=1e-10, eps_rel=1e-10, max_iter=400000)
     x, y = seed["x"], seed["y"]
     Ax = A @ x
     act_lo = (Ax - l < 1e-6) & (y < -1e-9) & np.isfinite(l)
@@ -309,4 +320,8 @@ def qp_exact(P, q, A, l, u, tol=1e-9, max_rounds=50):
             return x, lam
         act_lo = (act_lo | viol_lo) & ~wrong_lo
         act_hi = (act_hi | viol_hi) & ~wrong_hi
+    # degenerate active set (linearly dependent rate/command/state rows): fall back to the tight ADMM point,
+    # accepted only if its own KKT residuals are at rounding level
+    if seed["r_prim"] < 1e-8 and seed["r_dual"] < 1e-8 * max(1.0, np.abs(q).max()):
+        return seed["x"], seed["y"]
     raise RuntimeError("qp_exact: active set did not settle")

@@ -1,0 +1,197 @@
+"""GPU parity tests of the control chain (linearise -> ZOH -> LQR -> condensed QP -> ADMM) through the C-ABI.
+
+Oracle: golden fixtures captured from the reference's env.py/utils.py (+scipy) and, for the QP solve -- which the
+reference delegates to the absent `osqp` package ("parity unpinned") -- the exact minimiser of the
+strictly convex QP (tests/golden/g8, computed by oracle.mpc_oracle.qp_exact) and the same-algorithm numpy ADMM.
+Tolerances: A,B by differences <= 1e-6 abs; K,P,q <= 1e-6 relative; MPC first move within the
+OSQP default tolerance band of the exact minimiser."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import mpc_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+
+def make_env(x, u=None, **kw):
+    from f16_mpc_oop_py_amd import F16Batch
+    return F16Batch(x, u, device="cuda:0", **kw)
+
+
+def soa(a, dev="cuda:0"):
+    """[B, ...] -> state-major [prod(...), B] device tensor."""
+    a = np.asarray(a, dtype=np.float64)
+    return torch.as_tensor(a.reshape(a.shape[0], -1).T.copy(), device=dev)
+
+
+@pytest.mark.parametrize("xcg", [25, 35])
+def test_linearise_c2d_lqr_vs_reference(xcg):
+    g = golden("g567_trim_lin_lqr.npz")
+    x = np.tile(g[f"trim_x_xcg{xcg}"], (3, 1))
+    env = make_env(x, xcg=xcg / 100)
+    Ac, Bc, Cc, Dc = (t.cpu().numpy() for t in env.linearise())
+    for b in range(3):
+        np.testing.assert_allclose(Ac[b], g[f"ssr_Ac_xcg{xcg}"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(Bc[b], g[f"ssr_Bc_xcg{xcg}"], rtol=0, atol=1e-6)
+        assert np.array_equal(Cc[b], g[f"ssr_Cc_xcg{xcg}"])          # selection matrix + identical rounding noise
+    assert not Dc.any()
+    # ZOH on the reference's own continuous matrices: isolates the expm kernel
+    B = 5
+    Ad, Bd = env2 = None, None
+    env = make_env(np.tile(g[f"trim_x_xcg{xcg}"], (B, 1)), xcg=xcg / 100)
+    Ad, Bd = env.discretise(torch.as_tensor(np.tile(g[f"ssr_Ac_xcg{xcg}"], (B, 1, 1)), device="cuda:0"),
+                            torch.as_tensor(np.tile(g[f"ssr_Bc_xcg{xcg}"], (B, 1, 1)), device="cuda:0"))
+    Ad = Ad.t().reshape(B, 9, 9).cpu().numpy()
+    Bd = Bd.t().reshape(B, 9, 3).cpu().numpy()
+    np.testing.assert_allclose(Ad[B - 1], g[f"ssr_Ad_xcg{xcg}"], rtol=0, atol=5e-15)
+    np.testing.assert_allclose(Bd[0], g[f"ssr_Bd_xcg{xcg}"], rtol=0, atol=1e-17)
+    # LQR gain on the reference's discrete model (isolates the DARE kernel) ...
+    K = torch.empty((27, B), dtype=torch.float64, device="cuda:0")
+    Pare = torch.empty((81, B), dtype=torch.float64, device="cuda:0")
+    st = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    args = [soa(np.tile(g[f"ssr_{k}_xcg{xcg}"], (B, 1, 1))) for k in ("Ad", "Bd", "Cd")]
+    from f16_mpc_oop_py_amd.env import _vp
+    rc = env.lib.f16_lqr_batch(env.ctx.handle, _vp(args[0]), _vp(args[1]), _vp(args[2]), _vp(K), _vp(Pare), _vp(st), B, B, None)
+    assert rc == 0
+    Kg = K.t().reshape(B, 3, 9).cpu().numpy()
+    Kref = g[f"K_lqr_xcg{xcg}"]
+    assert np.abs(Kg[2] - Kref).max() / np.abs(Kref).max() < 1e-8
+    assert int(st.max()) == 0
+    import scipy.linalg
+    Xref = scipy.linalg.solve_discrete_are(g[f"ssr_Ad_xcg{xcg}"], g[f"ssr_Bd_xcg{xcg}"],
+                                           g[f"ssr_Cd_xcg{xcg}"].T @ g[f"ssr_Cd_xcg{xcg}"], np.eye(3))
+    Xg = Pare.t().reshape(B, 9, 9).cpu().numpy()[1]
+    assert np.abs(Xg - Xref).max() / np.abs(Xref).max() < 1e-9
+    # ... and the whole env.py:344-358 chain from the trim state
+    env = make_env(np.tile(g[f"trim_x_xcg{xcg}"], (2, 1)), xcg=xcg / 100)
+    Kc = env._calc_LQR_gain().cpu().numpy()
+    assert np.abs(Kc[1] - Kref).max() / np.abs(Kref).max() < 1e-6
+    if xcg == 25:
+        u = env._calc_LQR_action(0.1, -0.05, 0.02, torch.as_tensor(np.tile(Kref, (2, 1, 1)), device="cuda:0"),
+                                 np.tile(g["lqr_action_x9"], (2, 1)), np.tile(g["trim_x_xcg25"][13:16], (2, 1)))
+        np.testing.assert_allclose(u[0].cpu().numpy(), g["lqr_action_u"], rtol=1e-12)
+
+
+def qp_debug(env, Ad, Bd, Cd, dem, b, N):
+    n, rows = 3 * N, 15 * N
+    P, q, A = np.zeros((n, n)), np.zeros(n), np.zeros((rows, n))
+    l, u = np.zeros(rows), np.zeros(rows)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    from f16_mpc_oop_py_amd.env import _vp
+    rc = env.lib.f16_mpc_qp_debug(env.ctx.handle, _vp(Ad), _vp(Bd), _vp(Cd), _vp(env._x), _vp(dem), b, env.B, N, env.dt,
+                                  p(P), p(q), p(A), p(l), p(u))
+    assert rc == 0, env.lib.f16_last_error()
+    return P, q, A, l, u
+
+
+@pytest.mark.parametrize("xcg", [25, 35])
+@pytest.mark.parametrize("N", [4, 10, 30])
+def test_qp_build_vs_reference_setup_OSQP(xcg, N):
+    g5, g8 = golden("g567_trim_lin_lqr.npz"), golden("g8_mpc_qp.npz")
+    B = 3
+    env = make_env(np.tile(g5[f"trim_x_xcg{xcg}"], (B, 1)), xcg=xcg / 100)
+    Ad, Bd, Cd = (soa(np.tile(g5[f"ssr_{k}_xcg{xcg}"], (B, 1, 1))) for k in ("Ad", "Bd", "Cd"))
+    dem = torch.zeros((3, B), dtype=torch.float64, device="cuda:0")
+    P, q, A, l, u = qp_debug(env, Ad, Bd, Cd, dem, 1, N)
+    tag = f"xcg{xcg}_N{N}"
+    assert np.abs(P - g8[f"P_{tag}"]).max() / np.abs(g8[f"P_{tag}"]).max() < 1e-9
+    assert np.abs(q - g8[f"q_{tag}"]).max() / np.abs(g8[f"q_{tag}"]).max() < 1e-7
+    np.testing.assert_allclose(A, g8[f"A_{tag}"], rtol=1e-12, atol=1e-18)
+    fin = np.isfinite(g8[f"l_{tag}"])
+    assert np.array_equal(np.isfinite(l), fin) and np.array_equal(np.isfinite(u), np.isfinite(g8[f"u_{tag}"]))
+    np.testing.assert_allclose(l[fin], g8[f"l_{tag}"][fin], rtol=1e-12, atol=1e-12)
+    fin = np.isfinite(u)
+    np.testing.assert_allclose(u[fin], g8[f"u_{tag}"][fin], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("xcg", [25, 35])
+def test_mpc_action_vs_exact_minimiser_and_same_algorithm_oracle(xcg):
+    g5, g8 = golden("g567_trim_lin_lqr.npz"), golden("g8_mpc_qp.npz")
+    B, N = 4, 30
+    env = make_env(np.tile(g5[f"trim_x_xcg{xcg}"], (B, 1)), xcg=xcg / 100)
+    env.ssr = tuple(soa(np.tile(g5[f"ssr_{k}_xcg{xcg}"], (B, 1, 1))) for k in ("Ad", "Bd", "Cd"))
+    tag = f"xcg{xcg}_N{N}"
+    xstar = g8[f"xstar_{tag}"]
+    u, info = env._calc_MPC_action(0.0, 0.0, 0.0, N, return_info=True)
+    u = u.cpu().numpy()
+    # (a) OSQP-default tolerances: inside the solver band around the exact minimiser (~4e-3)
+    assert np.abs(u[0] - xstar[:3]).max() < 2e-2
+    assert int(info["status"].max()) == 0
+    # (b) same algorithm, same settings, in numpy: iterates agree to rounding, same iteration count
+    ref = mo.admm_osqp_style(*(g8[f"{k}_{tag}"] for k in "PqAlu"))
+    assert int(info["iters"][0]) == ref["iters"]
+    assert np.abs(info["u_seq"][0].cpu().numpy() - ref["x"]).max() < 1e-7
+    # (c) tight tolerances: converges to the exact minimiser
+    u, info = env._calc_MPC_action(0.0, 0.0, 0.0, N, settings=dict(eps_abs=1e-9, eps_rel=1e-9, max_iter=200000),
+                                   return_info=True)
+    assert np.abs(info["u_seq"][2].cpu().numpy() - xstar).max() < 1e-6
+    assert int(info["status"].max()) == 0
+    if xcg == 35:
+        np.testing.assert_allclose(u[3].cpu().numpy(), [-0.56435742, -0.01095324, 0.00097151], atol=2e-6)
+
+
+def test_mpc_batch_of_perturbed_aircraft_vs_oracle_chain(oracle):
+    """Config-4 shape at reduced batch: each aircraft linearised at its own state (xcg 0.35), N=30, demands != 0."""
+    from f16_mpc_oop_py_amd.workload import config2_states
+    B, N = 192, 30
+    x0, u0 = config2_states(B, seed=4)
+    env = make_env(x0, u0, xcg=0.35)
+    Ad, Bd, Cd = env.build_ssr()
+    dem = np.array([0.05, -0.02, 0.01])
+    u, info = env._calc_MPC_action(dem[0], dem[1], dem[2], N, return_info=True)
+    u = u.cpu().numpy()
+    st = info["status"].cpu().numpy()
+    Adh, Bdh, Cdh = (t.t().cpu().numpy() for t in (Ad, Bd, Cd))
+    # aircraft 26 sits on the lf2 = 25 bound and its linear model predicts leaving it: infeasible QP (OSQP would
+    # return NaN); aircraft 29 violates lf2 >= 0 by ~3e-5 only and converges slowly.
+    for b in (0, 17, 101, 150, 26, 29):
+        A_, B_, C_, D_ = oracle.linearise_na(x0[b], u3=u0[b, 1:], xcg=0.35)
+        Ado, Bdo, _, _ = mo.c2d(A_, B_, C_, D_, 0.001)
+        np.testing.assert_allclose(Adh[b].reshape(9, 9), Ado, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(Bdh[b].reshape(9, 3), Bdo, rtol=0, atol=1e-9)
+        # QP + solve from the GPU's own (Ad,Bd,Cd): same-algorithm agreement + exact-minimiser band
+        P, q, A, l, uu = mo.mpc_qp(x0[b], Adh[b].reshape(9, 9), Bdh[b].reshape(9, 3), Cdh[b].reshape(9, 9), N, 0.001, *dem)
+        ref = mo.admm_osqp_style(P, q, A, l, uu)
+        assert abs(int(info["iters"][b]) - ref["iters"]) <= 25, (b, int(info["iters"][b]), ref["iters"])
+        if ref["infeasible"]:
+            assert st[b] == 128 and np.isnan(u[b]).all()
+            continue
+        assert st[b] == 0
+        assert np.abs(u[b] - ref["x"][:3]).max() < 1e-4
+        if b != 29:
+            xs, _ = mo.qp_exact(P, q, A, l, uu)
+            assert np.abs(u[b] - xs[:3]).max() < 5e-2
+    assert set(np.unique(st)) <= {0, 128}
+
+
+def test_config4_workload_is_feasible_everywhere():
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(1024)
+    env = make_env(x0, u0, xcg=0.35)
+    env.build_ssr()
+    u, info = env._calc_MPC_action(0.0, 0.0, 0.0, 30, return_info=True)
+    assert int(info["status"].max()) == 0 and torch.isfinite(u).all()
+    assert int(info["iters"].max()) <= 2000
+
+
+def test_mpc_horizon_limits_and_closed_loop_smoke():
+    g5 = golden("g567_trim_lin_lqr.npz")
+    env = make_env(np.tile(g5["trim_x_xcg35"], (8, 1)), xcg=0.35)
+    env.build_ssr()
+    from f16_mpc_oop_py_amd import lib
+    with pytest.raises(lib.F16HipError):
+        env._calc_MPC_action(0, 0, 0, 41)
+    for N in (1, 2, 10, 40):
+        u = env._calc_MPC_action(0, 0, 0, N)
+        assert torch.isfinite(u).all()
+    # test_env.py:480-495 closed-loop pattern: cmd = MPC(...,10); u.values[1:] = cmd; step(u.values)
+    for _ in range(20):
+        cmd = env._calc_MPC_action(0.0, 0.0, 0.0, 10)
+        env._u[1:4] = cmd.t()
+        env.step()
+    assert int(env.status.max()) == 0 and torch.isfinite(env.x_values).all()
+    assert torch.allclose(env.x_values[0], env.x_values[7])       # identical aircraft stay identical
