@@ -43,14 +43,10 @@ def main():
     from f16_mpc_oop_py_amd import F16Batch
     from f16_mpc_oop_py_amd.workload import config2_states
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    from f16_mpc_oop_py_amd import dist as fdist
+    rank, world, local = fdist.init_from_env()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
         if world > 1:
@@ -86,11 +82,7 @@ def main():
         e.record()
         assert rc == 0
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = fdist.max_over_ranks(time.perf_counter() - t0, dev)
     kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
     assert int(env.status.max()) == 0, "an aircraft left the envelope"
     assert bool(torch.isfinite(traj[-1]).all())
@@ -112,36 +104,79 @@ def main():
                      "note": "B=4096 is 64 wavefronts on 1024 SIMDs: latency/issue-bound, see DESIGN.md"},
     }
 
-    if rank == 0 and world == 1 and not args.no_mpc and hasattr(env.lib, "f16_mpc_batch"):
-        out["mpc"] = bench_mpc(args, dev)
+    out["roofline"]["traffic"] = recorded_traffic(B, T)
+    if world > 1:
+        # the one data-path collective -- all-gather of the trajectory shards -- timed on its own
+        barrier()
+        t0 = time.perf_counter()
+        full = fdist.all_gather_trajectories(traj)
+        barrier()
+        tg = fdist.max_over_ranks(time.perf_counter() - t0, dev)
+        out["allgather"] = {"ms": tg * 1e3, "bytes_received_per_gpu": int(full.numel() * 8),
+                            "GB/s_per_gpu": full.numel() * 8 / tg / 1e9,
+                            "steps_per_s_including_collation": world * B * T / (elapsed / args.steps + tg)}
+        del full
+    if not args.no_mpc:
+        del traj
+        out["mpc"] = bench_mpc(args, dev, rank, world, fdist, barrier)
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(x0, u0, T)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        barrier()
         dist.destroy_process_group()
 
 
-def bench_mpc(args, dev):
-    """BASELINE config 4: B=4096, xcg=0.35, N=30, one calc_MPC_action per aircraft (linearised at its own state)."""
+def recorded_traffic(B, T):
+    """HBM bytes per k_rollout launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE/WRITE_SIZE,
+    corrected as MI355X_MICROARCH.md prescribes); recorded under profiles/ by tools/pmc_summary.py.  None if the
+    recorded run was a different workload."""
+    path = os.path.join(REPO, "profiles", "traffic_k_rollout.json")
+    try:
+        rec = json.load(open(path))
+        if rec.get("batch") == B and rec.get("euler_steps") == T:
+            return rec["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
+def bench_mpc(args, dev, rank, world, fdist, barrier):
+    """BASELINE config 4: B=4096/GPU, xcg=0.35, N=30, one calc_MPC_action per aircraft, (A,B) from each aircraft's
+    own linearisation.  Same barrier + max-over-ranks timing rule as the dynamics leg."""
     import torch
     from f16_mpc_oop_py_amd import F16Batch
     from f16_mpc_oop_py_amd.workload import config4_states
-    x0, u0 = config4_states(args.batch)
-    env = F16Batch(x0, u0, xcg=0.35, device=dev)
+    B = args.batch
+    x0, u0 = config4_states(B * world)
+    env = F16Batch(x0[rank * B:(rank + 1) * B], u0[rank * B:(rank + 1) * B], xcg=0.35, device=dev)
     env.build_ssr()
     env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn)
-    torch.cuda.synchronize()
-    n = 5
+    n = max(2, args.steps // 4)
+    barrier()
     t0 = time.perf_counter()
     for _ in range(n):
         u, info = env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn, return_info=True)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n
+    barrier()
+    dt = fdist.max_over_ranks(time.perf_counter() - t0, dev) / n
     it = info["iters"].cpu().numpy()
-    return {"metric": "MPC solves/sec (calc_MPC_action, N=%d, batch %d, xcg=0.35)" % (args.mpc_hzn, args.batch),
-            "value": args.batch / dt, "unit": "solves/s", "ms_per_batch": dt * 1e3,
-            "admm_iters": {"min": float(it.min()), "median": float(np.median(it)), "max": float(it.max())}}
+    assert fdist.or_status(info["status"]) == 0
+    # linearise + ZOH + LQR chain (BASELINE config 3)
+    env._calc_LQR_gain()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        env._calc_LQR_gain()
+    barrier()
+    dl = fdist.max_over_ranks(time.perf_counter() - t0, dev) / n
+    flop_per_solve = 5.2e6 + 1.15e5 * float(np.mean(it))          # SURVEY.md 8(d) dense-form accounting
+    return {"metric": "MPC solves/sec (calc_MPC_action, N=%d, batch %d per GPU, xcg=0.35)" % (args.mpc_hzn, B),
+            "value": world * B / dt, "unit": "solves/s", "ms_per_batch": dt * 1e3,
+            "admm_iters": {"min": float(it.min()), "median": float(np.median(it)), "max": float(it.max())},
+            "roofline": {"bound": "fp64 vector/MFMA (78.6 TF/s)", "achieved": flop_per_solve * B / dt / 1e12,
+                         "peak": 78.6, "unit": "TFLOP/s", "frac": flop_per_solve * B / dt / 78.6e12},
+            "linearise_zoh_lqr_per_s": world * B / dl}
 
 
 def cpu_baseline(x0, u0, T):
@@ -149,7 +184,8 @@ def cpu_baseline(x0, u0, T):
     workload (first n aircraft x T steps), single thread and all cores."""
     from oracle import mpc_oracle as mo
     ora = mo.COracle()
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 64)
     n1 = 256
     t0 = time.perf_counter()
     ora.rollout(x0[:n1], u0[:n1], T, store=True, nthreads=1)

@@ -1,0 +1,100 @@
+"""Multi-GPU layer: one process per GPU, aircraft sharded contiguously, ONE collective.
+
+The reference is single-process; aircraft never interact, so the batch is partitioned
+contiguously -- rank g owns aircraft [g*B/W, (g+1)*B/W) -- tables and constants are replicated, and there is
+no exchange inside the time loop.  The only data-path collective is the all-gather that collates the per-rank
+trajectory shards [T,18,B/W] (RCCL `ncclAllGather` over xGMI through torch.distributed's "nccl" backend; "gloo"
+on CPU tensors for the host-logic tests).  Scalars (max-over-ranks time, OR of status words) use all-reduce.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total, world, rank):
+    """Contiguous shard [lo, hi) of `total` aircraft for `rank` of `world`; sizes differ by at most one."""
+    base, rem = divmod(int(total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/LOCAL_RANK/MASTER_* (torchrun contract).
+    Returns (rank, world, local_rank).  World size 1 needs no process group."""
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend, **kw)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def all_gather_trajectories(traj_local, total=None):
+    """traj_local [T,18,Bl] (equal Bl on every rank) -> collated [T,18,W*Bl] on every rank, aircraft in global
+    order.  One all-gather of the contiguous shard; the [W,T,18,Bl] receive buffer is re-viewed, not copied twice."""
+    W = world_size()
+    if W == 1:
+        return traj_local
+    T, K, Bl = traj_local.shape
+    recv = torch.empty((W, T, K, Bl), dtype=traj_local.dtype, device=traj_local.device)
+    dist.all_gather_into_tensor(recv.view(-1), traj_local.contiguous().view(-1))   # flat: valid for RCCL and gloo
+    out = recv.permute(1, 2, 0, 3).reshape(T, K, W * Bl)
+    return out if total is None else out[..., :total]
+
+
+def max_over_ranks(value, device=None):
+    """max of a Python float over all ranks (the bench's timing rule)."""
+    if world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device=None):
+    if world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def or_status(status):
+    """Bitwise OR over every aircraft of every rank (int)."""
+    v = 0
+    s = status.detach().to("cpu").numpy()
+    for bit in (1, 2, 4, 8, 16, 32, 64, 128):
+        if (s & bit).any():
+            v |= bit
+    if world_size() == 1:
+        return v
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([(v >> k) & 1 for k in range(8)], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(sum(int(b) << k for k, b in enumerate(t.tolist())))
+
+
+def closed_loop_mpc_rollout(env, steps, hzn, p_dem=0.0, q_dem=0.0, r_dem=0.0, traj_every=1, gather=True):
+    """BASELINE config 5 / test_env.py:480-495 pattern on this rank's shard, then one all-gather:
+    per step  cmd = calc_MPC_action(p,q,r,hzn); u.values[1:] = cmd; step(u.values).
+    Returns the collated trajectory [steps//traj_every, 18, B_total] (or the local shard if gather=False)."""
+    T = steps // traj_every
+    traj = torch.empty((T, 18, env.B), dtype=torch.float64, device=env.device)
+    for k in range(steps):
+        cmd = env._calc_MPC_action(p_dem, q_dem, r_dem, hzn)
+        env._u[1:4] = cmd.t()
+        env.rollout(1)
+        if (k + 1) % traj_every == 0:
+            traj[(k + 1) // traj_every - 1] = env._x
+    return all_gather_trajectories(traj) if gather else traj

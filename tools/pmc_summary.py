@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output of `bench.py` into profiles/ (run after copying gpurun_out/prof_* back).
+
+  python tools/pmc_summary.py gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write r01
+
+writes profiles/<tag>_kernel_stats.csv (the --kernel-trace --stats summary), profiles/<tag>_pmc_k_rollout.csv (the
+two separate --pmc passes, FETCH_SIZE and WRITE_SIZE rows of the dominant kernel) and profiles/traffic_k_rollout.json
+(HBM bytes per k_rollout launch).  Unit/correction per /opt/skills/guides/MI355X_MICROARCH.md "HBM": counters are in
+KiB; WRITE_SIZE is exact for streaming stores; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, so the
+read side is doubled (an upper bound for our 8-byte-per-lane state loads)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+stats_dir, fetch_dir, write_dir, tag = sys.argv[1:5]
+batch, euler = (int(sys.argv[5]), int(sys.argv[6])) if len(sys.argv) > 6 else (4096, 1000)
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+out = os.path.join(REPO, "profiles")
+os.makedirs(out, exist_ok=True)
+
+
+def one(d, pat):
+    f = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    assert f, (d, pat)
+    return f[0]
+
+
+rows = list(csv.DictReader(open(one(stats_dir, "*kernel_stats.csv"))))
+with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=rows[0].keys())
+    w.writeheader()
+    for r in rows:
+        r["Name"] = r["Name"][:120]
+        w.writerow(r)
+kern = [r for r in rows if "k_rollout" in r["Name"]][0]
+
+
+def counter(d, name):
+    vals, meta = [], None
+    for r in csv.DictReader(open(one(d, "*counter_collection.csv"))):
+        if "k_rollout" in r["Kernel_Name"] and r["Counter_Name"] == name:
+            vals.append(float(r["Counter_Value"]))
+            meta = r
+    return vals, meta
+
+
+fetch, meta = counter(fetch_dir, "FETCH_SIZE")
+write, _ = counter(write_dir, "WRITE_SIZE")
+with open(os.path.join(out, f"{tag}_pmc_k_rollout.csv"), "w") as f:
+    f.write("kernel,counter,launches,mean_KiB,min_KiB,max_KiB,VGPR,LDS_bytes,workgroup\n")
+    for nm, v in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
+        f.write(f"k_rollout<64>,{nm},{len(v)},{sum(v)/len(v):.3f},{min(v):.3f},{max(v):.3f},{meta['VGPR_Count']},"
+                f"{meta['LDS_Block_Size']},{meta['Workgroup_Size']}\n")
+fk, wk = sum(fetch) / len(fetch), sum(write) / len(write)
+rec = {"kernel": "k_rollout<64>", "batch": batch, "euler_steps": euler,
+       "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "fetch_correction": 2.0,
+       "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024),
+       "algorithmic_bytes_per_launch": batch * euler * 144,
+       "rocprof_avg_kernel_ns": float(kern["AverageNs"]), "source": f"profiles/{tag}_pmc_k_rollout.csv"}
+json.dump(rec, open(os.path.join(out, "traffic_k_rollout.json"), "w"), indent=1)
+print(json.dumps(rec, indent=1))
