@@ -62,7 +62,14 @@ F16_DEV void atmos_dev(double alt, double vt, double &mach, double &qbar, double
   const double tfac = 1 - .703e-5 * alt;
   double temp = 519.0 * tfac;
   if (alt >= 35000.0) temp = 390;
+#ifdef F16_FAST_POW
+  // tfac^4.14 = (tfac^2)^2 * exp(0.14 log tfac): |0.14 log tfac| < 0.2 on the flight envelope keeps the
+  // exp-of-log error below 1 ulp; two exact-to-0.5ulp squarings on top => <= 2 ulp vs libm pow.
+  const double t2 = tfac * tfac;
+  const double rho = rho0 * ((t2 * t2) * exp(0.14 * log(tfac)));
+#else
   const double rho = rho0 * pow(tfac, 4.14);
+#endif
   mach = vt / sqrt(1.4 * 1716.3 * temp);
   qbar = .5 * rho * (vt * vt);
   ps = 1715.0 * rho * temp;
@@ -339,7 +346,11 @@ F16_DEV void plant(TP T, const double *__restrict__ LT, const double *xu, double
   sincos(theta, &st, &ct);
   sincos(phi, &sphi, &cphi);
   sincos(psi, &spsi, &cpsi);
+#ifdef F16_FAST_TAN
+  const double tt = st / ct;
+#else
   const double tt = tan(theta);
+#endif
   if (vt <= 0.01) vt = 0.01;
 
   const double Thr = xu[12], el = xu[13], ail = xu[14], rud = xu[15], lef = xu[16];
