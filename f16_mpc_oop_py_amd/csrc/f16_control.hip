@@ -21,6 +21,7 @@
 #include "f16_ctx.h"
 #include "f16_plant.hpp"
 #include "f16_smallmat.hpp"
+#include "f16_mpc.hpp"
 
 namespace f16 {
 
@@ -266,27 +267,6 @@ __global__ __launch_bounds__(64) void k_lqr(LqrArgs a) {
 }
 
 // ------------------------------------------------------------------------------------ MPC (QP build + ADMM)
-constexpr int MAXN = 40;                         // horizon limit of the LDS-resident solver
-constexpr int MAXT = (12 * MAXN + 63) / 64;      // constraint rows per lane
-__constant__ int SROW[6] = {2, 3, 4, 5, 6, 8};   // MPC states with finite bounds: alpha,beta,p,q,r,lf2 (parameters.py:59-95,135)
-__constant__ double SLB[6] = {-20., -30., -300., -100., -50., 0.};
-__constant__ double SUB[6] = {90., 30., 300., 100., 50., 25.};
-__constant__ double ULB[3] = {-25., -21.5, -30.}, UUB[3] = {25., 21.5, 30.};      // parameters.py:125-126
-__constant__ double RLB[3] = {-60., -80., -120.}, RUB[3] = {60., 80., 120.};      // parameters.py:128-129
-
-struct MpcArgs {
-  const double *Ad, *Bd, *Cd, *x, *dem;
-  double *ucmd, *useq, *info;
-  int32_t *status;
-  double *Ppk, *Apk;          // workspace [B][np] packed P and A'A
-  double *dbg;                // optional debug dump for ONE aircraft (dbg_b): q[n] G[N*27] pred[9N]
-  long dbg_b;
-  long B, ld;
-  int N;
-  double dt;
-  f16_qp_settings s;
-};
-
 // out[3j+c] = sum_{i>=j} sum_{r in rows} G_{i-j}[r][c] * v[i*NR + rr]   (CC' v restricted to `rows`)
 template <int NR>
 __device__ __forceinline__ void conv_adjoint(double *out, const double *G, const double *v, int N, const int *rows) {
@@ -313,13 +293,14 @@ __device__ __forceinline__ double conv_forward_row(const double *G, const double
   return s;
 }
 
+template <bool SETUP_ONLY>
 __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int N = a.N, n = 3 * N, np = n * (n + 1) / 2, ms = 6 * N, m = 12 * N;
   const int l = lane_id();
   Bump al{smem};
   // R0 is time-shared: DARE/dlyap scratch -> Q G_k / Qbar G_k blocks -> packed KKT inverse
-  const int r0 = max(max(np, 54 * N), 1200);
+  const int r0 = SETUP_ONLY ? max(54 * N, 1200) : max(max(np, 54 * N), 1200);
   double *Minv = al.take(r0);
   double *G = al.take(N * 27);
   double *A = al.take(81), *Bm = al.take(27), *Q = al.take(81), *Qb = al.take(81), *K = al.take(27);
@@ -448,13 +429,21 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
         }
       }
     }
-    if (a.dbg && b == a.dbg_b) {
-      for (int e = l; e < n; e += F16_WAVE) a.dbg[e] = qv[e];
-      for (int e = l; e < N * 27; e += F16_WAVE) a.dbg[n + e] = G[e];
-      for (int e = l; e < 9 * N; e += F16_WAVE) a.dbg[n + N * 27 + e] = pred[e];
+    if (a.ext) {   // per-aircraft extras for the register-resident solver / the debug entry point
+      double *ex = a.ext + (size_t)b * mpc_ext_doubles(N);
+      for (int e = l; e < n; e += F16_WAVE) ex[e] = qv[e];
+      for (int e = l; e < N * 27; e += F16_WAVE) ex[n + e] = G[e];
+      for (int e = l; e < 9 * N; e += F16_WAVE) ex[n + N * 27 + e] = pred[e];
     }
+    if (SETUP_ONLY) { __syncthreads(); continue; }
     // ---------------- ADMM (OSQP Algorithm 1, reduced dense form; settings a.s)
     double rho = a.s.rho;
+    if (!(rho > 0.0)) {   // automatic: balance the two terms of P + rho A'A
+      __syncthreads();
+      double tp = 0.0, ta = 0.0;
+      for (int e = l; e < n; e += F16_WAVE) { tp += Pg[tri(e, e)]; ta += Ag[tri(e, e)]; }
+      rho = fmin(fmax(sqrt(wave_sum(tp) / wave_sum(ta)), 1e-6), 1e6);
+    }
     const double sigma = a.s.sigma, alpha = a.s.alpha;
     auto build_minv = [&](double r) {
       __syncthreads();
@@ -594,10 +583,10 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
   }
 }
 
-static size_t mpc_lds_doubles(int N) {
+static size_t mpc_lds_doubles(int N, bool setup_only) {
   const int n = 3 * N, np = n * (n + 1) / 2, m = 12 * N;
   auto ev = [](int v) { return (size_t)((v + 1) & ~1); };
-  int r0 = np > 54 * N ? np : 54 * N;
+  int r0 = (!setup_only && np > 54 * N) ? np : 54 * N;
   if (r0 < 1200) r0 = 1200;
   return ev(r0) + ev(N * 27) + ev(81) * 3 + ev(27) * 2 + ev(n) * 5 + ev(m) + ev(9 * N) + ev(9) * 2;
 }
@@ -644,16 +633,19 @@ extern "C" int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, c
 
 extern "C" void f16_qp_default_settings(f16_qp_settings *s) {
   // OSQP defaults with the deterministic schedule of SURVEY.md 8(d) config 4
-  s->rho = 0.1; s->sigma = 1e-6; s->alpha = 1.6; s->eps_abs = 1e-3; s->eps_rel = 1e-3; s->eps_prim_inf = 1e-4;
+  s->rho = 0.0;   // 0 = automatic sqrt(tr P / tr A'A) (OSQP's 0.1 presumes its Ruiz scaling); > 0 = fixed start value
+  s->sigma = 1e-6; s->alpha = 1.6; s->eps_abs = 1e-3; s->eps_rel = 1e-3; s->eps_prim_inf = 1e-4;
   s->max_iter = 40000;            // env.py:421
   s->check_every = 25; s->rho_every = 100; s->adaptive_rho = 1;
 }
 
-static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream) {
+// mode 0: generic one-wave kernel (build + ADMM); 1: build only (workspace P, A'A, q|G|pred); 2: build, then the
+// register-resident 512-thread solver (N <= 32).
+static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream, int mode) {
   const int N = a.N;
   if (N < 1 || N > MAXN) return set_error(F16_EINVAL, "horizon must be 1..40 for the LDS-resident QP solver");
   const size_t np = (size_t)(3 * N) * (3 * N + 1) / 2;
-  const size_t need = 2 * np * (size_t)a.B * sizeof(double);
+  const size_t need = (2 * np + mpc_ext_doubles(N)) * (size_t)a.B * sizeof(double);
   {
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
@@ -665,13 +657,21 @@ static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream) {
   }
   a.Ppk = (double *)ctx->d_work;
   a.Apk = a.Ppk + np * (size_t)a.B;
-  const size_t lds = mpc_lds_doubles(N) * sizeof(double);
+  a.ext = mode ? a.Apk + np * (size_t)a.B : nullptr;
+  const size_t lds = mpc_lds_doubles(N, mode != 0) * sizeof(double);
   if (lds > 160 * 1024) return set_error(F16_EINVAL, "horizon too large for LDS");
-  if (int rc = hip_check(hipFuncSetAttribute((const void *)k_mpc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                         "hipFuncSetAttribute"))
+  if (mode == 0) {
+    if (int rc = hip_check(hipFuncSetAttribute((const void *)k_mpc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"))
+      return rc;
+    hipLaunchKernelGGL(k_mpc<false>, dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
+    return hip_check(hipGetLastError(), "f16_mpc_batch launch");
+  }
+  if (int rc = hip_check(hipFuncSetAttribute((const void *)k_mpc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"))
     return rc;
-  hipLaunchKernelGGL(k_mpc, dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
-  return hip_check(hipGetLastError(), "f16_mpc_batch launch");
+  hipLaunchKernelGGL(k_mpc<true>, dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
+  if (int rc = hip_check(hipGetLastError(), "f16_mpc_batch setup launch")) return rc;
+  if (mode == 1) return F16_OK;
+  return mpc_fast_solve_launch(ctx, a, stream);
 }
 
 extern "C" int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
@@ -681,10 +681,13 @@ extern "C" int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, c
   if (B == 0) return F16_OK;
   MpcArgs a{};
   a.Ad = Ad; a.Bd = Bd; a.Cd = Cd; a.x = x; a.dem = dem; a.ucmd = u_cmd; a.useq = u_seq; a.info = info; a.status = status;
-  a.B = B; a.ld = ld; a.N = hzn; a.dt = dt; a.dbg = nullptr; a.dbg_b = -1;
+  a.B = B; a.ld = ld; a.N = hzn; a.dt = dt;
   if (s) a.s = *s; else f16_qp_default_settings(&a.s);
-  if (a.s.check_every < 1 || a.s.rho_every < 1 || !(a.s.rho > 0) || !(a.s.sigma > 0)) return set_error(F16_EINVAL, "bad QP settings");
-  return mpc_launch(ctx, a, stream);
+  if (a.s.check_every < 1 || a.s.rho_every < 1 || !(a.s.rho >= 0) || !(a.s.sigma > 0)) return set_error(F16_EINVAL, "bad QP settings");
+  // solver selection: the register-resident solver covers N <= 32; a negative max_iter forces the generic kernel (tests)
+  const bool generic = hzn > FAST_MAXN || a.s.max_iter < 0;
+  if (a.s.max_iter < 0) a.s.max_iter = -a.s.max_iter;
+  return mpc_launch(ctx, a, stream, generic ? 0 : 2);
 }
 
 extern "C" int f16_mpc_qp_debug(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
@@ -695,24 +698,20 @@ extern "C" int f16_mpc_qp_debug(f16_ctx *ctx, const double *Ad, const double *Bd
   const int N = hzn, n = 3 * N, rows = 15 * N;
   if (N < 1 || N > MAXN) return set_error(F16_EINVAL, "horizon must be 1..40");
   const size_t np = (size_t)n * (n + 1) / 2;
-  const size_t ndbg = (size_t)n + N * 27 + 9 * N;
-  double *d_dbg = nullptr, *d_u = nullptr;
+  const size_t ndbg = mpc_ext_doubles(N);
+  double *d_u = nullptr;
   int rc;
-  if ((rc = hip_check(hipMalloc(&d_dbg, ndbg * sizeof(double)), "hipMalloc dbg"))) return rc;
-  if ((rc = hip_check(hipMalloc(&d_u, 3 * ld * sizeof(double)), "hipMalloc dbg u"))) { (void)hipFree(d_dbg); return rc; }
+  if ((rc = hip_check(hipMalloc(&d_u, 3 * ld * sizeof(double)), "hipMalloc dbg u"))) return rc;
   MpcArgs a{};
   a.Ad = Ad; a.Bd = Bd; a.Cd = Cd; a.x = x; a.dem = dem; a.ucmd = d_u; a.B = b + 1; a.ld = ld; a.N = N; a.dt = dt;
-  a.dbg = d_dbg; a.dbg_b = b;
   f16_qp_default_settings(&a.s);
-  a.s.max_iter = 0;                                 // build only
-  rc = mpc_launch(ctx, a, nullptr);
+  rc = mpc_launch(ctx, a, nullptr, 1);              // build only
   std::vector<double> dbg(ndbg), Ppk(np), xcol(18);
   if (!rc) rc = hip_check(hipDeviceSynchronize(), "sync");
-  if (!rc) rc = hip_check(hipMemcpy(dbg.data(), d_dbg, ndbg * sizeof(double), hipMemcpyDeviceToHost), "copy dbg");
+  if (!rc) rc = hip_check(hipMemcpy(dbg.data(), a.ext + ndbg * (size_t)b, ndbg * sizeof(double), hipMemcpyDeviceToHost), "copy ext");
   if (!rc) rc = hip_check(hipMemcpy(Ppk.data(), a.Ppk + np * (size_t)b, np * sizeof(double), hipMemcpyDeviceToHost), "copy P");
   for (int k = 0; k < 18 && !rc; ++k)
     rc = hip_check(hipMemcpy(&xcol[k], x + k * ld + b, sizeof(double), hipMemcpyDeviceToHost), "copy x");
-  (void)hipFree(d_dbg);
   (void)hipFree(d_u);
   if (rc) return rc;
   // reference-format QP (utils.py:111-165): P dense, A = [CC; I; D] (15N x 3N), l/u with +-inf rows kept

@@ -1,0 +1,40 @@
+// f16_mpc.hpp -- shared definitions of the MPC kernels (f16_control.hip: QP build + generic ADMM;
+// f16_mpc_solve.hip: register-resident ADMM for N <= 32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/f16_hip.h"
+#include "f16_ctx.h"
+
+namespace f16 {
+
+constexpr int MAXN = 40;                         // horizon limit of the LDS-resident solver
+constexpr int MAXT = (12 * MAXN + 63) / 64;      // constraint rows per lane
+static __constant__ int SROW[6] = {2, 3, 4, 5, 6, 8};   // MPC states with finite bounds: alpha,beta,p,q,r,lf2 (parameters.py:59-95,135)
+static __constant__ double SLB[6] = {-20., -30., -300., -100., -50., 0.};
+static __constant__ double SUB[6] = {90., 30., 300., 100., 50., 25.};
+static __constant__ double ULB[3] = {-25., -21.5, -30.}, UUB[3] = {25., 21.5, 30.};      // parameters.py:125-126
+static __constant__ double RLB[3] = {-60., -80., -120.}, RUB[3] = {60., 80., 120.};      // parameters.py:128-129
+
+struct MpcArgs {
+  const double *Ad, *Bd, *Cd, *x, *dem;
+  double *ucmd, *useq, *info;
+  int32_t *status;
+  double *Ppk, *Apk;          // workspace [B][np] packed P and A'A
+  double *ext;                // workspace [B][mpc_ext_doubles(N)]: q | G | pred (setup kernel -> fast solver / debug)
+  long B, ld;
+  int N;
+  double dt;
+  f16_qp_settings s;
+};
+
+
+// per-aircraft extras written by the setup kernel: q[n] | G[27N] | pred[9N]
+__host__ __device__ inline size_t mpc_ext_doubles(int N) { return (size_t)3 * N + 27 * N + 9 * N; }
+
+// f16_mpc_solve.hip
+constexpr int FAST_MAXN = 32;
+int mpc_fast_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream);
+
+}  // namespace f16
