@@ -1,7 +1,7 @@
 // f16_mpc_solve.hip -- register-resident OSQP-style ADMM for the condensed MPC QP (N <= 32), gfx950.
 //
 // Same algorithm, settings, termination / rho-update / infeasibility rules as the generic solver in
-// f16_control.hip (k_mpc) and as oracle/mpc_oracle.py:admm_osqp_style -- what changes is the mapping:
+// f16_control.hip (k_mpc) -- what changes is the mapping:
 //
 //   one 512-thread workgroup (8 wavefronts) per aircraft; the three linear operators of an ADMM iteration
 //     stage 1   t  = CCs' w_s      (3N x 6N, block upper-triangular Toeplitz)      utils.py:163 (A' part)
