@@ -80,6 +80,48 @@ __global__ __launch_bounds__(BLOCK) void k_linearise(LinArgs a) {
   }
 }
 
+// env.py:294-342 with the default _calc_xdot / get_obs (env.py:45): 18-state model, 22 perturbed columns.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_linearise_full(LinArgs a) {
+  __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
+  if (a.fi == 1) {
+    const double2 *src = reinterpret_cast<const double2 *>(a.tab);
+    double2 *dst = reinterpret_cast<double2 *>(tab);
+    for (int i = threadIdx.x; i < TABLE_IMAGE_DOUBLES / 2; i += BLOCK) dst[i] = src[i];
+    __syncthreads();
+  }
+  const long total = a.B * 22;
+  for (long e = (long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long)gridDim.x * BLOCK) {
+    const int c = (int)(e / a.B);          // 0..17 states, 18..21 inputs
+    const long b = e - (long)c * a.B;
+    double x[18], xp[18], u[4], up[4], f0[18], f1[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) { x[k] = a.x[k * a.ld + b]; xp[k] = x[k] + (k == c ? a.eps : 0.0); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { u[k] = a.u[k * a.ld + b]; up[k] = u[k] + (k == c - 18 ? a.eps : 0.0); }
+    int st = 0;
+    calc_xdot((const double *)tab, a.lofi, xp, up, f1, a.xcg, a.fi, a.flags, st);
+    calc_xdot((const double *)tab, a.lofi, x, u, f0, a.xcg, a.fi, a.flags, st);
+    if (c < 18) {
+#pragma unroll
+      for (int r = 0; r < 18; ++r) a.Ac[(r * 18 + c) * a.ld + b] = (f1[r] - f0[r]) / a.eps;
+      // C = d get_obs / dx, observed states [2,3,4,7,8,9,10,11,16,17] (parameters.py:134,160)
+      const int OBS[10] = {2, 3, 4, 7, 8, 9, 10, 11, 16, 17};
+#pragma unroll
+      for (int r = 0; r < 10; ++r) {
+        double d = 0.0;
+#pragma unroll
+        for (int k = 0; k < 18; ++k) if (k == OBS[r]) d = (xp[k] - x[k]) / a.eps;
+        a.Cc[(r * 18 + c) * a.ld + b] = d;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 18; ++r) a.Bc[(r * 4 + (c - 18)) * a.ld + b] = (f1[r] - f0[r]) / a.eps;
+    }
+    if (a.status && st) atomicOr(&a.status[b], st);
+  }
+}
+
 // ------------------------------------------------------------------------------------ small LDS allocator
 struct Bump {
   double *p;
@@ -98,60 +140,65 @@ __device__ __forceinline__ void store_soa(double *dst, const double *src, int n,
 // exp([[A,B],[0,0]] h) = [[E,F],[0,I]]: only the top 9x12 block [E F] is propagated.
 // Scaling-and-squaring Taylor: X = A h/2^s, Y = B h/2^s, T_1 = [X Y], T_{k+1} = X T_k/(k+1), 13 terms
 // (||X|| <= 0.5 => truncation < 1e-15 relative), then s squarings [E F] <- E [E F] + [0 F].
+template <int NS, int NI>
 __device__ void c2d_wave(const double *A, const double *Bm, double h, double *Ad, double *Bd, double *scr) {
+  constexpr int NW = NS + NI, NE = NS * NW;
   Bump al{scr};
-  double *X = al.take(81), *T = al.take(108), *Tn = al.take(108), *EF = al.take(108);
+  double *X = al.take(NS * NS), *T = al.take(NE), *Tn = al.take(NE), *EF = al.take(NE);
   const int l = lane_id();
   double rs = 0.0;
-  if (l < 9) {
-    for (int j = 0; j < 9; ++j) rs += fabs(A[l * 9 + j]);
-    for (int j = 0; j < 3; ++j) rs += fabs(Bm[l * 3 + j]);
+  if (l < NS) {
+    for (int j = 0; j < NS; ++j) rs += fabs(A[l * NS + j]);
+    for (int j = 0; j < NI; ++j) rs += fabs(Bm[l * NI + j]);
     rs *= fabs(h);
   }
   const double nrm = wave_max(rs);
   int s = 0;
   if (nrm > 0.5) s = min(40, (int)ceil(log2(nrm / 0.5)));
   const double sc = ldexp(h, -s);
-  for (int e = l; e < 81; e += F16_WAVE) X[e] = A[e] * sc;
-  for (int e = l; e < 108; e += F16_WAVE) {
-    const int i = e / 12, j = e - i * 12;
-    const double v = j < 9 ? A[i * 9 + j] * sc : Bm[i * 3 + (j - 9)] * sc;
+  for (int e = l; e < NS * NS; e += F16_WAVE) X[e] = A[e] * sc;
+  for (int e = l; e < NE; e += F16_WAVE) {
+    const int i = e / NW, j = e - i * NW;
+    const double v = j < NS ? A[i * NS + j] * sc : Bm[i * NI + (j - NS)] * sc;
     T[e] = v;
     EF[e] = v + (j == i ? 1.0 : 0.0);
   }
   __syncthreads();
   for (int k = 2; k <= 13; ++k) {
-    mm<false, false>(Tn, X, T, 9, 9, 12, 1.0 / k);
-    for (int e = l; e < 108; e += F16_WAVE) { T[e] = Tn[e]; EF[e] += Tn[e]; }
+    mm<false, false>(Tn, X, T, NS, NS, NW, 1.0 / k);
+    for (int e = l; e < NE; e += F16_WAVE) { T[e] = Tn[e]; EF[e] += Tn[e]; }
     __syncthreads();
   }
   for (int q = 0; q < s; ++q) {
-    for (int e = l; e < 81; e += F16_WAVE) X[e] = EF[(e / 9) * 12 + (e % 9)];   // E
+    for (int e = l; e < NS * NS; e += F16_WAVE) X[e] = EF[(e / NS) * NW + (e % NS)];   // E
     __syncthreads();
-    mm<false, false>(Tn, X, EF, 9, 9, 12);
-    for (int e = l; e < 108; e += F16_WAVE) {
-      const int j = e % 12;
-      EF[e] = Tn[e] + (j >= 9 ? EF[e] : 0.0);
+    mm<false, false>(Tn, X, EF, NS, NS, NW);
+    for (int e = l; e < NE; e += F16_WAVE) {
+      const int j = e % NW;
+      EF[e] = Tn[e] + (j >= NS ? EF[e] : 0.0);
     }
     __syncthreads();
   }
-  for (int e = l; e < 81; e += F16_WAVE) Ad[e] = EF[(e / 9) * 12 + (e % 9)];
-  for (int e = l; e < 27; e += F16_WAVE) Bd[e] = EF[(e / 3) * 12 + 9 + (e % 3)];
+  for (int e = l; e < NS * NS; e += F16_WAVE) Ad[e] = EF[(e / NS) * NW + (e % NS)];
+  for (int e = l; e < NS * NI; e += F16_WAVE) Bd[e] = EF[(e / NI) * NW + NS + (e % NI)];
   __syncthreads();
 }
 
 struct C2dArgs { const double *Ac, *Bc; double *Ad, *Bd; long B, ld; double dt; };
 
+template <int NS, int NI>
 __global__ __launch_bounds__(64) void k_c2d(C2dArgs a) {
-  __shared__ double smem[81 + 28 + 81 + 28 + 82 + 108 * 3];
+  constexpr int NW = NS + NI;
+  __shared__ double smem[2 * (NS * NS + 2) + 2 * (NS * NI + 2) + (NS * NS + 2) + 3 * (NS * NW + 2)];
   Bump al{smem};
-  double *A = al.take(81), *Bm = al.take(27), *Ad = al.take(81), *Bd = al.take(27), *scr = al.take(82 + 324);
+  double *A = al.take(NS * NS), *Bm = al.take(NS * NI), *Ad = al.take(NS * NS), *Bd = al.take(NS * NI);
+  double *scr = al.take(NS * NS + 2 + 3 * (NS * NW + 2) - 2);
   for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
-    load_soa(A, a.Ac, 81, a.ld, b);
-    load_soa(Bm, a.Bc, 27, a.ld, b);
-    c2d_wave(A, Bm, a.dt, Ad, Bd, scr);
-    store_soa(a.Ad, Ad, 81, a.ld, b);
-    store_soa(a.Bd, Bd, 27, a.ld, b);
+    load_soa(A, a.Ac, NS * NS, a.ld, b);
+    load_soa(Bm, a.Bc, NS * NI, a.ld, b);
+    c2d_wave<NS, NI>(A, Bm, a.dt, Ad, Bd, scr);
+    store_soa(a.Ad, Ad, NS * NS, a.ld, b);
+    store_soa(a.Bd, Bd, NS * NI, a.ld, b);
     __syncthreads();
   }
 }
@@ -618,8 +665,33 @@ extern "C" int f16_c2d_batch(f16_ctx *ctx, const double *Ac, const double *Bc, d
   if (!ctx || !Ac || !Bc || !Ad || !Bd || B < 0 || ld < B) return set_error(F16_EINVAL, "bad argument to f16_c2d_batch");
   if (B == 0) return F16_OK;
   C2dArgs a{Ac, Bc, Ad, Bd, B, ld, dt};
-  hipLaunchKernelGGL(k_c2d, dim3(wave_grid(B)), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((k_c2d<9, 3>), dim3(wave_grid(B)), dim3(64), 0, (hipStream_t)stream, a);
   return hip_check(hipGetLastError(), "f16_c2d_batch launch");
+}
+
+extern "C" int f16_linearise_full_batch(f16_ctx *ctx, const double *x, const double *u, double *Ac, double *Bc, double *Cc,
+                                        int32_t *status, long B, long ld, double eps, double xcg, int fi_flag, unsigned flags,
+                                        void *stream) {
+  if (!ctx || !x || !u || !Ac || !Bc || !Cc || B < 0 || ld < B) return set_error(F16_EINVAL, "bad argument to f16_linearise_full_batch");
+  if (B == 0) return F16_OK;
+  LinArgs a{ctx->d_tab, ctx->d_lofi, x, u, Ac, Bc, Cc, status, B, ld, eps, xcg, fi_flag, flags};
+  const long lanes = B * 22;
+  if (lanes <= 64L * 256) {
+    hipLaunchKernelGGL(k_linearise_full<64>, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
+  } else {
+    long blocks = (lanes + 255) / 256;
+    hipLaunchKernelGGL(k_linearise_full<256>, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, (hipStream_t)stream, a);
+  }
+  return hip_check(hipGetLastError(), "f16_linearise_full_batch launch");
+}
+
+extern "C" int f16_c2d_full_batch(f16_ctx *ctx, const double *Ac, const double *Bc, double *Ad, double *Bd, long B, long ld,
+                                  double dt, void *stream) {
+  if (!ctx || !Ac || !Bc || !Ad || !Bd || B < 0 || ld < B) return set_error(F16_EINVAL, "bad argument to f16_c2d_full_batch");
+  if (B == 0) return F16_OK;
+  C2dArgs a{Ac, Bc, Ad, Bd, B, ld, dt};
+  hipLaunchKernelGGL((k_c2d<18, 4>), dim3(wave_grid(B)), dim3(64), 0, (hipStream_t)stream, a);
+  return hip_check(hipGetLastError(), "f16_c2d_full_batch launch");
 }
 
 extern "C" int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, double *K, double *Pare,

@@ -49,6 +49,40 @@ class F16Batch:
         self.status = torch.zeros(self.B, dtype=torch.int32, device=self.device)
         self.ssr = None                         # (Ad,Bd,Cd) per aircraft once linearised (env.py:49-60)
 
+    # ------------------------------------------------------------------ env.py:198-292
+    @staticmethod
+    def trim(h_t, v_t, *, stab_flag=None, xcg=None, fi_flag=P.fi_flag, device="cuda:0", flags=0, maxiter=50000, context=None):
+        """Batched F16.trim: straight-and-level trim at altitudes h_t [B] (ft) and airspeeds v_t [B] (ft/s) by the
+        reference's Nelder-Mead, all conditions in one launch.  Returns (x_trim [B,18], info dict)."""
+        if not torch.cuda.is_available():
+            raise _lib.F16HipError("trim needs an AMD GPU (no CPU fallback)")
+        dev = torch.device(device)
+        torch.cuda.set_device(dev)
+        ctx = context or _lib.Context(dev.index or 0)
+        xcg = float(xcg) if xcg is not None else P.xcg_of(P.stab_flag if stab_flag is None else stab_flag)
+        h = torch.as_tensor(np.atleast_1d(np.asarray(h_t, dtype=np.float64)), device=dev)
+        v = torch.as_tensor(np.atleast_1d(np.asarray(v_t, dtype=np.float64)), device=dev)
+        B = h.shape[0]
+        assert v.shape[0] == B
+        xt = torch.empty((18, B), dtype=torch.float64, device=dev)
+        cost = torch.empty(B, dtype=torch.float64, device=dev)
+        iters = torch.zeros(B, dtype=torch.int32, device=dev)
+        nfev = torch.zeros(B, dtype=torch.int32, device=dev)
+        st = torch.zeros(B, dtype=torch.int32, device=dev)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(ctx.lib.f16_trim_batch(ctx.handle, _vp(h), _vp(v), _vp(xt), _vp(cost), _vp(iters), _vp(nfev), _vp(st), B, B,
+                                          xcg, int(fi_flag), int(flags), int(maxiter), None, stream), ctx.lib)
+        return xt.t(), dict(cost=cost, iters=iters, nfev=nfev, status=st, context=ctx)
+
+    @classmethod
+    def from_trim(cls, h_t, v_t, **kw):
+        """env.py:42-44: construct the batch at its trim points (x.initial_condition = trim, u = x[12:16])."""
+        tk = {k: kw[k] for k in ("stab_flag", "xcg", "fi_flag", "device", "flags") if k in kw}
+        x, info = cls.trim(h_t, v_t, **tk)
+        env = cls(x.cpu().numpy(), None, context=info["context"], **{k: v for k, v in kw.items() if k != "maxiter"})
+        env.trim_info = info
+        return env
+
     # ------------------------------------------------------------------ helpers
     def _soa(self, a, rows=None):
         """[B,k] (or [k], broadcast) host/device array -> contiguous state-major [k,B] fp64 on the GPU."""
@@ -178,6 +212,26 @@ class F16Batch:
         self._lin = (Ac, Bc, Cc)
         return (Ac.t().reshape(self.B, 9, 9), Bc.t().reshape(self.B, 9, 3), Cc.t().reshape(self.B, 9, 9),
                 torch.zeros((self.B, 9, 3), dtype=torch.float64, device=self.device))
+
+    def linearise_full(self, eps=1e-5, discretise=True):
+        """env.py:45-46: 18-state linearisation (default _calc_xdot/get_obs) at every aircraft's own (x, u) and its
+        zero-order-hold discretisation.  Returns dict(Ac [B,18,18], Bc [B,18,4], Cc [B,10,18], Dc, Ad, Bd)."""
+        B = self.B
+        Ac = torch.empty((324, B), dtype=torch.float64, device=self.device)
+        Bc = torch.empty((72, B), dtype=torch.float64, device=self.device)
+        Cc = torch.empty((180, B), dtype=torch.float64, device=self.device)
+        st = torch.zeros(B, dtype=torch.int32, device=self.device)
+        self._check(self.lib.f16_linearise_full_batch(self.ctx.handle, _vp(self._x), _vp(self._u), _vp(Ac), _vp(Bc), _vp(Cc),
+                                                      _vp(st), B, B, eps, self.xcg, self.fi_flag, self.flags, self._stream))
+        self.last_status = st
+        out = dict(Ac=Ac.t().reshape(B, 18, 18), Bc=Bc.t().reshape(B, 18, 4), Cc=Cc.t().reshape(B, 10, 18),
+                   Dc=torch.zeros((B, 10, 4), dtype=torch.float64, device=self.device))
+        if discretise:
+            Ad, Bd = torch.empty_like(Ac), torch.empty_like(Bc)
+            self._check(self.lib.f16_c2d_full_batch(self.ctx.handle, _vp(Ac), _vp(Bc), _vp(Ad), _vp(Bd), B, B, self.dt,
+                                                    self._stream))
+            out["Ad"], out["Bd"] = Ad.t().reshape(B, 18, 18), Bd.t().reshape(B, 18, 4)
+        return out
 
     def discretise(self, Ac=None, Bc=None):
         """scipy.signal.cont2discrete(..., dt) zero-order hold (env.py:50,351) per aircraft."""

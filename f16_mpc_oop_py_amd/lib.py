@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.environ.get("F16HIP_SO", os.path.join(HERE, "libf16hip.so"))   # override only for A/B experiments
-SOURCES = ["f16_api.hip", "f16_dynamics.hip", "f16_control.hip", "f16_mpc_solve.hip", "f16_tables.cpp"]
+SOURCES = ["f16_api.hip", "f16_dynamics.hip", "f16_control.hip", "f16_mpc_solve.hip", "f16_trim.hip", "f16_tables.cpp"]
 # Default build: FMA contraction on, tan = sin/cos, tfac^4.14 = tfac^4 * exp(0.14 log tfac)  (each <= 2 ulp away from
 # the strict form; measured: xdot max rel. error vs the CPU restatement unchanged at 5e-14, -16 % kernel time).
 # F16_STRICT=1 builds the expression-by-expression variant (no contraction, libm tan/pow): 97 % of xdot outputs
@@ -82,9 +82,12 @@ def load():
     L.f16_nlplant_batch.argtypes = [vp, vp, vp, vp, l, l, d, i, u, vp]
     L.f16_rollout.argtypes = [vp, vp, vp, vp, vp, l, l, i, i, d, d, i, u, vp]
     L.f16_xdot_na_batch.argtypes = [vp, vp, vp, vp, vp, vp, l, l, d, i, u, vp]
+    L.f16_trim_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, l, l, d, i, u, i, vp, vp]
     if hasattr(L, "f16_linearise_batch"):
         L.f16_linearise_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, l, l, d, d, i, u, vp]
         L.f16_c2d_batch.argtypes = [vp, vp, vp, vp, vp, l, l, d, vp]
+        L.f16_linearise_full_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, l, l, d, d, i, u, vp]
+        L.f16_c2d_full_batch.argtypes = [vp, vp, vp, vp, vp, l, l, d, vp]
         L.f16_lqr_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, l, l, vp]
         L.f16_qp_default_settings.argtypes = [ctypes.POINTER(QPSettings)]
         L.f16_qp_default_settings.restype = None

@@ -89,6 +89,14 @@ int f16_rollout(f16_ctx *ctx, double *x, const double *u, double *traj, int32_t 
 int f16_xdot_na_batch(f16_ctx *ctx, const double *x_full, const double *x9, const double *u3, double *xdot9,
                       int32_t *status, long B, long ld, double xcg, int fi_flag, unsigned flags, void *stream);
 
+/* ---- (2) batched trim ---------------------------------------------------- */
+/* env.py:198-292 F16.trim(h_t, v_t) for B flight conditions h[B], v[B] (device): the reference's Nelder-Mead
+ * (scipy defaults, tol 1e-10, maxiter 5e4; initial guess env.py:265-271 unless h_x0[5] on the HOST is given)
+ * -> x_trim[18][ld]; cost[B], iters[B], nfev[B], status[B] may be NULL. */
+int f16_trim_batch(f16_ctx *ctx, const double *h, const double *v, double *x_trim, double *cost, int32_t *iters,
+                   int32_t *nfev, int32_t *status, long B, long ld, double xcg, int fi_flag, unsigned flags,
+                   int maxiter, const double *h_x0, void *stream);
+
 /* ---- (2) batched control chain ---------------------------------------------------------- */
 /* env.py:294-342 with _calc_xdot_na/_get_obs_na at each aircraft's own point: x9 = x[mpc idx] of x[18][ld],
  * u3 = u[1..3] of u[4][ld] (self.u._get_mpc_u(), env.py:348): Ac[81][ld] Bc[27][ld] Cc[81][ld]
@@ -99,6 +107,13 @@ int f16_linearise_batch(f16_ctx *ctx, const double *x, const double *u, double *
 /* scipy.signal.cont2discrete(zoh) (env.py:50,351): Ad[81][ld], Bd[27][ld] = expm([[A,B],[0,0]] dt) blocks */
 int f16_c2d_batch(f16_ctx *ctx, const double *Ac, const double *Bc, double *Ad, double *Bd,
                   long B, long ld, double dt, void *stream);
+/* env.py:45-46: the 18-state model.  linearise with the default _calc_xdot/get_obs: Ac[324][ld] (18x18), Bc[72][ld]
+ * (18x4), Cc[180][ld] (10x18, observed states parameters.py:134); then cont2discrete(zoh): Ad[324][ld], Bd[72][ld]. */
+int f16_linearise_full_batch(f16_ctx *ctx, const double *x, const double *u, double *Ac, double *Bc, double *Cc,
+                             int32_t *status, long B, long ld, double eps, double xcg, int fi_flag,
+                             unsigned flags, void *stream);
+int f16_c2d_full_batch(f16_ctx *ctx, const double *Ac, const double *Bc, double *Ad, double *Bd,
+                       long B, long ld, double dt, void *stream);
 /* utils.py:219-245 dlqr with Q = Cd'Cd, R = I3 (env.py:353-356): K[27][ld] = -dlqr (3x9 row-major),
  * Pare[81][ld] = DARE solution (may be NULL). */
 int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, double *K, double *Pare,

@@ -146,6 +146,42 @@ class COracle:
         return A, B, C, D
 
 
+def trim(oracle, h_t, v_t, fi_flag=1, xcg=0.25):
+    """env.py:198-292 restated: scipy's Nelder-Mead (the reference's own optimiser call, env.py:273) on the C
+    restatement of _calc_xdot.  Returns (x_trim[18], scipy result)."""
+    from scipy.optimize import minimize
+    pi = np.pi
+
+    def obj(UX0):
+        P3, dh, da, dr, alpha = UX0
+        rho0 = 2.377e-3
+        tfac = 1 - 0.703e-5 * h_t
+        temp = 519 * tfac
+        if h_t >= 35000:
+            temp = 390
+        rho = rho0 * tfac ** 4.14
+        qbar = 0.5 * rho * v_t ** 2
+        ps = 1715 * rho * temp
+        dlef = 1.38 * alpha * 180 / pi - 9.05 * qbar / ps + 1.45
+        x = np.array([0, 0, h_t, 0, alpha, 0, v_t, alpha, 0, 0, 0, 0, P3, dh, da, dr, dlef, -alpha * 180 / pi])
+        x[12] = np.clip(x[12], 1000, 19000)
+        x[13] = np.clip(x[13], -25, 25)
+        x[14] = np.clip(x[14], -21.5, 21.5)
+        x[15] = np.clip(x[15], -30., 30)
+        x[7] = np.clip(x[7], -20. * pi / 180, 90 * pi / 180)
+        xd = oracle.calc_xdot(x, x[12:16], fi_flag, xcg)
+        w = np.array([0, 0, 5, 10, 10, 10, 2, 10, 10, 10, 10, 10.])
+        return np.matmul(w, xd[0:12] ** 2)
+
+    opt = minimize(obj, [5000, -0.09, 8.49, -0.01, 0.01], method="Nelder-Mead", tol=1e-10, options={"maxiter": 5e+04})
+    P3, dh, da, dr, al = opt.x
+    tfac = 1 - 0.703e-5 * h_t
+    temp = 390 if h_t >= 35000 else 519 * tfac
+    rho = 2.377e-3 * tfac ** 4.14
+    dlef = 1.38 * al * 180 / pi - 9.05 * (0.5 * rho * v_t ** 2) / (1715 * rho * temp) + 1.45
+    return np.array([0, 0, h_t, 0, al, 0, v_t, al, 0, 0, 0, 0, P3, dh, da, dr, dlef, -al * 180 / pi]), opt
+
+
 # ------------------------------------------------------- control chain
 def c2d(A, B, C, D, dt):
     """env.py:46,50,351 -- scipy.signal.cont2discrete, default method zoh."""

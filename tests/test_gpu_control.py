@@ -195,3 +195,19 @@ def test_mpc_horizon_limits_and_closed_loop_smoke():
         env.step()
     assert int(env.status.max()) == 0 and torch.isfinite(env.x_values).all()
     assert torch.allclose(env.x_values[0], env.x_values[7])       # identical aircraft stay identical
+
+
+@pytest.mark.parametrize("xcg", [25, 35])
+def test_linearise_full_18_state_and_zoh_vs_reference(xcg):
+    """env.py:45-46: 18-state forward-difference model + 22x22 zero-order hold."""
+    g = golden("g567_trim_lin_lqr.npz")
+    x = np.tile(g[f"trim_x_xcg{xcg}"], (3, 1))
+    env = make_env(x, xcg=xcg / 100)
+    r = {k: v.cpu().numpy() for k, v in env.linearise_full().items()}
+    for b in (0, 2):
+        np.testing.assert_allclose(r["Ac"][b], g[f"A18_xcg{xcg}"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(r["Bc"][b], g[f"B18_xcg{xcg}"], rtol=0, atol=1e-6)
+        assert np.array_equal(r["Cc"][b], g[f"C18_xcg{xcg}"])
+        np.testing.assert_allclose(r["Ad"][b], g[f"Ad18_xcg{xcg}"], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(r["Bd"][b], g[f"Bd18_xcg{xcg}"], rtol=0, atol=1e-8)
+    assert int(env.last_status.max()) == 0

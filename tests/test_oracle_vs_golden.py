@@ -164,3 +164,14 @@ def test_g9_admm_reaches_exact_minimiser_band(xcg):
     assert np.abs(tight["x"] - xs).max() < 1e-6
     if xcg == 35:
         np.testing.assert_allclose(xs[:3], [-0.56435742, -0.01095324, 0.00097151], atol=2e-6)
+
+
+@pytest.mark.parametrize("xcg", [25, 35])
+def test_g5_trim_restatement_reproduces_the_reference_trim(oracle, xcg):
+    """scipy Nelder-Mead on the restated objective lands on the reference's trim point bit for bit (1,932 evaluations
+    at xcg 0.25)."""
+    g = golden("g567_trim_lin_lqr.npz")
+    x, opt = mo.trim(oracle, 10000, 700, xcg=xcg / 100)
+    assert np.array_equal(x, g[f"trim_x_xcg{xcg}"])
+    if xcg == 25:
+        assert opt.nfev == 1932
