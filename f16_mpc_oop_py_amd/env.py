@@ -271,11 +271,13 @@ class F16Batch:
         return -(K @ (x_ref - x).unsqueeze(-1)).squeeze(-1) + u0
 
     # ------------------------------------------------------------------ env.py:373-424
-    def _calc_MPC_action(self, p_dem, q_dem, r_dem, hzn, settings=None, return_info=False):
+    def _calc_MPC_action(self, p_dem, q_dem, r_dem, hzn, settings=None, return_info=False, relinearise=False):
         """First MPC move [B,3] (dh,da,dr commands) for demands p,q,r (scalars or [B]) over horizon hzn, from the
         frozen reduced model self.ssr (env.py:385-387) and the current state.  The QP of utils.py:21-167 is solved
         on the GPU by OSQP-style ADMM (the reference calls the `osqp` package, env.py:420-422)."""
-        if self.ssr is None:
+        # relinearise=True: SURVEY.md 8f-2 -- the reduced model is re-derived at the CURRENT state on every call (the
+        # reference freezes it at construction, env.py:49-60; its test_env.py:625-687 loops re-linearise per step)
+        if self.ssr is None or relinearise:
             self.build_ssr()
         Ad, Bd, Cd = self.ssr
         dem = torch.empty((3, self.B), dtype=torch.float64, device=self.device)
