@@ -295,7 +295,7 @@ __device__ int dlyap_wave(const double *Phi, const double *Wm, double *X, double
 struct LqrArgs { const double *Ad, *Bd, *Cd; double *K, *Pare; int32_t *status; long B, ld; };
 
 __global__ __launch_bounds__(64) void k_lqr(LqrArgs a) {
-  __shared__ double smem[82 * 5 + 28 * 2 + DARE_SCRATCH + 100];
+  __shared__ double smem[82 * 5 + 28 * 2 + DARE_SCRATCH + 100];   // DARE scratch also serves lqr_gain_wave
   Bump al{smem};
   double *A = al.take(81), *Bm = al.take(27), *C = al.take(81), *Q = al.take(81), *X = al.take(81), *K = al.take(27);
   double *scr = al.take(DARE_SCRATCH + 90);
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
   const int l = lane_id();
   Bump al{smem};
   // R0 is time-shared: DARE/dlyap scratch -> Q G_k / Qbar G_k blocks -> packed KKT inverse
-  const int r0 = SETUP_ONLY ? max(54 * N, 1200) : max(max(np, 54 * N), 1200);
+  const int r0 = SETUP_ONLY ? max(54 * N, 1100) : max(max(np, 54 * N), 1100);
   double *Minv = al.take(r0);
   double *G = al.take(N * 27);
   double *A = al.take(81), *Bm = al.take(27), *Q = al.take(81), *Qb = al.take(81), *K = al.take(27);
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
   double *wbuf = al.take(m);
   double *pred = al.take(9 * N);      // MM x: A^(i+1) x
   double *x9 = al.take(9), *xref = al.take(9);
-  double *scr = Minv, *X = Minv + 760, *Phi = Minv + 842, *Wm = Minv + 924;
+  double *scr = Minv, *X = Minv + 760;                  // DARE scratch (748 doubles), then X (82)
   double *QG = Minv, *QbG = Minv + N * 27;
 
   for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
@@ -373,13 +373,10 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
     __syncthreads();
     dare_sda_wave(A, Bm, Q, X, scr);
     lqr_gain_wave(A, Bm, X, K, scr);                  // K_dlqr; the reference uses K = -dlqr (utils.py:96)
-    mm<false, false>(Phi, Bm, K, 9, 3, 9, -1.0);      // Phi = A + B K_ref = A - B K_dlqr
-    for (int e = l; e < 81; e += F16_WAVE) Phi[e] += A[e];
-    __syncthreads();
-    mm<true, false>(Wm, K, K, 9, 3, 9);               // W = Q + K'RK, R = I
-    for (int e = l; e < 81; e += F16_WAVE) Wm[e] += Q[e];
-    __syncthreads();
-    dlyap_wave(Phi, Wm, Qb, scr);                     // Q_bar (utils.py:100)
+    // Q_bar (utils.py:100) solves X = Phi' X Phi + Q + K'RK with Phi = A + B K: for the LQR gain K that equation IS the
+    // DARE, so its solution is the DARE solution X itself.  (Measured on the reference's trim models: SDA's X agrees
+    // with scipy.linalg.solve_discrete_lyapunov's Q_bar to 3e-13 relative -- closer than scipy's own DARE result.)
+    copy(Qb, X, 81);
     // ---------------- prediction blocks G_k = A^k B, pred_i = A^(i+1) x (utils.py:171-197 without forming CC/MM)
     copy(G, Bm, 27);
     for (int k = 1; k < N; ++k) mm<false, false>(G + k * 27, A, G + (k - 1) * 27, 9, 9, 3);
@@ -634,7 +631,7 @@ static size_t mpc_lds_doubles(int N, bool setup_only) {
   const int n = 3 * N, np = n * (n + 1) / 2, m = 12 * N;
   auto ev = [](int v) { return (size_t)((v + 1) & ~1); };
   int r0 = (!setup_only && np > 54 * N) ? np : 54 * N;
-  if (r0 < 1200) r0 = 1200;
+  if (r0 < 1100) r0 = 1100;
   return ev(r0) + ev(N * 27) + ev(81) * 3 + ev(27) * 2 + ev(n) * 5 + ev(m) + ev(9 * N) + ev(9) * 2;
 }
 

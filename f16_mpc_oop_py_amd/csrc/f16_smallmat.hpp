@@ -88,6 +88,7 @@ __device__ __forceinline__ bool inverse(double *M, int n, double *W, double *f) 
   return ok;
 }
 
+
 // ---- packed symmetric storage (lower triangle, row-major): element (i,j), i>=j at i(i+1)/2 + j.
 // With one row per lane the row reads hit bank slots (T_i + k) mod 32, T_i triangular numbers: a
 // permutation over 32 consecutive i, so ds_read_b64 is conflict-free; column reads are contiguous.
