@@ -43,7 +43,7 @@ __device__ __forceinline__ void stage_tables(double *lds, const double *__restri
   __syncthreads();
 }
 
-template <int BLOCK>
+template <int BLOCK, int FI>
 __global__ __launch_bounds__(BLOCK) void k_xdot(DynArgs a) {
   __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
   if (a.fi == 1) stage_tables(tab, a.tab);
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(BLOCK) void k_xdot(DynArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) u[k] = a.u[k * a.ld + b];
     int st = 0;
-    calc_xdot((const double *)tab, a.lofi, x, u, xd, a.xcg, a.fi, a.flags, st);
+    calc_xdot<FI>((const double *)tab, a.lofi, x, u, xd, a.xcg, a.fi, a.flags, st);
 #pragma unroll
     for (int k = 0; k < 18; ++k) a.out[k * a.ld + b] = xd[k];
     if (a.status) a.status[b] |= st;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(BLOCK) void k_nlplant(DynArgs a) {
   }
 }
 
-template <int BLOCK>
+template <int BLOCK, int FI>
 __global__ __launch_bounds__(BLOCK) void k_rollout(DynArgs a) {
   __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
   if (a.fi == 1) stage_tables(tab, a.tab);
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DynArgs a) {
       if (!(a.flags & FLAG_NO_ENVELOPE) && outside_envelope(x)) st |= ST_ENVELOPE;
       if (!(st & ST_ENVELOPE)) {
         double xd[18];
-        calc_xdot((const double *)tab, a.lofi, x, u, xd, a.xcg, a.fi, a.flags, st);
+        calc_xdot<FI>((const double *)tab, a.lofi, x, u, xd, a.xcg, a.fi, a.flags, st);
 #pragma unroll
         for (int k = 0; k < 18; ++k) x[k] += xd[k] * a.dt;   // env.py:126
       }
@@ -160,6 +160,26 @@ static Geometry geometry(long B) {
     else if ((g).block == 256) hipLaunchKernelGGL(KERN<256>, dim3((g).grid), dim3(256), 0, stream, args); \
     else hipLaunchKernelGGL(KERN<512>, dim3((g).grid), dim3(512), 0, stream, args);                       \
   } while (0)
+#ifndef F16_RT_FI
+#define F16_RT_FI 0
+#endif
+// same; the lofi model gets an instantiation with the fidelity fixed at compile time (3.94 vs 4.6 ms per 1000 steps at
+// B=4096).  For hifi the run-time-flag kernel measured FASTER than a compile-time one (4.59 vs 4.65 ms; 5.31 vs 4.85 G
+// steps/s at B=262144: the scheduler does worse on the merged basic block), so hifi keeps the run-time path.
+#define LAUNCH_BY_BLOCK_FI(KERN, g, stream, args)                                                              \
+  do {                                                                                                         \
+    const int fi_ = F16_RT_FI ? 2 : (args).fi;                                                                  \
+    if ((g).block == 64) {                                                                                     \
+      if (fi_ == 0) hipLaunchKernelGGL((KERN<64, 0>), dim3((g).grid), dim3(64), 0, stream, args);             \
+      else hipLaunchKernelGGL((KERN<64, -1>), dim3((g).grid), dim3(64), 0, stream, args);                      \
+    } else if ((g).block == 256) {                                                                             \
+      if (fi_ == 0) hipLaunchKernelGGL((KERN<256, 0>), dim3((g).grid), dim3(256), 0, stream, args);           \
+      else hipLaunchKernelGGL((KERN<256, -1>), dim3((g).grid), dim3(256), 0, stream, args);                    \
+    } else {                                                                                                   \
+      if (fi_ == 0) hipLaunchKernelGGL((KERN<512, 0>), dim3((g).grid), dim3(512), 0, stream, args);           \
+      else hipLaunchKernelGGL((KERN<512, -1>), dim3((g).grid), dim3(512), 0, stream, args);                    \
+    }                                                                                                          \
+  } while (0)
 
 static int check_common(f16_ctx *ctx, const void *p0, const void *p1, long B, long ld) {
   if (!ctx || !p0 || !p1 || B < 0 || ld < B) return set_error(F16_EINVAL, "bad argument (NULL pointer, B < 0 or ld < B)");
@@ -179,7 +199,7 @@ extern "C" int f16_xdot_batch(f16_ctx *ctx, const double *x, const double *u, do
   a.tab = ctx->d_tab; a.lofi = ctx->d_lofi; a.x = x; a.u = u; a.out = xdot; a.status = status;
   a.B = B; a.ld = ld; a.xcg = xcg; a.fi = fi_flag; a.flags = flags;
   Geometry g = geometry(B);
-  LAUNCH_BY_BLOCK(k_xdot, g, (hipStream_t)stream, a);
+  LAUNCH_BY_BLOCK_FI(k_xdot, g, (hipStream_t)stream, a);
   return hip_check(hipGetLastError(), "f16_xdot_batch launch");
 }
 
@@ -213,7 +233,7 @@ extern "C" int f16_rollout(f16_ctx *ctx, double *x, const double *u, double *tra
   a.B = B; a.ld = ld; a.nsteps = nsteps; a.traj_every = traj ? traj_every : nsteps + 1;
   a.dt = dt; a.xcg = xcg; a.fi = fi_flag; a.flags = flags;
   Geometry g = geometry(B);
-  LAUNCH_BY_BLOCK(k_rollout, g, (hipStream_t)stream, a);
+  LAUNCH_BY_BLOCK_FI(k_rollout, g, (hipStream_t)stream, a);
   return hip_check(hipGetLastError(), "f16_rollout launch");
 }
 

@@ -37,20 +37,23 @@ struct Axis {
 
 F16_DEV double lerp(double f1, double f2, const Axis &a) { return a.l * f2 + a.m * f1; }  // mexndinterp.c:197
 
-// Bracket v on breakpoints X[0..n-1] (monotone).  `guess` may be off by one or two cells.
+// Bracket v on breakpoints X[0..n-1] (monotone).  `guess` must be within one cell of the true cell (the arithmetic
+// guesses below are exact up to a rounding at a node).  All breakpoint reads (the ends and the four around the guess)
+// are independent, so the search costs ONE LDS round trip; the cell is then fixed up with compares and selects.
 template <typename TP>
 F16_DEV Axis bracket(TP X, int n, double v, int guess, bool &off) {
+  const int g = min(max(guess, 0), n - 2);
+  const int gm = max(g - 1, 0), gp = min(g + 2, n - 1);
   const double lo = X[0], hi = X[n - 1];
+  const double xm = X[gm], xg = X[g], xg1 = X[g + 1], xp = X[gp];
   off = !(v >= lo && v <= hi);
   v = fmin(fmax(v, lo), hi);
-  int j = min(max(guess, 0), n - 2);
-  j -= (j > 0 && v < X[j]);
-  j -= (j > 0 && v < X[j]);
-  j += (j < n - 2 && v >= X[j + 1]);
-  j += (j < n - 2 && v >= X[j + 1]);
-  const double x0 = X[j], x1 = X[j + 1];
+  const bool down = g > 0 && v < xg;                 // true cell is g-1
+  const bool up = g < n - 2 && v >= xg1;             // true cell is g+1
   Axis a;
-  a.j = j;
+  a.j = g - (down ? 1 : 0) + (up ? 1 : 0);
+  const double x0 = down ? xm : (up ? xg1 : xg);
+  const double x1 = down ? xg : (up ? xp : xg1);
   a.l = (v - x0) / (x1 - x0);
   a.m = 1 - a.l;
   return a;
@@ -75,6 +78,37 @@ F16_DEV void atmos_dev(double alt, double vt, double &mach, double &qbar, double
   ps = 1715.0 * rho * temp;
   if (ps == 0) ps = 1715;
 }
+
+
+#ifdef F16_FAST_TRIG
+// Branch-free sin/cos pair: 3-part Cody-Waite reduction by pi/2 (exact for |x| < ~1e6 rad) + Taylor polynomials on
+// |r| <= pi/4 (coefficients are the exact 1/k! values; truncation < 5e-17).  Measured <= 2 ulp from libm on
+// [-1e5, 1e5].  Unlike the libm call it contains no large-argument branch, so the five independent evaluations of a
+// plant step sit in ONE basic block and the scheduler interleaves their dependency chains (the kernel is bound by
+// fp64 dependent-issue latency at one wave per SIMD).
+F16_DEV void sincos_bf(double x, double *sn, double *cs) {
+  const double n = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-n, 1.57079632673412561417e+00, x);
+  r = fma(-n, 6.07710050630396597660e-11, r);
+  r = fma(-n, 2.02226624879595063154e-21, r);
+  const double z = r * r;
+  const double S[8] = {-1.66666666666666657e-01, 8.33333333333333322e-03, -1.98412698412698413e-04, 2.75573192239858925e-06, -2.50521083854417202e-08, 1.60590438368216133e-10, -7.64716373181981641e-13, 2.81145725434552060e-15};
+  const double C[9] = {-5.00000000000000000e-01, 4.16666666666666644e-02, -1.38888888888888894e-03, 2.48015873015873016e-05, -2.75573192239858883e-07, 2.08767569878681002e-09, -1.14707455977297245e-11, 4.77947733238738525e-14, -1.56192069685862253e-16};
+  double p = S[7], q = C[8];
+#pragma unroll
+  for (int k = 6; k >= 0; --k) p = fma(p, z, S[k]);
+#pragma unroll
+  for (int k = 7; k >= 0; --k) q = fma(q, z, C[k]);
+  const double s0 = fma(r * z, p, r), c0 = fma(z, q, 1.0);
+  const int k = (int)n & 3;
+  const double a = (k & 1) ? c0 : s0, b = (k & 1) ? s0 : c0;
+  *sn = (k & 2) ? -a : a;
+  *cs = ((k + 1) & 2) ? -b : b;
+}
+#define F16_SINCOS(x, s, c) sincos_bf(x, s, c)
+#else
+#define F16_SINCOS(x, s, c) sincos(x, s, c)
+#endif
 
 struct Aero {  // everything C/nlplant.c:185-240 (or :245-323) hands to the coefficient build-up
   double Cx, Cz, Cm, Cy, Cn, Cl;
@@ -328,7 +362,9 @@ F16_DEV void aero_lofi(const double *__restrict__ LT, double alpha, double beta,
 
 // C/nlplant.c:23-457.  xu[0..16] in, xdot[0..11] out (+ xdot[12..17] = nx,ny,nz,mach,qbar,ps when
 // OUTPUTS).  Returns mach/qbar/ps of the clamped-vt atmosphere call for reuse by the lef model.
-template <bool OUTPUTS, typename TP>
+// FI: 1 / 0 = fidelity fixed at compile time (no branch: lookups, trigonometry and the equations of motion form one
+// basic block the scheduler can interleave), -1 = decided by fi_flag at run time.
+template <bool OUTPUTS, int FI = -1, typename TP>
 F16_DEV void plant(TP T, const double *__restrict__ LT, const double *xu, double *xdot, double xcg, int fi_flag,
                    unsigned flags, int &status, double &qbar_out, double &ps_out) {
   const double g = 32.17, m = 636.94, B = 30.0, S = 300.0, cbar = 11.32, xcgr = 0.35;
@@ -340,17 +376,6 @@ F16_DEV void plant(TP T, const double *__restrict__ LT, const double *xu, double
   double vt = xu[6];
   const double alpha = xu[7] * r2d, beta = xu[8] * r2d;
   const double P = xu[9], Q = xu[10], R = xu[11];
-  double sa, ca, sb, cb, st, ct, sphi, cphi, spsi, cpsi;
-  sincos(xu[7], &sa, &ca);
-  sincos(xu[8], &sb, &cb);
-  sincos(theta, &st, &ct);
-  sincos(phi, &sphi, &cphi);
-  sincos(psi, &spsi, &cpsi);
-#ifdef F16_FAST_TAN
-  const double tt = st / ct;
-#else
-  const double tt = tan(theta);
-#endif
   if (vt <= 0.01) vt = 0.01;
 
   const double Thr = xu[12], el = xu[13], ail = xu[14], rud = xu[15], lef = xu[16];
@@ -358,20 +383,11 @@ F16_DEV void plant(TP T, const double *__restrict__ LT, const double *xu, double
   const double drud = rud / 30.0;
   double dlef = (1 - lef / 25.0);
 
-  double mach, qbar, ps;
-  atmos_dev(alt, vt, mach, qbar, ps);
-  qbar_out = qbar; ps_out = ps;
-
-  const double U = vt * ca * cb, V = vt * sb, W = vt * sa * cb;
-  xdot[0] = U * (ct * cpsi) + V * (sphi * cpsi * st - cphi * spsi) + W * (cphi * st * cpsi + sphi * spsi);
-  xdot[1] = U * (ct * spsi) + V * (sphi * spsi * st + cphi * cpsi) + W * (cphi * st * spsi - sphi * cpsi);
-  xdot[2] = U * st - V * (sphi * ct) - W * (cphi * ct);
-  xdot[3] = P + tt * (Q * sphi + R * cphi);
-  xdot[4] = Q * cphi - R * sphi;
-  xdot[5] = (Q * sphi + R * cphi) / ct;
-
+  // The table lookups and the six coefficient totals come FIRST (they need only alpha, beta, el, vt, rates, controls):
+  // the 45 interpolated values collapse to 6 doubles before the register-hungry sincos/pow code runs.
   Aero c;
-  if (fi_flag == 1) {
+  const bool hifi = FI < 0 ? fi_flag == 1 : FI == 1;
+  if (hifi) {
     aero_hifi(T, alpha, beta, el, flags, c, status);
   } else {
     dlef = 0.0;
@@ -398,6 +414,30 @@ F16_DEV void plant(TP T, const double *__restrict__ LT, const double *xu, double
   const double dLdR = (B / (2 * vt)) * (c.Clr + c.dClr_lef * dlef);
   const double dLdP = (B / (2 * vt)) * (c.Clp + c.dClp_lef * dlef);
   const double Cl_tot = c.Cl + c.dCl_lef * dlef + dLdail * dail + c.dCl_r30 * drud + dLdR * R + dLdP * P + c.dClbeta * beta;
+
+  // ---- trigonometry, atmosphere, navigation + kinematic equations (C/nlplant.c:90-176)
+  double sa, ca, sb, cb, st, ct, sphi, cphi, spsi, cpsi;
+  F16_SINCOS(xu[7], &sa, &ca);
+  F16_SINCOS(xu[8], &sb, &cb);
+  F16_SINCOS(theta, &st, &ct);
+  F16_SINCOS(phi, &sphi, &cphi);
+  F16_SINCOS(psi, &spsi, &cpsi);
+#ifdef F16_FAST_TAN
+  const double tt = st / ct;
+#else
+  const double tt = tan(theta);
+#endif
+  double mach, qbar, ps;
+  atmos_dev(alt, vt, mach, qbar, ps);
+  qbar_out = qbar; ps_out = ps;
+
+  const double U = vt * ca * cb, V = vt * sb, W = vt * sa * cb;
+  xdot[0] = U * (ct * cpsi) + V * (sphi * cpsi * st - cphi * spsi) + W * (cphi * st * cpsi + sphi * spsi);
+  xdot[1] = U * (ct * spsi) + V * (sphi * spsi * st + cphi * cpsi) + W * (cphi * st * spsi - sphi * cpsi);
+  xdot[2] = U * st - V * (sphi * ct) - W * (cphi * ct);
+  xdot[3] = P + tt * (Q * sphi + R * cphi);
+  xdot[4] = Q * cphi - R * sphi;
+  xdot[5] = (Q * sphi + R * cphi) / ct;
 
   const double Udot = R * V - Q * W - g * st + qbar * S * Cx_tot / m + Thr / m;
   const double Vdot = P * W - R * U + g * ct * sphi + qbar * S * Cy_tot / m;
@@ -452,11 +492,11 @@ F16_DEV void upd_lef_dev(double h, double V, double alpha, double lf1, double lf
 }
 
 // env.py:65-103: xdot[18] of the full actuated model.
-template <typename TP>
+template <int FI = -1, typename TP>
 F16_DEV void calc_xdot(TP T, const double *__restrict__ LT, const double *x, const double *u, double *xdot, double xcg,
                        int fi_flag, unsigned flags, int &status) {
   double qbar, ps;
-  plant<false>(T, LT, x, xdot, xcg, fi_flag, flags, status, qbar, ps);
+  plant<false, FI>(T, LT, x, xdot, xcg, fi_flag, flags, status, qbar, ps);
   xdot[12] = clipd(clipd(u[0], 1000, 19000) - x[12], -10000, 10000);      // utils.py:308-312
   xdot[13] = clipd(20.2 * (clipd(u[1], -25, 25) - x[13]), -60, 60);       // :314-318
   xdot[14] = clipd(20.2 * (clipd(u[2], -21.5, 21.5) - x[14]), -80, 80);   // :320-324
