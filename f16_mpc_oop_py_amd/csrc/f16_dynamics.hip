@@ -163,6 +163,9 @@ static Geometry geometry(long B) {
 #ifndef F16_RT_FI
 #define F16_RT_FI 0
 #endif
+#ifndef F16_CT_HIFI
+#define F16_CT_HIFI 0
+#endif
 // same; the lofi model gets an instantiation with the fidelity fixed at compile time (3.94 vs 4.6 ms per 1000 steps at
 // B=4096).  For hifi the run-time-flag kernel measured FASTER than a compile-time one (4.59 vs 4.65 ms; 5.31 vs 4.85 G
 // steps/s at B=262144: the scheduler does worse on the merged basic block), so hifi keeps the run-time path.
@@ -171,6 +174,7 @@ static Geometry geometry(long B) {
     const int fi_ = F16_RT_FI ? 2 : (args).fi;                                                                  \
     if ((g).block == 64) {                                                                                     \
       if (fi_ == 0) hipLaunchKernelGGL((KERN<64, 0>), dim3((g).grid), dim3(64), 0, stream, args);             \
+      else if (F16_CT_HIFI && fi_ == 1) hipLaunchKernelGGL((KERN<64, F16_CT_HIFI ? 1 : -1>), dim3((g).grid), dim3(64), 0, stream, args); \
       else hipLaunchKernelGGL((KERN<64, -1>), dim3((g).grid), dim3(64), 0, stream, args);                      \
     } else if ((g).block == 256) {                                                                             \
       if (fi_ == 0) hipLaunchKernelGGL((KERN<256, 0>), dim3((g).grid), dim3(256), 0, stream, args);           \

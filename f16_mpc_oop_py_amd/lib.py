@@ -19,7 +19,7 @@ SOURCES = ["f16_api.hip", "f16_dynamics.hip", "f16_control.hip", "f16_mpc_solve.
 if os.environ.get("F16_STRICT"):
     _NUMERICS = ["-ffp-contract=off"]
 else:
-    _NUMERICS = ["-ffp-contract=fast", "-DF16_FAST_TAN", "-DF16_FAST_POW", "-DF16_FAST_TRIG"]
+    _NUMERICS = ["-ffp-contract=fast", "-DF16_FAST_TAN", "-DF16_FAST_POW", "-DF16_FAST_TRIG", "-DF16_FAST_DIV"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result"] + _NUMERICS
 
 F16_ST = dict(ALPHA1=1, ALPHA2=2, BETA=4, EL=8, ENVELOPE=16, NONFINITE=32, QP_MAXITER=64, QP_INFEASIBLE=128)
