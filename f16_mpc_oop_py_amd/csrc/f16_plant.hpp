@@ -369,31 +369,31 @@ F16_DEV void aero_lofi(const double *__restrict__ LT, double alpha, double beta,
   c.eta_el = 1.0;
 }
 
-// C/nlplant.c:23-457.  xu[0..16] in, xdot[0..11] out (+ xdot[12..17] = nx,ny,nz,mach,qbar,ps when
-// OUTPUTS).  Returns mach/qbar/ps of the clamped-vt atmosphere call for reuse by the lef model.
-// FI: 1 / 0 = fidelity fixed at compile time (no branch: lookups, trigonometry and the equations of motion form one
-// basic block the scheduler can interleave), -1 = decided by fi_flag at run time.
-template <bool OUTPUTS, int FI = -1, typename TP>
-F16_DEV void plant(TP T, const double *__restrict__ LT, const double *xu, double *xdot, double xcg, int fi_flag,
-                   unsigned flags, int &status, double &qbar_out, double &ps_out) {
-  const double g = 32.17, m = 636.94, B = 30.0, S = 300.0, cbar = 11.32, xcgr = 0.35;
-  const double Heng = 0.0;
-  const double Jy = 55814.0, Jxz = 982.0, Jz = 63100.0, Jx = 9496.0;
-  const double r2d = 180.0 / 3.141592653589793;   // 180.0/acos(-1)
+// ---- C/nlplant.c:23-457 in three pieces ------------------------------------------------------------------------
+// (the single-wave kernels run them back to back; k_rollout_2w runs aero_totals on one wavefront while a second one
+//  runs plant_pre, see f16_dynamics.hip)
+struct Totals { double Cx, Cz, Cm, Cy, Cn, Cl; };   // C*_tot of C/nlplant.c:333-377
+struct Pre {                                        // trigonometry, atmosphere, body velocities
+  double sa, ca, sb, cb, st, ct, sphi, cphi;
+  double U, V, W, vt, mach, qbar, ps;
+};
 
-  const double alt = xu[2], phi = xu[3], theta = xu[4], psi = xu[5];
+// Table lookups + coefficient build-up (C/nlplant.c:183-377).  Needs xu[6..11], xu[13..16] only.
+// FI: 1 / 0 = fidelity fixed at compile time, -1 = decided by fi_flag at run time.
+template <int FI = -1, typename TP>
+F16_DEV void aero_totals(TP T, const double *__restrict__ LT, const double *xu, double xcg, int fi_flag, unsigned flags,
+                         Totals &t, int &status) {
+  const double B = 30.0, cbar = 11.32, xcgr = 0.35;
+  const double r2d = 180.0 / 3.141592653589793;   // 180.0/acos(-1)
   double vt = xu[6];
   const double alpha = xu[7] * r2d, beta = xu[8] * r2d;
   const double P = xu[9], Q = xu[10], R = xu[11];
   if (vt <= 0.01) vt = 0.01;
-
-  const double Thr = xu[12], el = xu[13], ail = xu[14], rud = xu[15], lef = xu[16];
+  const double el = xu[13], ail = xu[14], rud = xu[15], lef = xu[16];
   const double dail = F16_DIVC(ail, 21.5);
   const double drud = F16_DIVC(rud, 30.0);
   double dlef = (1 - F16_DIVC(lef, 25.0));
 
-  // The table lookups and the six coefficient totals come FIRST (they need only alpha, beta, el, vt, rates, controls):
-  // the 45 interpolated values collapse to 6 doubles before the register-hungry sincos/pow code runs.
   Aero c;
   const bool hifi = FI < 0 ? fi_flag == 1 : FI == 1;
   if (hifi) {
@@ -411,63 +411,79 @@ F16_DEV void plant(TP T, const double *__restrict__ LT, const double *xu, double
   const double kq = cbar / (2 * vt), kb = B / (2 * vt);
 #endif
   const double dXdQ = kq * (c.Cxq + c.dCxq_lef * dlef);
-  const double Cx_tot = c.Cx + c.dCx_lef * dlef + dXdQ * Q;
+  t.Cx = c.Cx + c.dCx_lef * dlef + dXdQ * Q;
   const double dZdQ = kq * (c.Czq + c.dCz_lef * dlef);
-  const double Cz_tot = c.Cz + c.dCz_lef * dlef + dZdQ * Q;
+  t.Cz = c.Cz + c.dCz_lef * dlef + dZdQ * Q;
   const double dMdQ = kq * (c.Cmq + c.dCmq_lef * dlef);
-  const double Cm_tot = c.Cm * c.eta_el + Cz_tot * (xcgr - xcg) + c.dCm_lef * dlef + dMdQ * Q + c.dCm;
+  t.Cm = c.Cm * c.eta_el + t.Cz * (xcgr - xcg) + c.dCm_lef * dlef + dMdQ * Q + c.dCm;
   const double dYdail = c.dCy_a20 + c.dCy_a20_lef * dlef;
   const double dYdR = kb * (c.Cyr + c.dCyr_lef * dlef);
   const double dYdP = kb * (c.Cyp + c.dCyp_lef * dlef);
-  const double Cy_tot = c.Cy + c.dCy_lef * dlef + dYdail * dail + c.dCy_r30 * drud + dYdR * R + dYdP * P;
+  t.Cy = c.Cy + c.dCy_lef * dlef + dYdail * dail + c.dCy_r30 * drud + dYdR * R + dYdP * P;
   const double dNdail = c.dCn_a20 + c.dCn_a20_lef * dlef;
   const double dNdR = kb * (c.Cnr + c.dCnr_lef * dlef);
   const double dNdP = kb * (c.Cnp + c.dCnp_lef * dlef);
-  const double Cn_tot = c.Cn + c.dCn_lef * dlef - Cy_tot * (xcgr - xcg) * (cbar / B) + dNdail * dail + c.dCn_r30 * drud +
-                        dNdR * R + dNdP * P + c.dCnbeta * beta;
+  t.Cn = c.Cn + c.dCn_lef * dlef - t.Cy * (xcgr - xcg) * (cbar / B) + dNdail * dail + c.dCn_r30 * drud + dNdR * R + dNdP * P +
+         c.dCnbeta * beta;
   const double dLdail = c.dCl_a20 + c.dCl_a20_lef * dlef;
   const double dLdR = kb * (c.Clr + c.dClr_lef * dlef);
   const double dLdP = kb * (c.Clp + c.dClp_lef * dlef);
-  const double Cl_tot = c.Cl + c.dCl_lef * dlef + dLdail * dail + c.dCl_r30 * drud + dLdR * R + dLdP * P + c.dClbeta * beta;
+  t.Cl = c.Cl + c.dCl_lef * dlef + dLdail * dail + c.dCl_r30 * drud + dLdR * R + dLdP * P + c.dClbeta * beta;
+}
 
-  // ---- trigonometry, atmosphere, navigation + kinematic equations (C/nlplant.c:90-176)
-  double sa, ca, sb, cb, st, ct, sphi, cphi, spsi, cpsi;
-  F16_SINCOS(xu[7], &sa, &ca);
-  F16_SINCOS(xu[8], &sb, &cb);
-  F16_SINCOS(theta, &st, &ct);
-  F16_SINCOS(phi, &sphi, &cphi);
+// Trigonometry, atmosphere, navigation + kinematic equations (C/nlplant.c:90-176): xdot[0..5].
+F16_DEV void plant_pre(const double *xu, Pre &p, double *xdot) {
+  const double alt = xu[2], phi = xu[3], theta = xu[4], psi = xu[5];
+  const double P = xu[9], Q = xu[10], R = xu[11];
+  double vt = xu[6];
+  if (vt <= 0.01) vt = 0.01;
+  p.vt = vt;
+  double spsi, cpsi;
+  F16_SINCOS(xu[7], &p.sa, &p.ca);
+  F16_SINCOS(xu[8], &p.sb, &p.cb);
+  F16_SINCOS(theta, &p.st, &p.ct);
+  F16_SINCOS(phi, &p.sphi, &p.cphi);
   F16_SINCOS(psi, &spsi, &cpsi);
 #ifdef F16_FAST_TAN
-  const double tt = st / ct;
+  const double tt = p.st / p.ct;
 #else
   const double tt = tan(theta);
 #endif
-  double mach, qbar, ps;
-  atmos_dev(alt, vt, mach, qbar, ps);
-  qbar_out = qbar; ps_out = ps;
-
-  const double U = vt * ca * cb, V = vt * sb, W = vt * sa * cb;
+  atmos_dev(alt, vt, p.mach, p.qbar, p.ps);
+  p.U = vt * p.ca * p.cb; p.V = vt * p.sb; p.W = vt * p.sa * p.cb;
+  const double U = p.U, V = p.V, W = p.W, st = p.st, ct = p.ct, sphi = p.sphi, cphi = p.cphi;
   xdot[0] = U * (ct * cpsi) + V * (sphi * cpsi * st - cphi * spsi) + W * (cphi * st * cpsi + sphi * spsi);
   xdot[1] = U * (ct * spsi) + V * (sphi * spsi * st + cphi * cpsi) + W * (cphi * st * spsi - sphi * cpsi);
   xdot[2] = U * st - V * (sphi * ct) - W * (cphi * ct);
   xdot[3] = P + tt * (Q * sphi + R * cphi);
   xdot[4] = Q * cphi - R * sphi;
   xdot[5] = (Q * sphi + R * cphi) / ct;
+}
 
-  const double Udot = R * V - Q * W - g * st + F16_DIVC(qbar * S * Cx_tot, m) + F16_DIVC(Thr, m);
-  const double Vdot = P * W - R * U + g * ct * sphi + F16_DIVC(qbar * S * Cy_tot, m);
-  const double Wdot = Q * U - P * V + g * ct * cphi + F16_DIVC(qbar * S * Cz_tot, m);
+// Force and moment equations (C/nlplant.c:383-436): xdot[6..11] (+ accels outputs 12..17 when OUTPUTS).
+template <bool OUTPUTS>
+F16_DEV void plant_post(const double *xu, const Pre &p, const Totals &t, double *xdot) {
+  const double g = 32.17, m = 636.94, B = 30.0, S = 300.0, cbar = 11.32;
+  const double Heng = 0.0;
+  const double Jy = 55814.0, Jxz = 982.0, Jz = 63100.0, Jx = 9496.0;
+  const double P = xu[9], Q = xu[10], R = xu[11], Thr = xu[12];
+  const double U = p.U, V = p.V, W = p.W, vt = p.vt, qbar = p.qbar;
+  const double st = p.st, ct = p.ct, sphi = p.sphi, cphi = p.cphi, cb = p.cb;
+  const double Udot = R * V - Q * W - g * st + F16_DIVC(qbar * S * t.Cx, m) + F16_DIVC(Thr, m);
+  const double Vdot = P * W - R * U + g * ct * sphi + F16_DIVC(qbar * S * t.Cy, m);
+  const double Wdot = Q * U - P * V + g * ct * cphi + F16_DIVC(qbar * S * t.Cz, m);
   xdot[6] = (U * Udot + V * Vdot + W * Wdot) / vt;
   xdot[7] = (U * Wdot - W * Udot) / (U * U + W * W);
   xdot[8] = (Vdot * vt - V * xdot[6]) / (vt * vt * cb);
 
-  const double L_tot = Cl_tot * qbar * S * B;
-  const double M_tot = Cm_tot * qbar * S * cbar;
-  const double N_tot = Cn_tot * qbar * S * B;
-  const double denom = Jx * Jz - Jxz * Jxz;
+  const double L_tot = t.Cl * qbar * S * B;
+  const double M_tot = t.Cm * qbar * S * cbar;
+  const double N_tot = t.Cn * qbar * S * B;
 #ifdef F16_FAST_DIV
-#define F16_DIV_DENOM *(1.0 / (9496.0 * 63100.0 - 982.0 * 982.0))
+  const double rdenom = 1.0 / (9496.0 * 63100.0 - 982.0 * 982.0);
+#define F16_DIV_DENOM *rdenom
 #else
+  const double denom = Jx * Jz - Jxz * Jxz;
 #define F16_DIV_DENOM / denom
 #endif
   xdot[9] = (Jz * L_tot + Jxz * N_tot - (Jz * (Jz - Jy) + Jxz * Jxz) * Q * R + Jxz * (Jx - Jy + Jz) * P * Q + Jxz * Q * Heng) F16_DIV_DENOM;
@@ -477,6 +493,7 @@ F16_DEV void plant(TP T, const double *__restrict__ LT, const double *xu, double
   if (OUTPUTS) {  // accels(), C/nlplant.c:512-552 (uses the UNclamped state[6])
     const double grav = 32.174;
     const double v6 = xu[6];
+    const double sa = p.sa, ca = p.ca, sb = p.sb;
     const double vel_u = v6 * cb * ca, vel_v = v6 * sb, vel_w = v6 * cb * sa;
     const double u_dot = cb * ca * xdot[6] - v6 * sb * ca * xdot[8] - v6 * cb * sa * xdot[7];
     const double v_dot = sb * xdot[6] + v6 * cb * xdot[8];
@@ -484,10 +501,24 @@ F16_DEV void plant(TP T, const double *__restrict__ LT, const double *xu, double
     xdot[12] = 1.0 / grav * (u_dot + Q * vel_w - R * vel_v) + st;
     xdot[13] = 1.0 / grav * (v_dot + R * vel_u - P * vel_w) - ct * sphi;
     xdot[14] = -1.0 / grav * (w_dot + P * vel_v - Q * vel_u) + ct * cphi;
-    xdot[15] = mach;
+    xdot[15] = p.mach;
     xdot[16] = qbar;
-    xdot[17] = ps;
+    xdot[17] = p.ps;
   }
+}
+
+// C/nlplant.c:23-457.  xu[0..16] in, xdot[0..11] out (+ xdot[12..17] = nx,ny,nz,mach,qbar,ps when OUTPUTS).
+// Returns qbar/ps of the clamped-vt atmosphere call for reuse by the lef model.  The lookups and the six coefficient
+// totals come FIRST: the 45 interpolated values collapse to 6 doubles before the register-hungry sincos/pow code runs.
+template <bool OUTPUTS, int FI = -1, typename TP>
+F16_DEV void plant(TP T, const double *__restrict__ LT, const double *xu, double *xdot, double xcg, int fi_flag,
+                   unsigned flags, int &status, double &qbar_out, double &ps_out) {
+  Totals t;
+  aero_totals<FI>(T, LT, xu, xcg, fi_flag, flags, t, status);
+  Pre p;
+  plant_pre(xu, p, xdot);
+  qbar_out = p.qbar; ps_out = p.ps;
+  plant_post<OUTPUTS>(xu, p, t, xdot);
 }
 
 F16_DEV double clipd(double a, double lo, double hi) { return fmin(fmax(a, lo), hi); }
@@ -511,12 +542,8 @@ F16_DEV void upd_lef_dev(double h, double V, double alpha, double lf1, double lf
   lf1_dot = LF_err * 7.25;
 }
 
-// env.py:65-103: xdot[18] of the full actuated model.
-template <int FI = -1, typename TP>
-F16_DEV void calc_xdot(TP T, const double *__restrict__ LT, const double *x, const double *u, double *xdot, double xcg,
-                       int fi_flag, unsigned flags, int &status) {
-  double qbar, ps;
-  plant<false, FI>(T, LT, x, xdot, xcg, fi_flag, flags, status, qbar, ps);
+// utils.py:308-330 + env.py:90-102: actuator and leading-edge-flap state derivatives xdot[12..17].
+F16_DEV void actuators_dev(const double *x, const double *u, double qbar, double ps, double *xdot) {
   xdot[12] = clipd(clipd(u[0], 1000, 19000) - x[12], -10000, 10000);      // utils.py:308-312
   xdot[13] = clipd(20.2 * (clipd(u[1], -25, 25) - x[13]), -60, 60);       // :314-318
   xdot[14] = clipd(20.2 * (clipd(u[2], -21.5, 21.5) - x[14]), -80, 80);   // :320-324
@@ -525,6 +552,15 @@ F16_DEV void calc_xdot(TP T, const double *__restrict__ LT, const double *x, con
   upd_lef_dev(x[2], x[6], x[7], x[17], x[16], qbar, ps, lf1_dot, lf2_dot);
   xdot[16] = lf2_dot;   // env.py:98,102: temp[4] -> xdot[16]
   xdot[17] = lf1_dot;
+}
+
+// env.py:65-103: xdot[18] of the full actuated model.
+template <int FI = -1, typename TP>
+F16_DEV void calc_xdot(TP T, const double *__restrict__ LT, const double *x, const double *u, double *xdot, double xcg,
+                       int fi_flag, unsigned flags, int &status) {
+  double qbar, ps;
+  plant<false, FI>(T, LT, x, xdot, xcg, fi_flag, flags, status, qbar, ps);
+  actuators_dev(x, u, qbar, ps, xdot);
 }
 
 // env.py:152-193: sv = full state with the 9 MPC states / 3 actuator positions already scattered in.
