@@ -239,6 +239,150 @@ __global__ __launch_bounds__(128) void k_rollout_2w(DynArgs a) {
   }
 }
 
+// Four-wavefront rollout (latency regime, hifi): one workgroup = 64 aircraft on the four SIMDs of a CU; the state is
+// split by owner and every wave integrates and range-checks what it owns:
+//   wave 0  x[0..8]   trigonometry, navigation + kinematic equations      | force equations, Euler x[0..8]
+//   wave 1  --        longitudinal lookups + totals (Cx, Cz, Cm); stores the PREVIOUS step's x[0..8] sample, which
+//                     wave 0 published at step start (takes 9 stores per sample off wave 0's critical path)
+//   wave 2  x[9..11]  lateral-directional lookups + totals (Cy, Cn, Cl)   | moment equations, Euler + store x[9..11]
+//   wave 3  x[12..17] atmosphere, actuator + flap models, Euler + store x[12..17]
+// First half of a step: all four in parallel; second half: force equations (wave 0) || moment equations (wave 2).
+// Two barriers per step; everything that crosses goes through lane-indexed (conflict-free) LDS arrays.
+// Same device functions and arithmetic as k_rollout.
+__global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
+  __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
+  __shared__ double xs[17][64], xt[8][64];   // xs: x[0..16] as published at step start ; xt: Cx Cz Cm Cy Cn Cl qbar ps
+  __shared__ int xenv[3][64], xst[2][64];
+  {
+    const double2 *src = reinterpret_cast<const double2 *>(a.tab);
+    double2 *dst = reinterpret_cast<double2 *>(tab);
+    for (int i = threadIdx.x; i < TABLE_IMAGE_DOUBLES / 2; i += 256) dst[i] = src[i];
+    __syncthreads();
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool envchk = !(a.flags & FLAG_NO_ENVELOPE);
+  for (long b0 = (long)blockIdx.x * 64; b0 < a.B; b0 += (long)gridDim.x * 64) {
+    const bool valid = b0 + lane < a.B;
+    const long b = valid ? b0 + lane : a.B - 1;           // ragged tail: shadow the last aircraft, never stored
+    double x[18], u[4];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) x[k] = a.out[k * a.ld + b];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = a.u[k * a.ld + b];
+    int st = a.status ? a.status[b] : 0;
+    double *tr = a.traj ? a.traj + b : nullptr;           // next sample to be written by THIS wave
+    int until_store = a.traj_every;
+    for (int t = 0; t <= a.nsteps; ++t) {
+      const bool last = t == a.nsteps;                    // extra trip: only flushes the final x[0..8] sample
+      // ---- step start: envelope test on the owned states (env.py:117-124), publish them
+      if (wave == 0) {
+        xenv[0][lane] = envchk && (x[2] < 0 || x[2] > 100000 || x[6] < 0 || x[6] > 900 || x[7] < -20. || x[7] > 90 ||
+                                   x[8] < -30. || x[8] > 30);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) xs[k][lane] = x[k];
+      } else if (wave == 2) {
+        xenv[1][lane] = envchk && (x[9] < -300 || x[9] > 300 || x[10] < -100 || x[10] > 100 || x[11] < -50 || x[11] > 50);
+#pragma unroll
+        for (int k = 9; k < 12; ++k) xs[k][lane] = x[k];
+      } else if (wave == 3) {
+        xenv[2][lane] = envchk && (x[12] < 1000 || x[12] > 19000 || x[13] < -25 || x[13] > 25 || x[14] < -21.5 ||
+                                   x[14] > 21.5 || x[15] < -30. || x[15] > 30 || x[16] < 0. || x[16] > 25);
+#pragma unroll
+        for (int k = 12; k < 17; ++k) xs[k][lane] = x[k];
+      }
+      __syncthreads();
+      if (wave == 1 && tr && t > 0 && --until_store == 0) {   // sample of the step that just finished
+        until_store = a.traj_every;
+        if (valid) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) __builtin_nontemporal_store(xs[k][lane], tr + k * a.ld);
+        }
+        tr += 18 * a.ld;
+      }
+      if (last) break;
+      if (xenv[0][lane] | xenv[1][lane] | xenv[2][lane]) st |= ST_ENVELOPE;
+      const bool live = !(st & ST_ENVELOPE);
+      Pre p;
+      double xd[18];
+      if (wave == 0) {
+        x[9] = xs[9][lane]; x[10] = xs[10][lane]; x[11] = xs[11][lane]; x[12] = xs[12][lane];
+        plant_pre<false>(x, p, xd);
+      } else if (wave == 3) {
+        x[2] = xs[2][lane]; x[6] = xs[6][lane]; x[7] = xs[7][lane];
+        double vt = x[6];
+        if (vt <= 0.01) vt = 0.01;
+        double mach, qbar, ps;
+        atmos_dev(x[2], vt, mach, qbar, ps);
+        xt[6][lane] = qbar; xt[7][lane] = ps;
+        if (live) {
+          actuators_dev(x, u, qbar, ps, xd);
+#pragma unroll
+          for (int k = 12; k < 18; ++k) x[k] += xd[k] * a.dt;   // env.py:126 on the actuator / flap states
+        }
+        if (tr && --until_store == 0) {
+          until_store = a.traj_every;
+          if (valid) {
+#pragma unroll
+            for (int k = 12; k < 18; ++k) __builtin_nontemporal_store(x[k], tr + k * a.ld);
+          }
+          tr += 18 * a.ld;
+        }
+      } else {
+#pragma unroll
+        for (int k = 6; k < 9; ++k) x[k] = xs[k][lane];
+#pragma unroll
+        for (int k = 13; k < 17; ++k) x[k] = xs[k][lane];
+        Totals tt;
+        int sa = 0;
+        if (wave == 1) {
+#pragma unroll
+          for (int k = 9; k < 12; ++k) x[k] = xs[k][lane];
+          aero_totals<1, 1>((const double *)tab, a.lofi, x, a.xcg, 1, a.flags, tt, sa);
+          xt[0][lane] = tt.Cx; xt[1][lane] = tt.Cz; xt[2][lane] = tt.Cm;
+        } else {
+          aero_totals<1, 2>((const double *)tab, a.lofi, x, a.xcg, 1, a.flags, tt, sa);
+          xt[3][lane] = tt.Cy; xt[4][lane] = tt.Cn; xt[5][lane] = tt.Cl;
+        }
+        xst[wave - 1][lane] = sa;
+      }
+      __syncthreads();
+      // ---- second half: force equations on wave 0 || moment equations on wave 2
+      if (wave == 0) {
+        if (live) {
+          p.qbar = xt[6][lane]; p.ps = xt[7][lane];
+          st |= xst[0][lane] | xst[1][lane];
+          plant_forces(x, p, xt[0][lane], xt[3][lane], xt[1][lane], xd);
+#pragma unroll
+          for (int k = 0; k < 9; ++k) x[k] += xd[k] * a.dt;   // env.py:126
+        }
+      } else if (wave == 2) {
+        if (live) {
+          plant_moments(x[9], x[10], x[11], xt[6][lane], xt[5][lane], xt[2][lane], xt[4][lane], xd);
+#pragma unroll
+          for (int k = 9; k < 12; ++k) x[k] += xd[k] * a.dt;
+        }
+        if (tr && --until_store == 0) {
+          until_store = a.traj_every;
+          if (valid) {
+#pragma unroll
+            for (int k = 9; k < 12; ++k) __builtin_nontemporal_store(x[k], tr + k * a.ld);
+          }
+          tr += 18 * a.ld;
+        }
+      }
+    }
+    if (valid && wave != 1) {
+      bool finite = true;
+      const int k0 = wave == 0 ? 0 : (wave == 2 ? 9 : 12), k1 = wave == 0 ? 9 : (wave == 2 ? 12 : 18);
+#pragma unroll
+      for (int k = 0; k < 18; ++k)
+        if (k >= k0 && k < k1) { finite = finite && isfinite(x[k]); a.out[k * a.ld + b] = x[k]; }
+      if (a.status) atomicOr(&a.status[b], st | (finite ? 0 : ST_NONFINITE));
+    }
+    __syncthreads();
+  }
+}
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_xdot_na(DynArgs a) {
   __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
@@ -288,6 +432,9 @@ static Geometry geometry(long B) {
 #endif
 #ifndef F16_NO_2W
 #define F16_NO_2W 0
+#endif
+#ifndef F16_USE_2W
+#define F16_USE_2W 0
 #endif
 // same; the lofi model gets an instantiation with the fidelity fixed at compile time (3.94 vs 4.6 ms per 1000 steps at
 // B=4096).  For hifi the run-time-flag kernel measured FASTER than a compile-time one (4.59 vs 4.65 ms; 5.31 vs 4.85 G
@@ -361,7 +508,8 @@ extern "C" int f16_rollout(f16_ctx *ctx, double *x, const double *u, double *tra
   a.dt = dt; a.xcg = xcg; a.fi = fi_flag; a.flags = flags;
   if (fi_flag == 1 && B <= 64L * 256 && !F16_NO_2W) {
     // latency regime: two wavefronts per 64 aircraft (lookups || trigonometry), one workgroup per CU
-    hipLaunchKernelGGL(k_rollout_2w, dim3((unsigned)((B + 63) / 64)), dim3(128), 0, (hipStream_t)stream, a);
+    if (F16_USE_2W) hipLaunchKernelGGL(k_rollout_2w, dim3((unsigned)((B + 63) / 64)), dim3(128), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_rollout_4w, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a);
     return hip_check(hipGetLastError(), "f16_rollout launch");
   }
   Geometry g = geometry(B);

@@ -380,7 +380,9 @@ struct Pre {                                        // trigonometry, atmosphere,
 
 // Table lookups + coefficient build-up (C/nlplant.c:183-377).  Needs xu[6..11], xu[13..16] only.
 // FI: 1 / 0 = fidelity fixed at compile time, -1 = decided by fi_flag at run time.
-template <int FI = -1, typename TP>
+// PART: 0 = all six totals; 1 = longitudinal only (Cx, Cz, Cm); 2 = lateral-directional only (Cy, Cn, Cl) -- the lookups
+// the other half needs are dead code and are dropped by the compiler (k_rollout_4w runs the halves on two wavefronts).
+template <int FI = -1, int PART = 0, typename TP>
 F16_DEV void aero_totals(TP T, const double *__restrict__ LT, const double *xu, double xcg, int fi_flag, unsigned flags,
                          Totals &t, int &status) {
   const double B = 30.0, cbar = 11.32, xcgr = 0.35;
@@ -410,28 +412,33 @@ F16_DEV void aero_totals(TP T, const double *__restrict__ LT, const double *xu, 
 #else
   const double kq = cbar / (2 * vt), kb = B / (2 * vt);
 #endif
-  const double dXdQ = kq * (c.Cxq + c.dCxq_lef * dlef);
-  t.Cx = c.Cx + c.dCx_lef * dlef + dXdQ * Q;
-  const double dZdQ = kq * (c.Czq + c.dCz_lef * dlef);
-  t.Cz = c.Cz + c.dCz_lef * dlef + dZdQ * Q;
-  const double dMdQ = kq * (c.Cmq + c.dCmq_lef * dlef);
-  t.Cm = c.Cm * c.eta_el + t.Cz * (xcgr - xcg) + c.dCm_lef * dlef + dMdQ * Q + c.dCm;
-  const double dYdail = c.dCy_a20 + c.dCy_a20_lef * dlef;
-  const double dYdR = kb * (c.Cyr + c.dCyr_lef * dlef);
-  const double dYdP = kb * (c.Cyp + c.dCyp_lef * dlef);
-  t.Cy = c.Cy + c.dCy_lef * dlef + dYdail * dail + c.dCy_r30 * drud + dYdR * R + dYdP * P;
-  const double dNdail = c.dCn_a20 + c.dCn_a20_lef * dlef;
-  const double dNdR = kb * (c.Cnr + c.dCnr_lef * dlef);
-  const double dNdP = kb * (c.Cnp + c.dCnp_lef * dlef);
-  t.Cn = c.Cn + c.dCn_lef * dlef - t.Cy * (xcgr - xcg) * (cbar / B) + dNdail * dail + c.dCn_r30 * drud + dNdR * R + dNdP * P +
-         c.dCnbeta * beta;
-  const double dLdail = c.dCl_a20 + c.dCl_a20_lef * dlef;
-  const double dLdR = kb * (c.Clr + c.dClr_lef * dlef);
-  const double dLdP = kb * (c.Clp + c.dClp_lef * dlef);
-  t.Cl = c.Cl + c.dCl_lef * dlef + dLdail * dail + c.dCl_r30 * drud + dLdR * R + dLdP * P + c.dClbeta * beta;
+  if (PART != 2) {
+    const double dXdQ = kq * (c.Cxq + c.dCxq_lef * dlef);
+    t.Cx = c.Cx + c.dCx_lef * dlef + dXdQ * Q;
+    const double dZdQ = kq * (c.Czq + c.dCz_lef * dlef);
+    t.Cz = c.Cz + c.dCz_lef * dlef + dZdQ * Q;
+    const double dMdQ = kq * (c.Cmq + c.dCmq_lef * dlef);
+    t.Cm = c.Cm * c.eta_el + t.Cz * (xcgr - xcg) + c.dCm_lef * dlef + dMdQ * Q + c.dCm;
+  }
+  if (PART != 1) {
+    const double dYdail = c.dCy_a20 + c.dCy_a20_lef * dlef;
+    const double dYdR = kb * (c.Cyr + c.dCyr_lef * dlef);
+    const double dYdP = kb * (c.Cyp + c.dCyp_lef * dlef);
+    t.Cy = c.Cy + c.dCy_lef * dlef + dYdail * dail + c.dCy_r30 * drud + dYdR * R + dYdP * P;
+    const double dNdail = c.dCn_a20 + c.dCn_a20_lef * dlef;
+    const double dNdR = kb * (c.Cnr + c.dCnr_lef * dlef);
+    const double dNdP = kb * (c.Cnp + c.dCnp_lef * dlef);
+    t.Cn = c.Cn + c.dCn_lef * dlef - t.Cy * (xcgr - xcg) * (cbar / B) + dNdail * dail + c.dCn_r30 * drud + dNdR * R + dNdP * P +
+           c.dCnbeta * beta;
+    const double dLdail = c.dCl_a20 + c.dCl_a20_lef * dlef;
+    const double dLdR = kb * (c.Clr + c.dClr_lef * dlef);
+    const double dLdP = kb * (c.Clp + c.dClp_lef * dlef);
+    t.Cl = c.Cl + c.dCl_lef * dlef + dLdail * dail + c.dCl_r30 * drud + dLdR * R + dLdP * P + c.dClbeta * beta;
+  }
 }
 
 // Trigonometry, atmosphere, navigation + kinematic equations (C/nlplant.c:90-176): xdot[0..5].
+template <bool ATMOS = true>
 F16_DEV void plant_pre(const double *xu, Pre &p, double *xdot) {
   const double alt = xu[2], phi = xu[3], theta = xu[4], psi = xu[5];
   const double P = xu[9], Q = xu[10], R = xu[11];
@@ -449,7 +456,8 @@ F16_DEV void plant_pre(const double *xu, Pre &p, double *xdot) {
 #else
   const double tt = tan(theta);
 #endif
-  atmos_dev(alt, vt, p.mach, p.qbar, p.ps);
+  if (ATMOS) atmos_dev(alt, vt, p.mach, p.qbar, p.ps);
+  else { p.mach = p.qbar = p.ps = 0.0; (void)alt; }
   p.U = vt * p.ca * p.cb; p.V = vt * p.sb; p.W = vt * p.sa * p.cb;
   const double U = p.U, V = p.V, W = p.W, st = p.st, ct = p.ct, sphi = p.sphi, cphi = p.cphi;
   xdot[0] = U * (ct * cpsi) + V * (sphi * cpsi * st - cphi * spsi) + W * (cphi * st * cpsi + sphi * spsi);
@@ -460,25 +468,28 @@ F16_DEV void plant_pre(const double *xu, Pre &p, double *xdot) {
   xdot[5] = (Q * sphi + R * cphi) / ct;
 }
 
-// Force and moment equations (C/nlplant.c:383-436): xdot[6..11] (+ accels outputs 12..17 when OUTPUTS).
-template <bool OUTPUTS>
-F16_DEV void plant_post(const double *xu, const Pre &p, const Totals &t, double *xdot) {
-  const double g = 32.17, m = 636.94, B = 30.0, S = 300.0, cbar = 11.32;
-  const double Heng = 0.0;
-  const double Jy = 55814.0, Jxz = 982.0, Jz = 63100.0, Jx = 9496.0;
+// Force equations (C/nlplant.c:383-405): xdot[6..8].
+F16_DEV void plant_forces(const double *xu, const Pre &p, double Cx_tot, double Cy_tot, double Cz_tot, double *xdot) {
+  const double g = 32.17, m = 636.94, S = 300.0;
   const double P = xu[9], Q = xu[10], R = xu[11], Thr = xu[12];
   const double U = p.U, V = p.V, W = p.W, vt = p.vt, qbar = p.qbar;
   const double st = p.st, ct = p.ct, sphi = p.sphi, cphi = p.cphi, cb = p.cb;
-  const double Udot = R * V - Q * W - g * st + F16_DIVC(qbar * S * t.Cx, m) + F16_DIVC(Thr, m);
-  const double Vdot = P * W - R * U + g * ct * sphi + F16_DIVC(qbar * S * t.Cy, m);
-  const double Wdot = Q * U - P * V + g * ct * cphi + F16_DIVC(qbar * S * t.Cz, m);
+  const double Udot = R * V - Q * W - g * st + F16_DIVC(qbar * S * Cx_tot, m) + F16_DIVC(Thr, m);
+  const double Vdot = P * W - R * U + g * ct * sphi + F16_DIVC(qbar * S * Cy_tot, m);
+  const double Wdot = Q * U - P * V + g * ct * cphi + F16_DIVC(qbar * S * Cz_tot, m);
   xdot[6] = (U * Udot + V * Vdot + W * Wdot) / vt;
   xdot[7] = (U * Wdot - W * Udot) / (U * U + W * W);
   xdot[8] = (Vdot * vt - V * xdot[6]) / (vt * vt * cb);
+}
 
-  const double L_tot = t.Cl * qbar * S * B;
-  const double M_tot = t.Cm * qbar * S * cbar;
-  const double N_tot = t.Cn * qbar * S * B;
+// Moment equations (C/nlplant.c:413-436): xdot[9..11].  Needs the body rates, qbar and Cl, Cm, Cn only.
+F16_DEV void plant_moments(double P, double Q, double R, double qbar, double Cl_tot, double Cm_tot, double Cn_tot, double *xdot) {
+  const double B = 30.0, S = 300.0, cbar = 11.32;
+  const double Heng = 0.0;
+  const double Jy = 55814.0, Jxz = 982.0, Jz = 63100.0, Jx = 9496.0;
+  const double L_tot = Cl_tot * qbar * S * B;
+  const double M_tot = Cm_tot * qbar * S * cbar;
+  const double N_tot = Cn_tot * qbar * S * B;
 #ifdef F16_FAST_DIV
   const double rdenom = 1.0 / (9496.0 * 63100.0 - 982.0 * 982.0);
 #define F16_DIV_DENOM *rdenom
@@ -489,6 +500,15 @@ F16_DEV void plant_post(const double *xu, const Pre &p, const Totals &t, double 
   xdot[9] = (Jz * L_tot + Jxz * N_tot - (Jz * (Jz - Jy) + Jxz * Jxz) * Q * R + Jxz * (Jx - Jy + Jz) * P * Q + Jxz * Q * Heng) F16_DIV_DENOM;
   xdot[10] = F16_DIVC(M_tot + (Jz - Jx) * P * R - Jxz * (P * P - R * R) - R * Heng, Jy);
   xdot[11] = (Jx * N_tot + Jxz * L_tot + (Jx * (Jx - Jy) + Jxz * Jxz) * P * Q - Jxz * (Jx - Jy + Jz) * Q * R + Jx * Q * Heng) F16_DIV_DENOM;
+}
+
+// Force and moment equations (C/nlplant.c:383-436): xdot[6..11] (+ accels outputs 12..17 when OUTPUTS).
+template <bool OUTPUTS>
+F16_DEV void plant_post(const double *xu, const Pre &p, const Totals &t, double *xdot) {
+  const double P = xu[9], Q = xu[10], R = xu[11];
+  const double qbar = p.qbar, st = p.st, ct = p.ct, sphi = p.sphi, cphi = p.cphi, cb = p.cb;
+  plant_forces(xu, p, t.Cx, t.Cy, t.Cz, xdot);
+  plant_moments(P, Q, R, qbar, t.Cl, t.Cm, t.Cn, xdot);
 
   if (OUTPUTS) {  // accels(), C/nlplant.c:512-552 (uses the UNclamped state[6])
     const double grav = 32.174;
