@@ -240,19 +240,24 @@ __global__ __launch_bounds__(128) void k_rollout_2w(DynArgs a) {
 }
 
 // Four-wavefront rollout (latency regime, hifi): one workgroup = 64 aircraft on the four SIMDs of a CU; the state is
-// split by owner and every wave integrates and range-checks what it owns:
-//   wave 0  x[0..8]   trigonometry, navigation + kinematic equations      | force equations, Euler x[0..8]
-//   wave 1  --        longitudinal lookups + totals (Cx, Cz, Cm); stores the PREVIOUS step's x[0..8] sample, which
-//                     wave 0 published at step start (takes 9 stores per sample off wave 0's critical path)
-//   wave 2  x[9..11]  lateral-directional lookups + totals (Cy, Cn, Cl)   | moment equations, Euler + store x[9..11]
-//   wave 3  x[12..17] atmosphere, actuator + flap models, Euler + store x[12..17]
-// First half of a step: all four in parallel; second half: force equations (wave 0) || moment equations (wave 2).
+// split by owner (every wave integrates and range-checks what it owns) and the table lookups -- the LDS-latency-bound
+// part of a step -- are spread over all four waves as four partial coefficient triples (aero_part<1..4>):
+//   wave 0  x[0..8]   trigonometry, navigation + kinematic eqs, longitudinal damping tables | force equations, Euler
+//   wave 1  --        longitudinal 3-D/2-D tables; stores the PREVIOUS step's x[0..8] sample that wave 0 published at
+//                     step start (takes 9 stores per sample off wave 0's critical path)
+//   wave 2  x[9..11]  lateral-directional 3-D/2-D tables                                    | moment equations, Euler
+//   wave 3  x[12..17] atmosphere, actuator + flap models (Euler), lateral damping tables
 // Two barriers per step; everything that crosses goes through lane-indexed (conflict-free) LDS arrays.
-// Same device functions and arithmetic as k_rollout.
+// Same terms as k_rollout (C/nlplant.c:333-377); the six totals are summed in a different order (ulp level).
+#ifdef F16_EXP_STAMP4W
+#define STAMP(acc) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; }
+#else
+#define STAMP(acc)
+#endif
 __global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
   __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
-  __shared__ double xs[17][64], xt[8][64];   // xs: x[0..16] as published at step start ; xt: Cx Cz Cm Cy Cn Cl qbar ps
-  __shared__ int xenv[3][64], xst[2][64];
+  __shared__ double xs[17][64], xt[14][64];  // xs: x[0..16] published at step start ; xt: 4 x 3 partial totals, qbar, ps
+  __shared__ int xenv[3][64], xst[4][64];
   {
     const double2 *src = reinterpret_cast<const double2 *>(a.tab);
     double2 *dst = reinterpret_cast<double2 *>(tab);
@@ -272,6 +277,9 @@ __global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
     int st = a.status ? a.status[b] : 0;
     double *tr = a.traj ? a.traj + b : nullptr;           // next sample to be written by THIS wave
     int until_store = a.traj_every;
+#ifdef F16_EXP_STAMP4W
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, t0 = __builtin_amdgcn_s_memtime();
+#endif
     for (int t = 0; t <= a.nsteps; ++t) {
       const bool last = t == a.nsteps;                    // extra trip: only flushes the final x[0..8] sample
       // ---- step start: envelope test on the owned states (env.py:117-124), publish them
@@ -290,7 +298,9 @@ __global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
 #pragma unroll
         for (int k = 12; k < 17; ++k) xs[k][lane] = x[k];
       }
+      STAMP(tD)
       __syncthreads();
+      STAMP(tA)
       if (wave == 1 && tr && t > 0 && --until_store == 0) {   // sample of the step that just finished
         until_store = a.traj_every;
         if (valid) {
@@ -302,20 +312,33 @@ __global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
       if (last) break;
       if (xenv[0][lane] | xenv[1][lane] | xenv[2][lane]) st |= ST_ENVELOPE;
       const bool live = !(st & ST_ENVELOPE);
+      // every wave sees the full published state (its own part is identical to its registers)
+      double xa[17];
+#pragma unroll
+      for (int k = 0; k < 17; ++k) xa[k] = xs[k][lane];
       Pre p;
-      double xd[18];
+      double xd[18], o[3];
+      int sa = 0;
       if (wave == 0) {
-        x[9] = xs[9][lane]; x[10] = xs[10][lane]; x[11] = xs[11][lane]; x[12] = xs[12][lane];
-        plant_pre<false>(x, p, xd);
-      } else if (wave == 3) {
-        x[2] = xs[2][lane]; x[6] = xs[6][lane]; x[7] = xs[7][lane];
-        double vt = x[6];
+        plant_pre<false>(xa, p, xd);
+        aero_part<3>((const double *)tab, xa, a.flags, o, sa);       // longitudinal damping derivatives (1-D tables)
+      } else if (wave == 1) {
+        aero_part<1>((const double *)tab, xa, a.flags, o, sa);       // longitudinal 3-D / 2-D tables
+      } else if (wave == 2) {
+        aero_part<2>((const double *)tab, xa, a.flags, o, sa);       // lateral-directional 3-D / 2-D tables
+      } else {
+        double vt = xa[6];
         if (vt <= 0.01) vt = 0.01;
         double mach, qbar, ps;
-        atmos_dev(x[2], vt, mach, qbar, ps);
-        xt[6][lane] = qbar; xt[7][lane] = ps;
+        atmos_dev(xa[2], vt, mach, qbar, ps);
+        xt[12][lane] = qbar; xt[13][lane] = ps;
+        aero_part<4>((const double *)tab, xa, a.flags, o, sa);       // lateral damping derivatives (1-D tables)
         if (live) {
-          actuators_dev(x, u, qbar, ps, xd);
+          double xq[18];
+#pragma unroll
+          for (int k = 0; k < 17; ++k) xq[k] = xa[k];
+          xq[17] = x[17];
+          actuators_dev(xq, u, qbar, ps, xd);
 #pragma unroll
           for (int k = 12; k < 18; ++k) x[k] += xd[k] * a.dt;   // env.py:126 on the actuator / flap states
         }
@@ -327,50 +350,52 @@ __global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
           }
           tr += 18 * a.ld;
         }
-      } else {
-#pragma unroll
-        for (int k = 6; k < 9; ++k) x[k] = xs[k][lane];
-#pragma unroll
-        for (int k = 13; k < 17; ++k) x[k] = xs[k][lane];
-        Totals tt;
-        int sa = 0;
-        if (wave == 1) {
-#pragma unroll
-          for (int k = 9; k < 12; ++k) x[k] = xs[k][lane];
-          aero_totals<1, 1>((const double *)tab, a.lofi, x, a.xcg, 1, a.flags, tt, sa);
-          xt[0][lane] = tt.Cx; xt[1][lane] = tt.Cz; xt[2][lane] = tt.Cm;
-        } else {
-          aero_totals<1, 2>((const double *)tab, a.lofi, x, a.xcg, 1, a.flags, tt, sa);
-          xt[3][lane] = tt.Cy; xt[4][lane] = tt.Cn; xt[5][lane] = tt.Cl;
-        }
-        xst[wave - 1][lane] = sa;
       }
+      // partial totals: wave 1 -> 0..2 (long. static), wave 0 -> 3..5 (long. damping), wave 2 -> 6..8, wave 3 -> 9..11
+      const int slot = wave == 1 ? 0 : (wave == 0 ? 3 : (wave == 2 ? 6 : 9));
+      xt[slot][lane] = o[0]; xt[slot + 1][lane] = o[1]; xt[slot + 2][lane] = o[2];
+      xst[wave][lane] = sa;
+      STAMP(tB)
       __syncthreads();
+      STAMP(tC)
       // ---- second half: force equations on wave 0 || moment equations on wave 2
-      if (wave == 0) {
-        if (live) {
-          p.qbar = xt[6][lane]; p.ps = xt[7][lane];
-          st |= xst[0][lane] | xst[1][lane];
-          plant_forces(x, p, xt[0][lane], xt[3][lane], xt[1][lane], xd);
+      if (wave == 0 || wave == 2) {
+        double ls[3], ldm[3], ts[3], td[3];
 #pragma unroll
-          for (int k = 0; k < 9; ++k) x[k] += xd[k] * a.dt;   // env.py:126
-        }
-      } else if (wave == 2) {
-        if (live) {
-          plant_moments(x[9], x[10], x[11], xt[6][lane], xt[5][lane], xt[2][lane], xt[4][lane], xd);
+        for (int k = 0; k < 3; ++k) { ls[k] = xt[k][lane]; ldm[k] = xt[3 + k][lane]; ts[k] = xt[6 + k][lane]; td[k] = xt[9 + k][lane]; }
+        Totals tt;
+        compose_totals(ls, ldm, ts, td, a.xcg, tt);
+        if (wave == 0) {
+          if (live) {
+            p.qbar = xt[12][lane]; p.ps = xt[13][lane];
+            st |= xst[0][lane] | xst[1][lane] | xst[2][lane] | xst[3][lane];
+            plant_forces(xa, p, tt.Cx, tt.Cy, tt.Cz, xd);
 #pragma unroll
-          for (int k = 9; k < 12; ++k) x[k] += xd[k] * a.dt;
-        }
-        if (tr && --until_store == 0) {
-          until_store = a.traj_every;
-          if (valid) {
-#pragma unroll
-            for (int k = 9; k < 12; ++k) __builtin_nontemporal_store(x[k], tr + k * a.ld);
+            for (int k = 0; k < 9; ++k) x[k] += xd[k] * a.dt;   // env.py:126
           }
-          tr += 18 * a.ld;
+        } else {
+          if (live) {
+            plant_moments(x[9], x[10], x[11], xt[12][lane], tt.Cl, tt.Cm, tt.Cn, xd);
+#pragma unroll
+            for (int k = 9; k < 12; ++k) x[k] += xd[k] * a.dt;
+          }
+          if (tr && --until_store == 0) {
+            until_store = a.traj_every;
+            if (valid) {
+#pragma unroll
+              for (int k = 9; k < 12; ++k) __builtin_nontemporal_store(x[k], tr + k * a.ld);
+            }
+            tr += 18 * a.ld;
+          }
         }
       }
     }
+#ifdef F16_EXP_STAMP4W
+    if (lane == 0 && blockIdx.x == 0 && a.traj) {   // diagnostic build: cycles per segment, per wave, into trajectory row 2
+      double *d = a.traj + 18 * a.ld * 2 + wave * 4;
+      d[0] = (double)tD; d[1] = (double)tA; d[2] = (double)tB; d[3] = (double)tC;
+    }
+#endif
     if (valid && wave != 1) {
       bool finite = true;
       const int k0 = wave == 0 ? 0 : (wave == 2 ? 9 : 12), k1 = wave == 0 ? 9 : (wave == 2 ? 12 : 18);

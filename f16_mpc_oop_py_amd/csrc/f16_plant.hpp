@@ -437,6 +437,61 @@ F16_DEV void aero_totals(TP T, const double *__restrict__ LT, const double *xu, 
   }
 }
 
+
+// The six totals as sums of four partial triples, so that four wavefronts can each look up one table family:
+//   PART 1  longitudinal, 3-D / 2-D tables  {Cx, Cz, Cm}_s        PART 3  longitudinal damping (1-D)  {Cx, Cz, Cm}_d
+//   PART 2  lateral, 3-D / 2-D tables       {Cy, Cn, Cl}_s        PART 4  lateral damping (1-D)       {Cy, Cn, Cl}_d
+// compose_totals() adds them and applies the cg-offset couplings of C/nlplant.c:347,367.  The terms are exactly those
+// of C/nlplant.c:333-377; only the order of the additions differs from the single-expression form (ulp level).
+template <int PART, typename TP>
+F16_DEV void aero_part(TP T, const double *xu, unsigned flags, double *out, int &status) {
+  const double B = 30.0, cbar = 11.32;
+  const double r2d = 180.0 / 3.141592653589793;
+  double vt = xu[6];
+  const double alpha = xu[7] * r2d, beta = xu[8] * r2d;
+  const double P = xu[9], Q = xu[10], R = xu[11];
+  if (vt <= 0.01) vt = 0.01;
+  const double el = xu[13], ail = xu[14], rud = xu[15], lef = xu[16];
+  const double dail = F16_DIVC(ail, 21.5);
+  const double drud = F16_DIVC(rud, 30.0);
+  const double dlef = (1 - F16_DIVC(lef, 25.0));
+  Aero c;
+  aero_hifi(T, alpha, beta, el, flags, c, status);     // lookups not used by this PART are dead code
+#ifdef F16_FAST_DIV
+  const double r2vt = 1.0 / (2 * vt);
+  const double kq = cbar * r2vt, kb = B * r2vt;
+#else
+  const double kq = cbar / (2 * vt), kb = B / (2 * vt);
+#endif
+  if (PART == 1) {
+    out[0] = c.Cx + c.dCx_lef * dlef;
+    out[1] = c.Cz + c.dCz_lef * dlef + kq * (c.dCz_lef * dlef) * Q;     // the dZdQ quirk keeps a 2-D term here
+    out[2] = c.Cm * c.eta_el + c.dCm_lef * dlef;
+  } else if (PART == 3) {
+    out[0] = kq * (c.Cxq + c.dCxq_lef * dlef) * Q;
+    out[1] = kq * c.Czq * Q;
+    out[2] = kq * (c.Cmq + c.dCmq_lef * dlef) * Q + c.dCm;
+  } else if (PART == 2) {
+    out[0] = c.Cy + c.dCy_lef * dlef + (c.dCy_a20 + c.dCy_a20_lef * dlef) * dail + c.dCy_r30 * drud;
+    out[1] = c.Cn + c.dCn_lef * dlef + (c.dCn_a20 + c.dCn_a20_lef * dlef) * dail + c.dCn_r30 * drud;
+    out[2] = c.Cl + c.dCl_lef * dlef + (c.dCl_a20 + c.dCl_a20_lef * dlef) * dail + c.dCl_r30 * drud;
+  } else {
+    out[0] = kb * (c.Cyr + c.dCyr_lef * dlef) * R + kb * (c.Cyp + c.dCyp_lef * dlef) * P;
+    out[1] = kb * (c.Cnr + c.dCnr_lef * dlef) * R + kb * (c.Cnp + c.dCnp_lef * dlef) * P + c.dCnbeta * beta;
+    out[2] = kb * (c.Clr + c.dClr_lef * dlef) * R + kb * (c.Clp + c.dClp_lef * dlef) * P + c.dClbeta * beta;
+  }
+}
+
+F16_DEV void compose_totals(const double *ls, const double *ld, const double *ts, const double *td, double xcg, Totals &t) {
+  const double B = 30.0, cbar = 11.32, xcgr = 0.35;
+  t.Cx = ls[0] + ld[0];
+  t.Cz = ls[1] + ld[1];
+  t.Cm = ls[2] + ld[2] + t.Cz * (xcgr - xcg);
+  t.Cy = ts[0] + td[0];
+  t.Cn = ts[1] + td[1] - t.Cy * (xcgr - xcg) * (cbar / B);
+  t.Cl = ts[2] + td[2];
+}
+
 // Trigonometry, atmosphere, navigation + kinematic equations (C/nlplant.c:90-176): xdot[0..5].
 template <bool ATMOS = true>
 F16_DEV void plant_pre(const double *xu, Pre &p, double *xdot) {
