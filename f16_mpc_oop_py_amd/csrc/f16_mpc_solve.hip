@@ -347,28 +347,42 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a, const FastDesc *__re
     // w = rho z - y of the start point (all zero)
     if (rown) { double *wdst = srow ? ws + tid : (tid < ms + n ? wc + (tid - ms) : wr + (tid - ms - n)); *wdst = 0.0; }
     __syncthreads();
+#ifdef F16_EXP_STAMPM
+    unsigned long long tS[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = __builtin_amdgcn_s_memtime();
+#define MSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t1 = __builtin_amdgcn_s_memtime(); tS[i] += t1 - t0; t0 = t1; }
+#else
+#define MSTAMP(i)
+#endif
     while (!done) {
       ++it;
       // stage 1 partials: (CCs' w_s) row segments
       p1[tid] = r1 >= 0 ? dot24(W1, ws + 6 * i01) : 0.0;
+      MSTAMP(0)
       __syncthreads();
+      MSTAMP(1)
       if (xown) {
         double t = 0.0;
 #pragma unroll
         for (int s = 0; s < 8; ++s) t += (s < c1) ? p1[f1 + s] : 0.0;
         rhs[tid] = sigma * xs - qe + (t + wc[tid] + (wr[tid] - (tid + 3 < n ? wr[tid + 3] : 0.0)));
       }
+      MSTAMP(2)
       __syncthreads();
+      MSTAMP(3)
       // stage 2: x~ = Minv rhs, four lanes per row
       {
         const double part = quad_sum(dot24(W2, rhs + FK * h2));
         if (h2 == 0 && r2 < n) xt[r2] = part;
       }
+      MSTAMP(4)
       __syncthreads();
+      MSTAMP(5)
       // stage 3 partials: (CCs x~) row segments; x relaxation
       p3[tid] = r3 >= 0 ? dot24_lds(w3run, xt + 3 * j03) : 0.0;
       if (xown) xs = alpha * xt[tid] + (1 - alpha) * xs;
+      MSTAMP(6)
       __syncthreads();
+      MSTAMP(7)
       if (rown) {
         double zt;
         if (srow) {
@@ -463,8 +477,13 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a, const FastDesc *__re
       }
       // w = rho z - y for the next iteration
       if (rown) { double *d = srow ? ws + tid : (tid < ms + n ? wc + (tid - ms) : wr + (tid - ms - n)); *d = rho * z - y; }
+      MSTAMP(8)
       __syncthreads();
+      MSTAMP(9)
     }
+#ifdef F16_EXP_STAMPM
+    if ((tid & 63) == 0 && a.useq && b == 0) for (int i = 0; i < 10; ++i) a.useq[(10 * (tid >> 6) + i) * a.ld + 1] = (double)tS[i] / it;
+#endif
     // res.x[0:3] (env.py:424); OSQP hands back NaN for a problem it certifies infeasible
     if (tid < 3) a.ucmd[tid * a.ld + b] = infeasible ? NAN : xs;
     if (a.useq && xown) a.useq[tid * a.ld + b] = infeasible ? NAN : xs;

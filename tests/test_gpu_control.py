@@ -237,3 +237,16 @@ def test_relinearised_mpc_and_trajectory_writers(tmp_path):
     assert "time,npos,epos,alt,phi,theta,psi,vel,alpha,beta,p,q,r,nx,ny,nz,mach,qbar,ps," in txt
     assert rows.shape == (steps, 23) and abs(rows[0, 3] - 10000.0) < 1.0 and abs(rows[0, 7] - 700.0) < 1.0
     assert 0.5 < rows[0, 16] < 0.8                                  # mach at 700 ft/s, 10 kft
+
+
+def test_config5_closed_loop_rollout_single_rank():
+    """BASELINE config 5 shape on one rank: per step calc_MPC_action then step, trajectory collated by dist (no group)."""
+    from f16_mpc_oop_py_amd import dist as fdist
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(128)
+    env = make_env(x0, u0, xcg=0.35)
+    env.build_ssr()
+    traj = fdist.closed_loop_mpc_rollout(env, steps=6, hzn=10, traj_every=2)
+    assert tuple(traj.shape) == (3, 18, 128) and torch.isfinite(traj).all()
+    assert torch.equal(traj[-1], env._x)
+    assert fdist.or_status(env.status) == 0
