@@ -47,14 +47,15 @@ def counter(d, name):
 
 
 fetch, meta = counter(fetch_dir, "FETCH_SIZE")
+kname = meta["Kernel_Name"].replace("void ", "").split("(")[0].replace(",", ";")
 write, _ = counter(write_dir, "WRITE_SIZE")
 with open(os.path.join(out, f"{tag}_pmc_k_rollout.csv"), "w") as f:
     f.write("kernel,counter,launches,mean_KiB,min_KiB,max_KiB,VGPR,LDS_bytes,workgroup\n")
     for nm, v in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
-        f.write(f"k_rollout<64>,{nm},{len(v)},{sum(v)/len(v):.3f},{min(v):.3f},{max(v):.3f},{meta['VGPR_Count']},"
+        f.write(f"{kname},{nm},{len(v)},{sum(v)/len(v):.3f},{min(v):.3f},{max(v):.3f},{meta['VGPR_Count']},"
                 f"{meta['LDS_Block_Size']},{meta['Workgroup_Size']}\n")
 fk, wk = sum(fetch) / len(fetch), sum(write) / len(write)
-rec = {"kernel": "k_rollout<64>", "batch": batch, "euler_steps": euler,
+rec = {"kernel": kname, "batch": batch, "euler_steps": euler,
        "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "fetch_correction": 2.0,
        "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024),
        "algorithmic_bytes_per_launch": batch * euler * 144,
