@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--euler-steps", type=int, default=1000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-mpc", action="store_true")
+    ap.add_argument("--no-large", action="store_true", help="skip the large-batch roofline leg")
+    ap.add_argument("--large-batch", type=int, default=262144)
     ap.add_argument("--mpc-hzn", type=int, default=30)
     args = ap.parse_args()
 
@@ -116,8 +118,10 @@ def main():
                             "GB/s_per_gpu": full.numel() * 8 / tg / 1e9,
                             "steps_per_s_including_collation": world * B * T / (elapsed / args.steps + tg)}
         del full
+    del traj
+    if not args.no_large:
+        out["roofline_large_batch"] = bench_large(args, dev, rank)
     if not args.no_mpc:
-        del traj
         out["mpc"] = bench_mpc(args, dev, rank, world, fdist, barrier)
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(x0, u0, T)
@@ -140,6 +144,41 @@ def recorded_traffic(B, T):
     except Exception:
         pass
     return None
+
+
+def bench_large(args, dev, rank):
+    """SURVEY.md 8(d) caveat: at B=4096 there are 64 wavefronts for 1024 SIMDs, so the HBM fraction of the same kernel
+    family is also reported where the chip is full: B=262,144 aircraft per GPU, 200 Euler steps, every state stored
+    (7.5 GB trajectory).  Same accounting (144 B per stored aircraft-step), HIP events on the launch stream."""
+    import torch
+    from f16_mpc_oop_py_amd import F16Batch
+    from f16_mpc_oop_py_amd.workload import config2_states
+    from f16_mpc_oop_py_amd.env import _vp
+    B, T = args.large_batch, 200
+    x0, u0 = config2_states(4096)                      # the verified config-2 set, tiled
+    reps = (B + 4095) // 4096
+    x0, u0 = np.tile(x0, (reps, 1))[:B], np.tile(u0, (reps, 1))[:B]
+    env = F16Batch(x0, u0, device=dev)
+    traj = torch.empty((T, 18, B), dtype=torch.float64, device=dev)
+    ts = []
+    for i in range(2 + 5):
+        env._x.copy_(env._x_init)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = env.lib.f16_rollout(env.ctx.handle, _vp(env._x), _vp(env._u), _vp(traj), _vp(env.status), B, B, T, 1,
+                                 env.dt, env.xcg, env.fi_flag, env.flags, env._stream)
+        e.record()
+        assert rc == 0
+        torch.cuda.synchronize()
+        if i >= 2:
+            ts.append(s.elapsed_time(e))
+    assert int(env.status.max()) == 0 and bool(torch.isfinite(traj[-1]).all())
+    ms = float(np.mean(ts))
+    gbs = B * T * BYTES_PER_STORED_STEP / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "k_rollout<256>", "batch_per_gpu": B, "euler_steps": T, "kernel_ms": ms,
+            "steps_per_s": B * T / (ms * 1e-3), "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": B * T * BYTES_PER_STORED_STEP,
+            "note": "one wave per SIMD on all 256 CUs; fp64/VALU issue-bound (~1,700 instructions per aircraft-step)"}
 
 
 def bench_mpc(args, dev, rank, world, fdist, barrier):

@@ -12,6 +12,7 @@
 // reference's batch of 4096 (= 64 wavefronts), by single-wave latency; algorithmic HBM traffic is
 // 320 B per aircraft-step for the state-resident step and 144 B per stored trajectory sample.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/f16_hip.h"
 #include "f16_ctx.h"
@@ -430,14 +431,19 @@ __global__ __launch_bounds__(BLOCK) void k_xdot_na(DynArgs a) {
 }
 
 // ------------------------------------------------------------------------------------ launchers
-// One lane per aircraft; with the table image in LDS a CU holds one workgroup, so small batches use
-// one-wave workgroups spread over as many CUs as possible and large batches 256-CU persistent grids.
+// One lane per aircraft; with the table image in LDS a CU holds one workgroup, so the workgroup size decides how many
+// waves share a SIMD.  hifi: the plant wants ~256 VGPRs, and at two waves per SIMD (512-lane workgroups, 256 unified
+// registers each) the allocator falls back to AGPR spill moves -- measured 5.7 G steps/s against 14-16 G steps/s with
+// ONE wave per SIMD (256 lanes) at B >= 131,072 -- so hifi never exceeds 256 lanes; lofi (small plant) gains from 512.
 struct Geometry { int block, grid; };
-static Geometry geometry(long B) {
+static Geometry geometry(long B, int fi) {
   Geometry g;
   if (B <= 64L * 256) g.block = 64;          // <= 256 one-wave workgroups: one per CU
-  else if (B <= 256L * 256) g.block = 256;   // one wave per SIMD
-  else g.block = 512;                        // two waves per SIMD (the plant needs ~256 VGPRs: no third)
+  else if (B <= 128L * 256) g.block = 128;   // fill all 256 CUs before stacking waves on a CU
+  else if (B <= 256L * 256 || fi == 1) g.block = 256;   // one wave per SIMD
+  else g.block = 512;                        // two waves per SIMD
+  static const int force = [] { const char *e = getenv("F16_DYN_BLOCK"); return e ? atoi(e) : 0; }();   // tuning knob
+  if (force == 64 || force == 128 || force == 256 || force == 512) g.block = force;
   long blocks = (B + g.block - 1) / g.block;
   g.grid = (int)(blocks < 256 ? blocks : 256);
   return g;
@@ -446,6 +452,7 @@ static Geometry geometry(long B) {
 #define LAUNCH_BY_BLOCK(KERN, g, stream, args)                                       \
   do {                                                                               \
     if ((g).block == 64) hipLaunchKernelGGL(KERN<64>, dim3((g).grid), dim3(64), 0, stream, args);        \
+    else if ((g).block == 128) hipLaunchKernelGGL(KERN<128>, dim3((g).grid), dim3(128), 0, stream, args); \
     else if ((g).block == 256) hipLaunchKernelGGL(KERN<256>, dim3((g).grid), dim3(256), 0, stream, args); \
     else hipLaunchKernelGGL(KERN<512>, dim3((g).grid), dim3(512), 0, stream, args);                       \
   } while (0)
@@ -471,6 +478,9 @@ static Geometry geometry(long B) {
       if (fi_ == 0) hipLaunchKernelGGL((KERN<64, 0>), dim3((g).grid), dim3(64), 0, stream, args);             \
       else if (F16_CT_HIFI && fi_ == 1) hipLaunchKernelGGL((KERN<64, F16_CT_HIFI ? 1 : -1>), dim3((g).grid), dim3(64), 0, stream, args); \
       else hipLaunchKernelGGL((KERN<64, -1>), dim3((g).grid), dim3(64), 0, stream, args);                      \
+    } else if ((g).block == 128) {                                                                             \
+      if (fi_ == 0) hipLaunchKernelGGL((KERN<128, 0>), dim3((g).grid), dim3(128), 0, stream, args);           \
+      else hipLaunchKernelGGL((KERN<128, -1>), dim3((g).grid), dim3(128), 0, stream, args);                    \
     } else if ((g).block == 256) {                                                                             \
       if (fi_ == 0) hipLaunchKernelGGL((KERN<256, 0>), dim3((g).grid), dim3(256), 0, stream, args);           \
       else hipLaunchKernelGGL((KERN<256, -1>), dim3((g).grid), dim3(256), 0, stream, args);                    \
@@ -497,7 +507,7 @@ extern "C" int f16_xdot_batch(f16_ctx *ctx, const double *x, const double *u, do
   DynArgs a{};
   a.tab = ctx->d_tab; a.lofi = ctx->d_lofi; a.x = x; a.u = u; a.out = xdot; a.status = status;
   a.B = B; a.ld = ld; a.xcg = xcg; a.fi = fi_flag; a.flags = flags;
-  Geometry g = geometry(B);
+  Geometry g = geometry(B, fi_flag);
   LAUNCH_BY_BLOCK_FI(k_xdot, g, (hipStream_t)stream, a);
   return hip_check(hipGetLastError(), "f16_xdot_batch launch");
 }
@@ -512,8 +522,9 @@ extern "C" int f16_nlplant_batch(f16_ctx *ctx, const double *xu, double *xdot, i
   if (B <= 256) {
     hipLaunchKernelGGL((k_nlplant<64, false>), dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
   } else {
-    Geometry g = geometry(B);
+    Geometry g = geometry(B, fi_flag);
     if (g.block == 64) hipLaunchKernelGGL((k_nlplant<64, true>), dim3(g.grid), dim3(64), 0, (hipStream_t)stream, a);
+    else if (g.block == 128) hipLaunchKernelGGL((k_nlplant<128, true>), dim3(g.grid), dim3(128), 0, (hipStream_t)stream, a);
     else if (g.block == 256) hipLaunchKernelGGL((k_nlplant<256, true>), dim3(g.grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((k_nlplant<512, true>), dim3(g.grid), dim3(512), 0, (hipStream_t)stream, a);
   }
@@ -531,13 +542,14 @@ extern "C" int f16_rollout(f16_ctx *ctx, double *x, const double *u, double *tra
   a.tab = ctx->d_tab; a.lofi = ctx->d_lofi; a.u = u; a.out = x; a.traj = traj; a.status = status;
   a.B = B; a.ld = ld; a.nsteps = nsteps; a.traj_every = traj ? traj_every : nsteps + 1;
   a.dt = dt; a.xcg = xcg; a.fi = fi_flag; a.flags = flags;
-  if (fi_flag == 1 && B <= 64L * 256 && !F16_NO_2W) {
+  static const long max4w = [] { const char *e = getenv("F16_ROLLOUT_4W_MAXB"); return e ? atol(e) : 64L * 256; }();
+  if (fi_flag == 1 && B <= max4w && !F16_NO_2W) {
     // latency regime: two wavefronts per 64 aircraft (lookups || trigonometry), one workgroup per CU
     if (F16_USE_2W) hipLaunchKernelGGL(k_rollout_2w, dim3((unsigned)((B + 63) / 64)), dim3(128), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_rollout_4w, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a);
     return hip_check(hipGetLastError(), "f16_rollout launch");
   }
-  Geometry g = geometry(B);
+  Geometry g = geometry(B, fi_flag);
   LAUNCH_BY_BLOCK_FI(k_rollout, g, (hipStream_t)stream, a);
   return hip_check(hipGetLastError(), "f16_rollout launch");
 }
@@ -551,7 +563,7 @@ extern "C" int f16_xdot_na_batch(f16_ctx *ctx, const double *x_full, const doubl
   DynArgs a{};
   a.tab = ctx->d_tab; a.lofi = ctx->d_lofi; a.x = x_full; a.u = x9; a.u3 = u3; a.out = xdot9; a.status = status;
   a.B = B; a.ld = ld; a.xcg = xcg; a.fi = fi_flag; a.flags = flags;
-  Geometry g = geometry(B);
+  Geometry g = geometry(B, fi_flag);
   LAUNCH_BY_BLOCK(k_xdot_na, g, (hipStream_t)stream, a);
   return hip_check(hipGetLastError(), "f16_xdot_na_batch launch");
 }
