@@ -12,8 +12,6 @@ struct f16_ctx {
   double *h_one;    // pinned mirror
   void *d_work;     // QP workspace (packed P and A'A per aircraft), grown on demand
   size_t work_bytes;
-  void *d_fast_desc;  // lane map of the register-resident MPC solver for horizon fast_desc_N
-  int fast_desc_N;
 };
 
 namespace f16 {

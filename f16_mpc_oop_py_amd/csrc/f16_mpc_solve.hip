@@ -1,25 +1,21 @@
 // f16_mpc_solve.hip -- register-resident OSQP-style ADMM for the condensed MPC QP (N <= 32), gfx950.
 //
 // Same algorithm, settings, termination / rho-update / infeasibility rules as the generic solver in
-// f16_control.hip (k_mpc) -- what changes is the mapping:
-//
-//   one 512-thread workgroup (8 wavefronts) per aircraft; the three linear operators of an ADMM iteration
+// f16_control.hip (k_mpc) -- what changes is the mapping: one 512-lane workgroup (8 wavefronts) per aircraft and
+// every operator of an ADMM iteration lives in registers for the whole solve:
 //     stage 1   t  = CCs' w_s      (3N x 6N, block upper-triangular Toeplitz)      utils.py:163 (A' part)
 //     stage 2   x~ = (P + sigma I + rho A'A)^-1 rhs        (3N x 3N dense)          OSQP linear system
 //     stage 3   z~ = CCs x~        (6N x 3N, block lower-triangular Toeplitz)       utils.py:163 (A part)
-//   are cut into row segments of 24 elements and each lane keeps ITS segment of each operator in registers
-//   (3 x 24 fp64 = 144 VGPRs) for the whole solve; per iteration a lane does 72 FMAs against operand vectors
-//   that live in LDS (16-byte reads of contiguous runs), partial sums of a row are combined through LDS
-//   (stages 1, 3) or by two DPP quad exchanges (stage 2).  The register file (512 KiB/CU) is the only on-chip
-//   memory that holds all three operators of an aircraft (24,840 doubles = 199 KB); LDS keeps the vectors.
-//   The KKT matrix is inverted in LDS (packed lower triangle) by the symmetric sweep operator, 512 lanes wide.
-//
-// Per-iteration cost: 24,840 useful MACs (of 36,864 issued with padding) + 5 workgroup barriers.
+//   * the KKT matrix is inverted ON THE fp64 MATRIX CORES (v_mfma_f64_16x16x4_f64, blocked symmetric sweep, four
+//     pivots per step) with the matrix resident in the MFMA accumulators, and stage 2 multiplies straight out of those
+//     accumulators (24 fp64 per lane on the six tile-row waves) -- the inverse never touches LDS or HBM;
+//   * stages 1 and 3 are the same block-Toeplitz operator used both ways: lane q of the 16-lane DPP row of horizon
+//     step i holds the two 6x3 blocks G_{2q}, G_{2q+1} (36 fp64), reads 12 / 6 contiguous operand doubles from LDS;
+//   * partial sums of a row are combined inside the DPP row by recursive halving (mirror / half-mirror / quad
+//     exchanges), so an iteration has three workgroup barriers and ~70 KB of LDS traffic (the first version: five
+//     barriers, 410 KB).
 #include <hip/hip_runtime.h>
 #include <math.h>
-
-#include <mutex>
-#include <vector>
 
 #include "f16_mpc.hpp"
 #include "f16_smallmat.hpp"
@@ -27,76 +23,7 @@
 namespace f16 {
 
 constexpr int FT = 512;                    // lanes per aircraft
-constexpr int FK = 24;                     // operator elements per lane and stage
 constexpr int FN = 3 * FAST_MAXN;          // 96
-constexpr int FMS = 6 * FAST_MAXN;         // 192
-constexpr int FNP = FN * (FN + 1) / 2;     // 4656
-constexpr int FSW = (FNP + FT - 1) / FT;   // packed elements per lane in the sweep (10)
-
-struct FastDesc {
-  short s1_row[FT], s1_i0[FT];   // stage 1: output e = 3j+c, first horizon step i0 of the lane's 4-step segment
-  short s3_row[FT], s3_j0[FT];   // stage 3: state row 6i+rr, first input block j0 of the lane's 8-block segment
-  short f1[FN], c1[FN];          // stage-1 partials of output e: first lane, count
-  short f3[FMS], c3[FMS];        // stage-3 partials of state row r
-};
-
-static int build_desc(int N, FastDesc &d) {
-  for (int t = 0; t < FT; ++t) { d.s1_row[t] = d.s3_row[t] = -1; d.s1_i0[t] = d.s3_j0[t] = 0; }
-  int lane = 0;
-  for (int j = 0; j < N; ++j)
-    for (int c = 0; c < 3; ++c) {
-      const int e = 3 * j + c, segs = (N - j + 3) / 4;
-      d.f1[e] = (short)lane; d.c1[e] = (short)segs;
-      for (int s = 0; s < segs; ++s, ++lane) {
-        if (lane >= FT) return -1;
-        d.s1_row[lane] = (short)e; d.s1_i0[lane] = (short)(j + 4 * s);
-      }
-    }
-  lane = 0;
-  for (int i = 0; i < N; ++i)
-    for (int rr = 0; rr < 6; ++rr) {
-      const int r = 6 * i + rr, segs = (i + 1 + 7) / 8;
-      d.f3[r] = (short)lane; d.c3[r] = (short)segs;
-      for (int s = 0; s < segs; ++s, ++lane) {
-        if (lane >= FT) return -1;
-        d.s3_row[lane] = (short)r; d.s3_j0[lane] = (short)(8 * s);
-      }
-    }
-  return 0;
-}
-
-// 24-element dot product: registers x contiguous LDS run (16-byte reads)
-__device__ __forceinline__ double dot24(const double (&W)[FK], const double *op) {
-  const double2 *p = reinterpret_cast<const double2 *>(op);
-  double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-  for (int k = 0; k < FK / 2; ++k) {
-    const double2 v = p[k];
-    a0 = fma(W[2 * k], v.x, a0);
-    a1 = fma(W[2 * k + 1], v.y, a1);
-  }
-  return a0 + a1;
-}
-
-// same, both factors in LDS (stage 3: the Toeplitz operator run is read instead of being held in registers)
-__device__ __forceinline__ double dot24_lds(const double *wop, const double *op) {
-  const double2 *w = reinterpret_cast<const double2 *>(wop);
-  const double2 *p = reinterpret_cast<const double2 *>(op);
-  double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-  for (int k = 0; k < FK / 2; ++k) {
-    const double2 u = w[k], v = p[k];
-    a0 = fma(u.x, v.x, a0);
-    a1 = fma(u.y, v.y, a1);
-  }
-  return a0 + a1;
-}
-
-__device__ __forceinline__ double quad_sum(double v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  return v;
-}
 
 // workgroup-wide reductions of NV values at once (red: [8][NV] doubles of LDS)
 template <int NV>
@@ -240,198 +167,517 @@ __device__ __attribute__((noinline)) bool sweep_inverse(double *Ms, double *cvec
   return ok;
 }
 
-__global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a, const FastDesc *__restrict__ D) {
-  __shared__ __attribute__((aligned(16))) double Mp[FN * (FN + 2)];   // square, lower triangle used (sweep_inverse)
-  __shared__ __attribute__((aligned(16))) double G[27 * FAST_MAXN];
-  __shared__ __attribute__((aligned(16))) double ws[FMS + FK], wc[FN], wr[FN + 4];
-  __shared__ __attribute__((aligned(16))) double ys[FMS + FK], yc[FN], yr[FN + 4];
-  __shared__ __attribute__((aligned(16))) double rhs[FN], xt[FN + FK], xb[FN + FK], pxv[FN];
-  __shared__ double p1[FT + 8], p3[FT + 8], cvec[2 * (FN + 8)], red[8 * 8];
-  // stage-3 operator: per kept state row type rr the sequence R_rr[3j'+c] = G_{N-1-j'}[S_rr][c] (0 for j' >= N); row (i,rr)
-  // segment j0 is the contiguous run starting at 3(j0+N-1-i).  Second copy shifted by one double so that every run
-  // start is 16-byte aligned in one of the two.
-  constexpr int RL = FN + FK + 4;
-  __shared__ __attribute__((aligned(16))) double Rq[2][6][RL];
+// ---------------------------------------------------------------------------------------------------------------
+// Blocked form of the same sweep on the fp64 matrix cores (v_mfma_f64_16x16x4_f64): the matrix lives in MFMA
+// accumulators -- wave w owns tile row w (rows 16w..16w+15, all six 16x16 tiles: 24 fp64 per lane) -- and a block step
+// sweeps FOUR pivots at once:
+//     M_rest <- M_rest - (C D^-1) C'      one 16x16x4 MFMA per tile        (C = the 4 pivot columns, D = 4x4 pivot block)
+//     M[:,K] <- C D^-1,   M[K,K] <- -D^-1                                   (lane-level fix-ups after the MFMAs)
+// Per block step: the owner of the pivot rows publishes them to LDS (the panel, by symmetry = the pivot columns), one
+// barrier, every lane inverts D in registers (2x2 Schur form), builds its A/B operands from the panel, six MFMAs.
+// 4*ceil(n/16) block steps instead of n pivots; padding rows/cols (n..16*nt) carry an identity block.
+// Register layout of v_mfma_f64_16x16x4_f64 (probed on the hardware, pinned by tests/test_gpu_control.py::
+// test_mfma_inverse): accumulator register q of lane l holds D[4q + l/16][l%16]; A operand: lane l -> A[l%16][l/16];
+// B operand: lane l -> B[l/16][l%16].  The four pivot rows of a block step are therefore ONE accumulator register
+// (q = p%4) across the whole wave.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+constexpr int NT = FN / 16;   // 6 tile rows / columns
 
-  const int N = a.N, n = 3 * N, np = n * (n + 1) / 2, ms = 6 * N, m = 12 * N;
-  const int tid = threadIdx.x;
+// 1/x to <= 1 ulp without the division sequence (v_rcp_f64 + two Newton steps); x is a positive, normal pivot minor
+__device__ __forceinline__ double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+}
+
+// inverse of a 4x4 SPD block given by its lower triangle; false if a leading minor is not positive
+__device__ __forceinline__ bool inv4_spd(const double (&d)[4][4], double (&o)[4][4]) {
+  const double a = d[0][0], b = d[1][0], c = d[1][1];
+  const double detA = a * c - b * b;
+  const double ia = rcp_nr(detA);
+  const double A00 = c * ia, A10 = -b * ia, A11 = a * ia;                  // A^-1
+  const double B00 = d[2][0], B01 = d[2][1], B10 = d[3][0], B11 = d[3][1];  // rows 2,3 x cols 0,1
+  const double T00 = B00 * A00 + B01 * A10, T01 = B00 * A10 + B01 * A11;    // T = B A^-1
+  const double T10 = B10 * A00 + B11 * A10, T11 = B10 * A10 + B11 * A11;
+  const double S00 = d[2][2] - (T00 * B00 + T01 * B01);                     // S = E - T B'
+  const double S10 = d[3][2] - (T10 * B00 + T11 * B01);
+  const double S11 = d[3][3] - (T10 * B10 + T11 * B11);
+  const double detS = S00 * S11 - S10 * S10;
+  const double is = rcp_nr(detS);
+  const double I00 = S11 * is, I10 = -S10 * is, I11 = S00 * is;            // S^-1
+  const double L00 = -(I00 * T00 + I10 * T10), L01 = -(I00 * T01 + I10 * T11);   // -S^-1 T
+  const double L10 = -(I10 * T00 + I11 * T10), L11 = -(I10 * T01 + I11 * T11);
+  o[2][2] = I00; o[3][2] = o[2][3] = I10; o[3][3] = I11;
+  o[2][0] = o[0][2] = L00; o[2][1] = o[1][2] = L01; o[3][0] = o[0][3] = L10; o[3][1] = o[1][3] = L11;
+  o[0][0] = A00 - (T00 * L00 + T10 * L10);                                    // A^-1 + T' S^-1 T
+  o[1][0] = o[0][1] = A10 - (T01 * L00 + T11 * L10);
+  o[1][1] = A11 - (T01 * L01 + T11 * L11);
+  return a > 0.0 && detA > 0.0 && S00 > 0.0 && detS > 0.0;
+}
+
+// lane-dependent pick of one of four values.  Scalars BY VALUE on purpose: with an array reference the optimiser turns
+// the selects into a dynamically indexed load before inlining, and the array then lives in scratch memory.
+__device__ __forceinline__ double sel4(double v0, double v1, double v2, double v3, int k) {
+  const double lo = (k & 1) ? v1 : v0, hi = (k & 1) ? v3 : v2;
+  return (k & 2) ? hi : lo;
+}
+
+// One block step of the sweep: pivots 16 Kt + 4 KQ .. +3 (accumulator register KQ of tile row Kt).  cb: this step's
+// panel C[col][0..3] = M[pivot row][col]; cbn: where the NEXT step's panel is published.
+template <int NTT, int KQ>
+__device__ __forceinline__ void inverse_step(d4_t (&acc)[NT], const double *cb, double *cbn, int Kt, int w, int lc, int lq,
+                                             bool &ok) {
+  const bool pl = (lc >> 2) == KQ;                       // this lane's column (within a tile) is a pivot column
+  // ---- D and its inverse (every lane; broadcast reads)
+  double D[4][4], Di[4][4];
+  {
+    const double2 *src = reinterpret_cast<const double2 *>(cb + (16 * Kt + 4 * KQ) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double2 u = src[2 * i], v = src[2 * i + 1];
+      D[i][0] = u.x; D[i][1] = u.y; D[i][2] = v.x; D[i][3] = v.y;
+    }
+  }
+  // operands that do not depend on D^-1 first (their LDS latency overlaps the 4x4 inverse)
+  double2 ca0, ca1;
+  {
+    const double2 *src = reinterpret_cast<const double2 *>(cb + (16 * w + lc) * 4);
+    ca0 = src[0]; ca1 = src[1];
+  }
+  double b_op[NTT];
+#pragma unroll
+  for (int J = 0; J < NTT; ++J) {
+    b_op[J] = cb[(16 * J + lc) * 4 + lq];
+    if (J == Kt && pl) b_op[J] = 0.0;
+  }
+  ok = inv4_spd(D, Di) && ok;
+  // ---- A operand: -(C D^-1)[16w + lc][lq], zero on pivot rows
+  double a_op;
+  {
+    double cdr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cdr[k] = ca0.x * Di[0][k] + ca0.y * Di[1][k] + ca1.x * Di[2][k] + ca1.y * Di[3][k];
+    a_op = -sel4(cdr[0], cdr[1], cdr[2], cdr[3], lq);
+    if (w == Kt && pl) a_op = 0.0;
+  }
+#pragma unroll
+  for (int J = 0; J < NTT; ++J) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op[J], acc[J], 0, 0, 0);
+  // ---- pivot columns of this tile row: M[i][pivot kk] = (C D^-1)[i][kk] for rows outside the pivot block
+  {
+    double dC[4], cd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dC[k] = sel4(Di[k][0], Di[k][1], Di[k][2], Di[k][3], lc & 3);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double2 *src = reinterpret_cast<const double2 *>(cb + (16 * w + 4 * q + lq) * 4);
+      const double2 u = src[0], v = src[1];
+      cd[q] = u.x * dC[0] + u.y * dC[1] + v.x * dC[2] + v.y * dC[3];
+    }
+#pragma unroll
+    for (int J = 0; J < NTT; ++J)
+      if (J == Kt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q != KQ) acc[J][q] = pl ? cd[q] : acc[J][q];
+        if (w != Kt) acc[J][KQ] = pl ? cd[KQ] : acc[J][KQ];
+      }
+  }
+  // ---- pivot rows (owner wave, register KQ): M[pivot lq][j] = (C D^-1)[j][lq], -D^-1 on the pivot block itself
+  if (w == Kt) {
+    double dA[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dA[k] = sel4(Di[k][0], Di[k][1], Di[k][2], Di[k][3], lq);
+    const double mdi = -sel4(dA[0], dA[1], dA[2], dA[3], lc & 3);
+#pragma unroll
+    for (int J = 0; J < NTT; ++J) {
+      const double2 *src = reinterpret_cast<const double2 *>(cb + (16 * J + lc) * 4);
+      const double2 u = src[0], v = src[1];
+      const double cdv = u.x * dA[0] + u.y * dA[1] + v.x * dA[2] + v.y * dA[3];
+      acc[J][KQ] = (J == Kt && pl) ? mdi : cdv;
+    }
+  }
+  // ---- publish the next pivot rows
+  if (KQ < 3) {
+    if (w == Kt) {
+#pragma unroll
+      for (int J = 0; J < NTT; ++J) cbn[(16 * J + lc) * 4 + lq] = acc[J][(KQ + 1) & 3];
+    }
+  } else if (w == Kt + 1) {
+#pragma unroll
+    for (int J = 0; J < NTT; ++J) cbn[(16 * J + lc) * 4 + lq] = acc[J][0];
+  }
+}
+
+// In-register blocked sweep over NTT x NTT tiles.  On return acc holds MINUS the inverse of P + sigma I + r A'A
+// (identity block on the padding rows n..16 NTT); tile (w,J), register q, lane l <-> element (16w + 4q + l/16, 16J + l%16).
+// Cs: LDS scratch [2][FN*4] doubles (double-buffered panel).  Return value is uniform over the workgroup.
+// Out of line on purpose: the block step wants ~200 registers of its own; as a call, the caller's live state is parked
+// once per inverse instead of being spilled and reloaded inside every block step.
+#ifndef F16_INV_ATTR
+#define F16_INV_ATTR __forceinline__
+#endif
+template <int NTT>
+__device__ F16_INV_ATTR bool mfma_inverse(d4_t *acc_out, double *Cs, const double *Pg, const double *Ag, double r,
+                                                       double sigma, int n) {
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  int lc = l & 15, lq = l >> 4;
+  // opaque to the optimiser: otherwise the tile index arithmetic below (loop-invariant for the caller's factorisation
+  // loop) is hoisted to the top of the kernel, does not fit in registers there and comes back through scratch memory
+  asm volatile("" : "+v"(lc), "+v"(lq));
+  bool ok = true;
+  d4_t acc[NT];
+  // tiles straight from the packed lower triangles in the workspace (L2-resident: the build kernel just wrote them).
+  // One tile at a time (scheduling fence): hoisting all 2 x 24 loads to the top costs more registers than there are.
+#pragma unroll
+  for (int J = 0; J < NTT; ++J) {
+    double pv[4], av[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 16 * w + 4 * q + lq, j = 16 * J + lc;
+      const bool in = i < n && j < n;
+      const int e = in ? (i >= j ? tri(i, j) : tri(j, i)) : 0;
+      pv[q] = Pg[e]; av[q] = Ag[e];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 16 * w + 4 * q + lq, j = 16 * J + lc;
+      acc[J][q] = (i < n && j < n) ? pv[q] + r * av[q] + (i == j ? sigma : 0.0) : (i == j ? 1.0 : 0.0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  double *c0 = Cs, *c1 = Cs + FN * 4;
+  __syncthreads();                        // previous users of Cs are done
+  if (w == 0) {
+#pragma unroll
+    for (int J = 0; J < NTT; ++J) c0[(16 * J + lc) * 4 + lq] = acc[J][0];
+  }
+  for (int Kt = 0; Kt < NTT; ++Kt) {
+    __syncthreads();
+    if (w < NTT) inverse_step<NTT, 0>(acc, c0, c1, Kt, w, lc, lq, ok);
+    __syncthreads();
+    if (w < NTT) inverse_step<NTT, 1>(acc, c1, c0, Kt, w, lc, lq, ok);
+    __syncthreads();
+    if (w < NTT) inverse_step<NTT, 2>(acc, c0, c1, Kt, w, lc, lq, ok);
+    __syncthreads();
+    if (w < NTT) inverse_step<NTT, 3>(acc, c1, c0, Kt, w, lc, lq, ok);
+  }
+#pragma unroll
+  for (int J = 0; J < NTT; ++J) acc_out[J] = acc[J];
+  return __syncthreads_and(ok) != 0;      // uniform over the workgroup (only the tile-row waves looked at pivots)
+}
+
+// diagnostic / test entry: inverse of B packed SPD matrices through mfma_inverse (or the scalar sweep_inverse)
+__global__ __launch_bounds__(FT) void k_dbg_inverse(const double *pk, double *out, int n, long B, int use_mfma) {
+  __shared__ __attribute__((aligned(16))) double Mp[FN * SLD];
+  __shared__ __attribute__((aligned(16))) double cv[2 * FN * 4];
+  const int np = n * (n + 1) / 2, nt = (n + 15) >> 4;
+  const int w = threadIdx.x >> 6, lc = threadIdx.x & 15, lq = (threadIdx.x & 63) >> 4;
+  for (long b = blockIdx.x; b < B; b += gridDim.x) {
+    const double *Pg = pk + (size_t)b * np;
+    double *o = out + (size_t)b * n * n;
+    if (use_mfma) {
+      d4_t acc[NT];
+      const bool ok = mfma_inverse<NT>(acc, cv, Pg, Pg, 0.0, 0.0, n);
+#pragma unroll
+      for (int J = 0; J < NT; ++J)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = 16 * w + 4 * q + lq, j = 16 * J + lc;
+          if (w < nt && J < nt && i < n && j < n) o[i * n + j] = ok ? -acc[J][q] : NAN;
+        }
+    } else {
+      const bool ok = sweep_inverse(Mp, cv, Pg, Pg, 0.0, 0.0, n, np);
+      for (int e = threadIdx.x; e < n * n; e += FT) {
+        const int i = e / n, j = e - i * n;
+        o[e] = ok ? -(i >= j ? Mp[i * SLD + j] : Mp[j * SLD + i]) : NAN;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Cross-lane sums over the 16 lanes of a DPP row by recursive halving: at each of the first steps a lane keeps half of
+// its values and hands the other half to its mirror partner, so V values cost about V + log steps instead of 4 V.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HMIRROR = 0x141, DPP_MIRROR = 0x140;
+
+// h,g,e = bits 3,2,1 of the lane's position in its row.  Totals land in: lanes 0-3 v0, 4-7 v1, 8-11 v2 (12-15: 0)
+__device__ __forceinline__ double reduce3(double v0, double v1, double v2, bool h, bool g) {
+  const double s0 = h ? v0 : v2, s1 = h ? v1 : 0.0;
+  double k0 = h ? v2 : v0, k1 = h ? 0.0 : v1;
+  k0 += dpp_f64<DPP_MIRROR>(s0);
+  k1 += dpp_f64<DPP_MIRROR>(s1);
+  const double s = g ? k0 : k1;
+  double k = g ? k1 : k0;
+  k += dpp_f64<DPP_HMIRROR>(s);
+  k += dpp_f64<DPP_XOR2>(k);
+  k += dpp_f64<DPP_XOR1>(k);
+  return k;
+}
+// quad k of the row (lanes 4k..4k+3) ends up with the total of v[k]
+__device__ __forceinline__ double reduce4(d4_t v, bool h, bool g) {
+  const double s0 = h ? v[0] : v[2], s1 = h ? v[1] : v[3];
+  double k0 = h ? v[2] : v[0], k1 = h ? v[3] : v[1];
+  k0 += dpp_f64<DPP_MIRROR>(s0);
+  k1 += dpp_f64<DPP_MIRROR>(s1);
+  const double s = g ? k0 : k1;
+  double k = g ? k1 : k0;
+  k += dpp_f64<DPP_HMIRROR>(s);
+  k += dpp_f64<DPP_XOR2>(k);
+  k += dpp_f64<DPP_XOR1>(k);
+  return k;
+}
+// totals land in: lanes 0,1 v0 | 2,3 v1 | 4-7 v2 | 8,9 v3 | 10,11 v4 | 12-15 v5
+__device__ __forceinline__ double reduce6(double v0, double v1, double v2, double v3, double v4, double v5, bool h, bool g,
+                                          bool e) {
+  const double k0 = (h ? v3 : v0) + dpp_f64<DPP_MIRROR>(h ? v0 : v3);
+  const double k1 = (h ? v4 : v1) + dpp_f64<DPP_MIRROR>(h ? v1 : v4);
+  const double k2 = (h ? v5 : v2) + dpp_f64<DPP_MIRROR>(h ? v2 : v5);
+  const double t0 = g ? k0 : k2, t1 = g ? k1 : 0.0;
+  double n0 = g ? k2 : k0, n1 = g ? 0.0 : k1;
+  n0 += dpp_f64<DPP_HMIRROR>(t0);
+  n1 += dpp_f64<DPP_HMIRROR>(t1);
+  const bool lo2 = !g && !e, hi2 = !g && e;
+  const double u = lo2 ? n1 : n0;
+  double r = hi2 ? n1 : n0;
+  r += dpp_f64<DPP_XOR2>(u);
+  r += dpp_f64<DPP_XOR1>(r);
+  return r;
+}
+
+// ---- the two Toeplitz operators of an iteration share ONE register-resident pair of 6x3 blocks per lane:
+// lane q of DPP row `blk` holds Gs_d = G_d[S][:] for d = 2q, 2q+1 (zero for d >= N), S = kept state rows.
+//   stage 1 (CCs' w)_j   = sum_d Gs_d' w_{j+d}     -> row blk = j, reads the 12 contiguous doubles w_{j+2q}, w_{j+2q+1}
+//   stage 3 (CCs x~)_i   = sum_d Gs_d  x~_{i-d}    -> row blk = i, reads the 6 contiguous doubles x~_{i-2q-1}, x~_{i-2q}
+// Out-of-range blocks read zeros (the vectors are zero-padded in LDS), so there is no per-lane masking.
+__device__ __forceinline__ void stage1_partial(const double (&Gd)[2][6][3], const double *wp, double (&o)[3]) {
+  const double2 *p = reinterpret_cast<const double2 *>(wp);
+  double wv[12];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { const double2 t = p[k]; wv[2 * k] = t.x; wv[2 * k + 1] = t.y; }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) { s0 = fma(Gd[0][rr][c], wv[rr], s0); s1 = fma(Gd[1][rr][c], wv[6 + rr], s1); }
+    o[c] = s0 + s1;
+  }
+}
+__device__ __forceinline__ void stage3_partial(const double (&Gd)[2][6][3], const double *xp, double (&o)[6]) {
+  double xv[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) xv[k] = xp[k];          // x~_{i-2q-1} (3), x~_{i-2q} (3)
+#pragma unroll
+  for (int rr = 0; rr < 6; ++rr) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { s0 = fma(Gd[0][rr][c], xv[3 + c], s0); s1 = fma(Gd[1][rr][c], xv[c], s1); }
+    o[rr] = s0 + s1;
+  }
+}
+
+constexpr int WSP = 6 * 64;            // zero-padded state-row vectors (stage 1 reads up to block 31 + 31 + 1)
+constexpr int XOFF = 3 * 32;           // zeros in front of x~ (stage 3 reads down to block -31)
+constexpr int XTP = XOFF + FN + 8;
+
+// One 512-lane workgroup per aircraft, three barriers per ADMM iteration:
+//   A  stage 1 partials + row reduce -> rhs = sigma x - q + A'(rho z - y)                      | barrier
+//   B  stage 2: x~ = Minv rhs straight from the MFMA accumulators of the inverse (tile-row waves) | barrier
+//   C  stage 3 partials + row reduce -> z~ ; relaxation, projection, dual update, w = rho z - y  | barrier
+// Lane roles inside DPP row blk (= horizon step): lanes 0,2,4,8,10,12 own the six kept state rows of step blk (that is
+// where reduce6 leaves their z~), lanes 1,3,5 the command rows, 9,11,13 the rate rows, lanes 0,4,8 also own x[3 blk + c].
+template <int NTT>
+__global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
+  __shared__ __attribute__((aligned(16))) double wsP[WSP], ysP[WSP], xtP[XTP], Cs[2 * FN * 4];
+  __shared__ double rhs[FN], wc[FN], wr[FN + 4], yc[FN], yr[FN + 4], red[8 * 8];
+
+  const int N = a.N, n = 3 * N;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lc = l & 15, lq = l >> 4, blk = tid >> 4, q = lc;
+  const bool h = lc & 8, g = lc & 4, e = lc & 2;
+  const bool inb = blk < N;
   // ---- lane roles (fixed for the whole launch)
-  const int r1 = D->s1_row[tid], i01 = D->s1_i0[tid];
-  const int r3 = D->s3_row[tid], j03 = D->s3_j0[tid];
-  const int r2 = tid >> 2, h2 = tid & 3;                      // stage 2: four lanes per row, 24 columns each
-  const bool xown = tid < n, rown = tid < m;
-  const int f1 = xown ? D->f1[tid] : 0, c1 = xown ? D->c1[tid] : 0;
-  const bool srow = tid < ms;
-  const int f3 = srow ? D->f3[tid] : 0, c3 = srow ? D->c3[tid] : 0;
-  // zero the pads once (never written again)
-  for (int e = tid; e < FMS + FK; e += FT) { ws[e] = 0.0; ys[e] = 0.0; }
-  for (int e = tid; e < FN + FK; e += FT) { xt[e] = 0.0; xb[e] = 0.0; }
-  for (int e = tid; e < FN + 4; e += FT) { wr[e] = 0.0; yr[e] = 0.0; }
-  for (int e = tid; e < FN; e += FT) { rhs[e] = 0.0; wc[e] = 0.0; yc[e] = 0.0; pxv[e] = 0.0; }
+  int kind = 0, sub = 0;                                       // 1 state row rr=sub, 2 command row c=sub, 3 rate row c=sub
+  if (inb) {
+    if (lc == 0 || lc == 2 || lc == 4) { kind = 1; sub = lc >> 1; }
+    else if (lc == 8 || lc == 10 || lc == 12) { kind = 1; sub = 3 + ((lc - 8) >> 1); }
+    else if (lc == 1 || lc == 3 || lc == 5) { kind = 2; sub = (lc - 1) >> 1; }
+    else if (lc == 9 || lc == 11 || lc == 13) { kind = 3; sub = (lc - 9) >> 1; }
+  }
+  const int k3 = 3 * blk + sub;                                // index of a command / rate row
+  const bool xown = inb && (lc == 0 || lc == 4 || lc == 8);
+  const int xe = 3 * blk + (lc >> 2);
+  double *const wdst = kind == 1 ? wsP + 6 * blk + sub : (kind == 2 ? wc + k3 : wr + k3);
+  double *const ydst = kind == 1 ? ysP + 6 * blk + sub : (kind == 2 ? yc + k3 : yr + k3);
+  // zero everything once: the pads are never written again
+  for (int i = tid; i < WSP; i += FT) { wsP[i] = 0.0; ysP[i] = 0.0; }
+  for (int i = tid; i < XTP; i += FT) xtP[i] = 0.0;
+  for (int i = tid; i < FN + 4; i += FT) { wr[i] = 0.0; yr[i] = 0.0; }
+  for (int i = tid; i < FN; i += FT) { rhs[i] = 0.0; wc[i] = 0.0; yc[i] = 0.0; }
   __syncthreads();
 
   const double sigma = a.s.sigma, alpha = a.s.alpha;
 
-  for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
+  {
+    const long b = blockIdx.x;                                 // one aircraft per workgroup (grid = B)
     const double *ex = a.ext + (size_t)b * mpc_ext_doubles(N);
-    const double *Pg = a.Ppk + (size_t)b * np, *Ag = a.Apk + (size_t)b * np;
-    const double *pred = ex + n + 27 * N;
-    for (int e = tid; e < 27 * N; e += FT) G[e] = ex[n + e];
-    const double qe = xown ? ex[tid] : 0.0;
+    const double *Pg = a.Ppk + (size_t)b * (n * (n + 1) / 2), *Ag = a.Apk + (size_t)b * (n * (n + 1) / 2);
+    const double *Gg = ex + n, *pred = ex + n + 27 * N;
+#ifdef F16_EXP_STAMPM
+    const unsigned long long tP0 = __builtin_amdgcn_s_memtime();
+#endif
+    const double qe = xown ? ex[xe] : 0.0;
     // ---- bounds of this lane's constraint row (utils.py:129-152; rows with two infinite bounds are not kept)
     double lo = 0.0, hi = 0.0, z = 0.0, y = 0.0, dy = 0.0, xs = 0.0;
-    if (srow) {
-      const int i = tid / 6, rr = tid - 6 * i;
-      const double pm = pred[i * 9 + SROW[rr]];
-      lo = SLB[rr] - pm; hi = SUB[rr] - pm;
-    } else if (tid < ms + n) {
-      const int c = (tid - ms) % 3;
-      lo = ULB[c]; hi = UUB[c];
-    } else if (rown) {
-      const int k = tid - ms - n, c = k % 3;
-      if (k < 3) {
-        const double act = a.x[(13 + c) * a.ld + b];
-        lo = act + RLB[c] * a.dt; hi = act + RUB[c] * a.dt;
-      } else { lo = RLB[c]; hi = RUB[c]; }               // reference quirk: not scaled by dt (utils.py:151-152)
+    if (kind == 1) {
+      const double pm = pred[blk * 9 + SROW[sub]];
+      lo = SLB[sub] - pm; hi = SUB[sub] - pm;
+    } else if (kind == 2) {
+      lo = ULB[sub]; hi = UUB[sub];
+    } else if (kind == 3) {
+      if (blk == 0) {
+        const double act = a.x[(13 + sub) * a.ld + b];
+        lo = act + RLB[sub] * a.dt; hi = act + RUB[sub] * a.dt;
+      } else { lo = RLB[sub]; hi = RUB[sub]; }               // reference quirk: not scaled by dt (utils.py:151-152)
     }
-    __syncthreads();
-    // ---- operator segments into registers
-    for (int e = tid; e < 6 * RL; e += FT) {
-      const int rr = e / RL, t = e - rr * RL;
-      constexpr int SRc[6] = {2, 3, 4, 5, 6, 8};
-      const int srr = rr == 0 ? SRc[0] : rr == 1 ? SRc[1] : rr == 2 ? SRc[2] : rr == 3 ? SRc[3] : rr == 4 ? SRc[4] : SRc[5];
-      auto val = [&](int u) { const int jp = u / 3, c = u - 3 * jp; return jp < N ? G[(N - 1 - jp) * 27 + srr * 3 + c] : 0.0; };
-      Rq[0][rr][t] = val(t);
-      Rq[1][rr][t] = val(t + 1);
-    }
-    const double *w3run;                                            // this lane's 24-element run of the stage-3 operator
-    {
-      const int i3 = r3 >= 0 ? r3 / 6 : 0, rr3 = r3 >= 0 ? r3 - 6 * i3 : 0;
-      const int st = 3 * (j03 + N - 1 - i3);
-      w3run = (st & 1) ? &Rq[1][rr3][st - 1] : &Rq[0][rr3][st];
-    }
-    double W1[FK], W2[FK];
-    auto load_w2 = [&]() {                                           // -(swept) = inverse; this lane's 24 columns of row r2
-#pragma unroll
-      for (int k = 0; k < FK; ++k) {
-        const int col = FK * h2 + k;
-        W2[k] = (r2 < n && col < n) ? -(r2 >= col ? Mp[r2 * SLD + col] : Mp[col * SLD + r2]) : 0.0;
-      }
-      __syncthreads();
-    };
-    auto load_w1 = [&]() {
-      // CCs'[(j,c),(i,rr)] = G_{i-j}[S_rr][c]; S = {2,3,4,5,6,8}: compile-time offsets off one base
-      constexpr int SR[6] = {2, 3, 4, 5, 6, 8};
-      const int j1 = r1 >= 0 ? r1 / 3 : 0, c1e = r1 >= 0 ? r1 - 3 * j1 : 0;
-      const double *g1 = G + (i01 - j1) * 27 + c1e;                 // + (k/6)*27 + SR[k%6]*3
-      const int lim1 = r1 >= 0 ? N - i01 : 0;                       // valid while k/6 < lim1
-#pragma unroll
-      for (int k = 0; k < FK; ++k) W1[k] = (k / 6 < lim1) ? g1[(k / 6) * 27 + SR[k % 6] * 3] : 0.0;
-    };
+    if (kind) *wdst = 0.0;                                     // w = rho z - y of the start point
     double rho = a.s.rho;
     if (!(rho > 0.0)) {   // automatic: balance the two terms of P + rho A'A (our QP is not Ruiz-scaled as OSQP's would be)
-      double tr[2] = {xown ? Pg[tri(tid, tid)] : 0.0, xown ? Ag[tri(tid, tid)] : 0.0};
+      double tr[2] = {xown ? Pg[tri(xe, xe)] : 0.0, xown ? Ag[tri(xe, xe)] : 0.0};
       const bool sums[2] = {true, true};
       block_reduce<2>(tr, sums, red);
       rho = fmin(fmax(sqrt(tr[0] / tr[1]), 1e-6), 1e6);
     }
-    bool ok = true;
-    ok = sweep_inverse(Mp, cvec, Pg, Ag, rho, sigma, n, np) && ok;
-    load_w2();
-    load_w1();
-
     int it = 0;
     double rp = INFINITY, rd = INFINITY;
-    bool converged = false, infeasible = false;
-    bool done = !ok || a.s.max_iter <= 0;
-    // w = rho z - y of the start point (all zero)
-    if (rown) { double *wdst = srow ? ws + tid : (tid < ms + n ? wc + (tid - ms) : wr + (tid - ms - n)); *wdst = 0.0; }
-    __syncthreads();
+    bool converged = false, infeasible = false, ok = true;
+    bool done = a.s.max_iter < 0;                              // (max_iter == 0: factor only, used for timing)
 #ifdef F16_EXP_STAMPM
-    unsigned long long tS[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long tS[6] = {0, 0, 0, 0, 0, 0}, tP1 = 0, tP2 = 0, t0 = 0;
 #define MSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t1 = __builtin_amdgcn_s_memtime(); tS[i] += t1 - t0; t0 = t1; }
 #else
 #define MSTAMP(i)
 #endif
+    // outer loop: one trip per KKT factorisation (rho changes at most every rho_every iterations).  The inverse is a
+    // real call; it sits OUTSIDE the iteration loop so that nothing big is live across it.
     while (!done) {
+      d4_t acc[NT];                                            // MINUS (P + sigma I + rho A'A)^-1, tile row w
+      {
+#ifdef F16_EXP_STAMPM
+        __builtin_amdgcn_s_waitcnt(0);
+        tP1 = __builtin_amdgcn_s_memtime();
+#endif
+        d4_t tmp[NT];                                          // the call hands the tiles over in memory: copy them into
+        ok = mfma_inverse<NTT>(tmp, Cs, Pg, Ag, rho, sigma, n) && ok;   // an array whose address never escapes
+#pragma unroll
+        for (int J = 0; J < NTT; ++J) acc[J] = tmp[J];
+#ifdef F16_EXP_STAMPM
+        tP2 = __builtin_amdgcn_s_memtime();
+        t0 = tP2;
+#endif
+      }
+      // ---- this lane's two Toeplitz blocks (utils.py:171-197: CC[i,j] = A^(i-j) B, rows S kept); loaded after the call
+      double Gd[2][6][3];
+      {
+        constexpr int SR[6] = {2, 3, 4, 5, 6, 8};
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          const int d = 2 * q + bb;
+#pragma unroll
+          for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Gd[bb][rr][c] = d < N ? Gg[d * 27 + SR[rr] * 3 + c] : 0.0;
+        }
+      }
+      const double rinv = 1.0 / rho;
+      bool refactor = false;
+      if (!ok || a.s.max_iter <= 0) done = true;
+      __syncthreads();
+    while (!done && !refactor) {
       ++it;
-      // stage 1 partials: (CCs' w_s) row segments
-      p1[tid] = r1 >= 0 ? dot24(W1, ws + 6 * i01) : 0.0;
+      // ---- A: rhs = sigma x - q + A'(rho z - y)
+      {
+        double o1[3];
+        stage1_partial(Gd, wsP + 6 * (blk + 2 * q), o1);
+        const double t = reduce3(o1[0], o1[1], o1[2], h, g);
+        if (xown) rhs[xe] = sigma * xs - qe + (t + wc[xe] + (wr[xe] - wr[xe + 3]));
+      }
       MSTAMP(0)
       __syncthreads();
       MSTAMP(1)
-      if (xown) {
-        double t = 0.0;
+      // ---- B: x~ = Minv rhs from the accumulators (element (16w + 4qq + lq, 16J + lc) in acc[J][qq])
+      if (w < NTT) {
+        d4_t part = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < 8; ++s) t += (s < c1) ? p1[f1 + s] : 0.0;
-        rhs[tid] = sigma * xs - qe + (t + wc[tid] + (wr[tid] - (tid + 3 < n ? wr[tid + 3] : 0.0)));
+        for (int J = 0; J < NTT; ++J) {
+          const double rj = rhs[16 * J + lc];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) part[qq] = fma(acc[J][qq], rj, part[qq]);
+        }
+        const double v = reduce4(part, h, g);
+        const int row = 16 * w + (lc & 12) + lq;
+        if ((lc & 3) == 0 && row < n) xtP[XOFF + row] = -v;
       }
       MSTAMP(2)
       __syncthreads();
       MSTAMP(3)
-      // stage 2: x~ = Minv rhs, four lanes per row
+      // ---- C: z~ = A x~, relaxation, projection, dual update
       {
-        const double part = quad_sum(dot24(W2, rhs + FK * h2));
-        if (h2 == 0 && r2 < n) xt[r2] = part;
-      }
-      MSTAMP(4)
-      __syncthreads();
-      MSTAMP(5)
-      // stage 3 partials: (CCs x~) row segments; x relaxation
-      p3[tid] = r3 >= 0 ? dot24_lds(w3run, xt + 3 * j03) : 0.0;
-      if (xown) xs = alpha * xt[tid] + (1 - alpha) * xs;
-      MSTAMP(6)
-      __syncthreads();
-      MSTAMP(7)
-      if (rown) {
-        double zt;
-        if (srow) {
-          zt = 0.0;
-#pragma unroll
-          for (int s = 0; s < 4; ++s) zt += (s < c3) ? p3[f3 + s] : 0.0;
+        double o3[6];
+        stage3_partial(Gd, xtP + XOFF + 3 * (blk - 2 * q - 1), o3);
+        const double zs = reduce6(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], h, g, e);
+        if (xown) xs = alpha * xtP[XOFF + xe] + (1 - alpha) * xs;
+        if (kind) {
+          const double zt = kind == 1 ? zs : (kind == 2 ? xtP[XOFF + k3] : xtP[XOFF + k3] - xtP[XOFF + k3 - 3]);
+          const double zr = alpha * zt + (1 - alpha) * z;
+          const double zn = fmin(fmax(fma(y, rinv, zr), lo), hi);
+          dy = rho * (zr - zn);
+          y = y + dy;
+          z = zn;
         }
-        else if (tid < ms + n) zt = xt[tid - ms];
-        else { const int k = tid - ms - n; zt = xt[k] - (k >= 3 ? xt[k - 3] : 0.0); }
-        const double zr = alpha * zt + (1 - alpha) * z;
-        const double zn = fmin(fmax(zr + y / rho, lo), hi);
-        dy = rho * (zr - zn);
-        y = y + dy;
-        z = zn;
       }
       const bool check = (it % a.s.check_every == 0) || it >= a.s.max_iter;
       if (check) {
         // ---- residuals (OSQP termination test): A x, P x, A' y
-        if (rown) { double *d = srow ? ys + tid : (tid < ms + n ? yc + (tid - ms) : yr + (tid - ms - n)); *d = y; }
-        if (xown) xb[tid] = xs;
+        if (kind) *ydst = y;
+        __syncthreads();                                        // all reads of x~ are done: the buffer now carries x
+        if (xown) xtP[XOFF + xe] = xs;
         __syncthreads();
-        p3[tid] = r3 >= 0 ? dot24_lds(w3run, xb + 3 * j03) : 0.0;
-        p1[tid] = r1 >= 0 ? dot24(W1, ys + 6 * i01) : 0.0;
-        {
-          double acc = 0.0;                                    // P x from the packed workspace copy of P
-          if (r2 < n) {
+        double o3[6], o1[3], px3[3] = {0.0, 0.0, 0.0};
+        stage3_partial(Gd, xtP + XOFF + 3 * (blk - 2 * q - 1), o3);
+        const double axs = reduce6(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], h, g, e);
+        stage1_partial(Gd, ysP + 6 * (blk + 2 * q), o1);
+        const double atys = reduce3(o1[0], o1[1], o1[2], h, g);
+        if (inb) {                                              // P x: row blk's 16 lanes split the columns six apiece
 #pragma unroll
-            for (int k = 0; k < FK; ++k) {
-              const int col = FK * h2 + k;
-              if (col < n) acc += (r2 >= col ? Pg[tri(r2, col)] : Pg[tri(col, r2)]) * xb[col];
+          for (int cc = 0; cc < 6; ++cc) {
+            const int col = 6 * q + cc;
+            if (col < n) {
+              const double xv = xtP[XOFF + col];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                const int row = 3 * blk + c;
+                px3[c] = fma(Pg[row >= col ? tri(row, col) : tri(col, row)], xv, px3[c]);
+              }
             }
           }
-          acc = quad_sum(acc);
-          if (h2 == 0 && r2 < n) pxv[r2] = acc;
         }
-        __syncthreads();
+        const double px = reduce3(px3[0], px3[1], px3[2], h, g);
         double v[7] = {0, 0, 0, 0, 0, 0, 0};                    // r1, |Ax|, |z|, r2, |Px|, |A'y|, |q|
-        if (rown) {
-          double ax;
-          if (srow) { ax = 0.0; for (int s = 0; s < c3; ++s) ax += p3[f3 + s]; }
-          else if (tid < ms + n) ax = xb[tid - ms];
-          else { const int k = tid - ms - n; ax = xb[k] - (k >= 3 ? xb[k - 3] : 0.0); }
+        if (kind) {
+          const double ax = kind == 1 ? axs : (kind == 2 ? xtP[XOFF + k3] : xtP[XOFF + k3] - xtP[XOFF + k3 - 3]);
           v[0] = fabs(ax - z); v[1] = fabs(ax); v[2] = fabs(z);
         }
         if (xown) {
-          double t = 0.0;
-          for (int s = 0; s < c1; ++s) t += p1[f1 + s];
-          const double aty = t + yc[tid] + (yr[tid] - (tid + 3 < n ? yr[tid + 3] : 0.0));
-          v[3] = fabs(pxv[tid] + qe + aty); v[4] = fabs(pxv[tid]); v[5] = fabs(aty); v[6] = fabs(qe);
+          const double aty = atys + yc[xe] + (yr[xe] - yr[xe + 3]);
+          v[3] = fabs(px + qe + aty); v[4] = fabs(px); v[5] = fabs(aty); v[6] = fabs(qe);
         }
         const bool allmax[7] = {false, false, false, false, false, false, false};
         block_reduce<7>(v, allmax, red);
@@ -440,58 +686,45 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a, const FastDesc *__re
         if (rp <= a.s.eps_abs + a.s.eps_rel * np_ && rd <= a.s.eps_abs + a.s.eps_rel * nd_) { done = true; converged = true; }
         else {
           // OSQP primal-infeasibility certificate on dy
-          double u[2] = {rown ? fabs(dy) : 0.0, rown ? hi * fmax(dy, 0.0) + lo * fmin(dy, 0.0) : 0.0};
+          double u[2] = {kind ? fabs(dy) : 0.0, kind ? hi * fmax(dy, 0.0) + lo * fmin(dy, 0.0) : 0.0};
           const bool kinds[2] = {false, true};
           block_reduce<2>(u, kinds, red);
           const double ndy = u[0], supp = u[1];
           if (ndy > a.s.eps_prim_inf && supp < -a.s.eps_prim_inf * ndy) {
-            if (rown) { double *d = srow ? ys + tid : (tid < ms + n ? yc + (tid - ms) : yr + (tid - ms - n)); *d = dy; }
+            if (kind) *ydst = dy;
             __syncthreads();
-            p1[tid] = r1 >= 0 ? dot24(W1, ys + 6 * i01) : 0.0;
-            __syncthreads();
-            double w[1] = {0.0};
-            if (xown) {
-              double t = 0.0;
-              for (int s = 0; s < c1; ++s) t += p1[f1 + s];
-              w[0] = fabs(t + yc[tid] + (yr[tid] - (tid + 3 < n ? yr[tid + 3] : 0.0)));
-            }
+            stage1_partial(Gd, ysP + 6 * (blk + 2 * q), o1);
+            const double t = reduce3(o1[0], o1[1], o1[2], h, g);
+            double wv[1] = {xown ? fabs(t + yc[xe] + (yr[xe] - yr[xe + 3])) : 0.0};
             const bool km[1] = {false};
-            block_reduce<1>(w, km, red);
-            if (w[0] < a.s.eps_prim_inf * ndy) { done = true; infeasible = true; }
+            block_reduce<1>(wv, km, red);
+            if (wv[0] < a.s.eps_prim_inf * ndy) { done = true; infeasible = true; }
           }
           if (!done) {
             if (it >= a.s.max_iter) done = true;
             else if (a.s.adaptive_rho && it % a.s.rho_every == 0) {
               double nw = rho * sqrt((rp / fmax(np_, 1e-10)) / fmax(rd / fmax(nd_, 1e-10), 1e-10));
               nw = fmin(fmax(nw, 1e-6), 1e6);
-              if (nw > 5 * rho || nw < rho / 5) {
-                rho = nw;
-                ok = sweep_inverse(Mp, cvec, Pg, Ag, rho, sigma, n, np) && ok;
-                load_w2();
-                load_w1();
-                if (!ok) done = true;
-              }
+              if (nw > 5 * rho || nw < rho / 5) { rho = nw; refactor = true; }
             }
           }
         }
       }
       // w = rho z - y for the next iteration
-      if (rown) { double *d = srow ? ws + tid : (tid < ms + n ? wc + (tid - ms) : wr + (tid - ms - n)); *d = rho * z - y; }
-      MSTAMP(8)
+      if (kind) *wdst = rho * z - y;
+      MSTAMP(4)
       __syncthreads();
-      MSTAMP(9)
+      MSTAMP(5)
+      }
     }
-#ifdef F16_EXP_STAMPM
-    if ((tid & 63) == 0 && a.useq && b == 0) for (int i = 0; i < 10; ++i) a.useq[(10 * (tid >> 6) + i) * a.ld + 1] = (double)tS[i] / it;
-#endif
+
     // res.x[0:3] (env.py:424); OSQP hands back NaN for a problem it certifies infeasible
-    if (tid < 3) a.ucmd[tid * a.ld + b] = infeasible ? NAN : xs;
-    if (a.useq && xown) a.useq[tid * a.ld + b] = infeasible ? NAN : xs;
+    if (xown) {
+      if (xe < 3) a.ucmd[xe * a.ld + b] = infeasible ? NAN : xs;
+      if (a.useq) a.useq[xe * a.ld + b] = infeasible ? NAN : xs;
+    }
     if (tid == 0) {
       if (a.info) {
-#ifdef F16_EXP_STAMP
-        rp = cvec[0]; rd = cvec[1];
-#endif
         a.info[0 * a.ld + b] = (double)it;
         a.info[1 * a.ld + b] = rp;
         a.info[2 * a.ld + b] = rd;
@@ -500,30 +733,33 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a, const FastDesc *__re
       if (a.status && infeasible) a.status[b] |= F16_ST_QP_INFEASIBLE;
       else if (a.status && a.s.max_iter > 0 && (!converged || !ok)) a.status[b] |= F16_ST_QP_MAXITER;
     }
-    __syncthreads();
+#ifdef F16_EXP_STAMPM
+    __syncthreads();      // diagnostic build: aircraft 0's u_seq column is replaced by the stamps
+    if ((tid & 63) == 0 && a.useq && b == 0) for (int i = 0; i < 6; ++i) a.useq[(6 * (tid >> 6) + i) * a.ld] = (double)tS[i] / it;
+    if (tid == 0 && a.useq && b == 0) { a.useq[48 * a.ld] = (double)(tP1 - tP0); a.useq[49 * a.ld] = (double)(tP2 - tP1); }
+#endif
   }
 }
 
 int mpc_fast_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
+  (void)ctx;
   if (a.N < 1 || a.N > FAST_MAXN) return set_error(F16_EINVAL, "fast MPC solver needs 1 <= N <= 32");
-  static std::mutex mu;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    if (!ctx->d_fast_desc || ctx->fast_desc_N != a.N) {
-      FastDesc h;
-      if (build_desc(a.N, h)) return set_error(F16_EINVAL, "internal: lane map does not fit");
-      if (!ctx->d_fast_desc) {
-        if (int rc = hip_check(hipMalloc(&ctx->d_fast_desc, sizeof(FastDesc)), "hipMalloc lane map")) return rc;
-      } else {
-        (void)hipStreamSynchronize((hipStream_t)stream);   // a previous launch may still read the old map
-      }
-      if (int rc = hip_check(hipMemcpy(ctx->d_fast_desc, &h, sizeof(FastDesc), hipMemcpyHostToDevice), "upload lane map")) return rc;
-      ctx->fast_desc_N = a.N;
-    }
-  }
-  const unsigned grid = (unsigned)(a.B < 512 ? a.B : 512);
-  hipLaunchKernelGGL(k_mpc_fast, dim3(grid), dim3(FT), 0, (hipStream_t)stream, a, (const FastDesc *)ctx->d_fast_desc);
+  // one aircraft per workgroup; the hardware queue balances the unequal iteration counts
+  if (a.B > 0x7fffffffL) return set_error(F16_EINVAL, "batch too large for one launch");
+  const unsigned grid = (unsigned)a.B;
+  const int nt = (3 * a.N + 15) / 16;       // 16x16 tiles per side of the KKT matrix, instantiated for 2 / 4 / 6
+  if (nt <= 2) hipLaunchKernelGGL(k_mpc_fast<2>, dim3(grid), dim3(FT), 0, (hipStream_t)stream, a);
+  else if (nt <= 4) hipLaunchKernelGGL(k_mpc_fast<4>, dim3(grid), dim3(FT), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_mpc_fast<6>, dim3(grid), dim3(FT), 0, (hipStream_t)stream, a);
   return hip_check(hipGetLastError(), "f16_mpc_batch solve launch");
 }
 
 }  // namespace f16
+
+extern "C" int f16_debug_spd_inverse(f16_ctx *ctx, const double *packed, double *out, int n, long B, int use_mfma, void *stream) {
+  using namespace f16;
+  if (!ctx || !packed || !out || n < 1 || n > FN || B < 0) return set_error(F16_EINVAL, "bad argument");
+  if (B == 0) return F16_OK;
+  hipLaunchKernelGGL(k_dbg_inverse, dim3((unsigned)(B < 512 ? B : 512)), dim3(FT), 0, (hipStream_t)stream, packed, out, n, B, use_mfma);
+  return hip_check(hipGetLastError(), "f16_debug_spd_inverse launch");
+}

@@ -250,3 +250,34 @@ def test_config5_closed_loop_rollout_single_rank():
     assert tuple(traj.shape) == (3, 18, 128) and torch.isfinite(traj).all()
     assert torch.equal(traj[-1], env._x)
     assert fdist.or_status(env.status) == 0
+
+
+@pytest.mark.parametrize("n", [3, 12, 30, 47, 90, 96])
+@pytest.mark.parametrize("use_mfma", [1, 0])
+def test_mfma_inverse(n, use_mfma):
+    """KKT-inverse routine of the MPC solver on its own: blocked fp64-MFMA sweep (and the scalar sweep it replaced)
+    against numpy.linalg.inv on random SPD matrices shaped like P + sigma I + rho A'A (condition ~1e3)."""
+    from f16_mpc_oop_py_amd import lib
+    L = lib.load()
+    ctx = lib.Context()
+    rng = np.random.default_rng(100 + n)
+    Bn = 5
+    mats, packed = [], []
+    for _ in range(Bn):
+        G = rng.standard_normal((n, n))
+        Q, _ = np.linalg.qr(G)
+        M = (Q * np.geomspace(1.0, 1e3, n)) @ Q.T
+        M = 0.5 * (M + M.T)
+        mats.append(M)
+        packed.append(M[np.tril_indices(n)])
+    pk = torch.tensor(np.stack(packed), dtype=torch.float64, device="cuda")
+    out = torch.empty((Bn, n * n), dtype=torch.float64, device="cuda")
+    lib.check(L.f16_debug_spd_inverse(ctx.handle, ctypes.c_void_p(pk.data_ptr()), ctypes.c_void_p(out.data_ptr()), n, Bn,
+                                      use_mfma, None), L)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(Bn, n, n)
+    for b in range(Bn):
+        ref = np.linalg.inv(mats[b])
+        assert np.isfinite(got[b]).all()
+        assert np.abs(got[b] - ref).max() <= 1e-11 * np.abs(ref).max()
+        assert np.abs(got[b] @ mats[b] - np.eye(n)).max() < 1e-10

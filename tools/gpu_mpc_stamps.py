@@ -1,0 +1,19 @@
+"""Diagnostic: per-phase cycles of k_mpc_fast from a -DF16_EXP_STAMPM build (run on the GPU box).
+usage: F16HIP_SO=build/libf16hip_stamp.so python tools/gpu_mpc_stamps.py [B]"""
+import sys
+sys.path.insert(0, ".")
+import numpy as np
+import torch
+from f16_mpc_oop_py_amd import F16Batch
+from f16_mpc_oop_py_amd.workload import config4_states
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+x0, u0 = config4_states(B)
+env = F16Batch(x0, u0, xcg=0.35)
+env.build_ssr()
+u, info = env._calc_MPC_action(0, 0, 0, 30, settings=dict(max_iter=100, check_every=1000), return_info=True)
+torch.cuda.synchronize()
+s = info["u_seq"][0, :48].cpu().numpy().reshape(8, 6)      # aircraft 0 column holds the stamps
+np.set_printoptions(linewidth=200, precision=0, suppress=True)
+print("cycles per iteration, rows = waves, cols = A, bar1, B, bar2, C, bar3 (s_memtime ticks @100MHz => x24 for 2.4GHz)")
+print(s, s.sum(1))
+print("prologue (loads, rho) / inverse cycles:", info["u_seq"][0, 48:50].cpu().numpy())
