@@ -208,44 +208,151 @@ __global__ __launch_bounds__(64) void k_c2d(C2dArgs a) {
 //   A0 = A, G0 = B R^-1 B', H0 = Q;  W = (I + G H)^-1;  A+ = A W A;  G+ = G + A W G A';  H+ = H + A' H W A.
 // H_k -> X quadratically (21 doublings at the reference's trim point; scipy.linalg.solve_discrete_are's
 // answer is reproduced to ~1e-11 relative).  R = I here (env.py:354, :405-407).
-constexpr int DARE_SCRATCH = 82 * 7 + 164 + 10;
-__device__ int dare_sda_wave(const double *A0, const double *Bm, const double *Q, double *X, double *scr) {
-  Bump al{scr};
-  double *A = al.take(81), *G = al.take(81), *H = al.take(81), *W = al.take(81);
-  double *T1 = al.take(81), *T2 = al.take(81), *T3 = al.take(81), *Wx = al.take(162), *f = al.take(9);
-  const int l = lane_id();
-  copy(A, A0, 81);
-  copy(H, Q, 81);
-  mm<false, true>(G, Bm, Bm, 9, 3, 9);
+//
+// Mapping: one wavefront per aircraft, every 9x9 operand lives in REGISTERS as a zero-padded 16x16 tile in the
+// accumulator layout of v_mfma_f64_16x16x4_f64 (register q of lane l holds element (4q + l/16, l%16); rows 12..15 are
+// padding and never stored), and every product is three chained MFMAs with no data movement at all, because
+//   * the B operand of k-step s (lane l -> B[4s + l/16][l%16]) IS register s of the right factor's tile, and
+//   * the A operand of k-step s (lane l -> A[l%16][4s + l/16]) IS register s of the tile of the left factor's TRANSPOSE,
+// so the iteration carries A and A' (G, H are symmetric) and forms each intermediate in the orientation its consumer
+// needs: 9 products = 27 MFMAs per doubling.  W = (I + G H)^-1 is a register-resident Gauss-Jordan (inverse9_tile).
+typedef double d4_t __attribute__((ext_vector_type(4)));
+constexpr int DARE_SCRATCH = 9 * 18 + 16;
+
+// D = C + L R, the left factor given as the tile of L'
+__device__ __forceinline__ d4_t mm16(const d4_t &Lt, const d4_t &R, d4_t C) {
+  C = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[0], R[0], C, 0, 0, 0);
+  C = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[1], R[1], C, 0, 0, 0);
+  C = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[2], R[2], C, 0, 0, 0);
+  return C;
+}
+// tile of the row-major 9x9 LDS matrix M (or of its transpose)
+__device__ __forceinline__ d4_t tile9(const double *M, bool transpose) {
+  const int l = lane_id(), lc = l & 15, lq = l >> 4;
+  d4_t t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int r = 4 * q + lq;
+    if (r < 9 && lc < 9) t[q] = transpose ? M[lc * 9 + r] : M[r * 9 + lc];
+  }
+  return t;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// W <- M^-1 for the 9x9 tile M: Gauss-Jordan with partial pivoting on [M | I] held one COLUMN per lane (lanes 0..17,
+// nine rows in registers).  A pivot step broadcasts the pivot column from its lane (v_readlane -> scalars), so the pivot
+// search and the multipliers are wave-uniform and the step needs no LDS and no barrier; rows are not swapped, the row
+// map is applied when the inverse is written back.  LDS (Wl, 81 doubles) only converts between the two layouts.
+__device__ __forceinline__ bool inverse9_tile(const d4_t &M, d4_t &W, double *Wl) {
+  const int l = lane_id(), lc = l & 15, lq = l >> 4;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int r = 4 * q + lq;
+    if (r < 9 && lc < 9) Wl[r * 9 + lc] = M[q];
+  }
+  __syncthreads();
+  const int j = l < 18 ? l : 17;                       // lanes beyond 17 shadow column 17
+  double r[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r[i] = j < 9 ? Wl[i * 9 + j] : (i == j - 9 ? 1.0 : 0.0);
+  unsigned done = 0;
+  int pinv[9];                                         // pinv[i] = the pivot step that used row i
+  bool ok = true;
+#pragma unroll
+  for (int p = 0; p < 9; ++p) {
+    double c[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c[i] = readlane_f64(r[i], p);
+    int piv = 0;
+    double best = -1.0, cp = 1.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const double v = ((done >> i) & 1u) ? -1.0 : fabs(c[i]);
+      const bool gt = v > best;
+      best = gt ? v : best; piv = gt ? i : piv; cp = gt ? c[i] : cp;
+    }
+    ok = ok && best > 0.0;
+    done |= 1u << piv;
+    double rp = r[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) rp = piv == i ? r[i] : rp;
+    rp *= 1.0 / cp;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      r[i] = piv == i ? rp : fma(-c[i], rp, r[i]);
+      pinv[i] = piv == i ? p : (p == 0 ? 0 : pinv[i]);
+    }
+  }
+  __syncthreads();                                     // all reads of Wl are long done; reuse it for the inverse
+  if (l >= 9 && l < 18) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Wl[pinv[i] * 9 + (l - 9)] = r[i];
+  }
+  __syncthreads();
+  W = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int rr = 4 * q + lq;
+    if (rr < 9 && lc < 9) W[q] = Wl[rr * 9 + lc];
+  }
+  __syncthreads();
+  return ok;
+}
+
+__device__ __forceinline__ int dare_sda_wave(const double *A0, const double *Bm, const double *Q, double *X, double *scr) {
+  const int l = lane_id(), lc = l & 15, lq = l >> 4;
+  const d4_t zero = {0.0, 0.0, 0.0, 0.0};
+  d4_t A = tile9(A0, false), At = tile9(A0, true), H = tile9(Q, false);
+  d4_t G;
+  {
+    d4_t Bt = zero;                                  // tile of B' (3x9): element (k, i) = B[i][k]
+    if (lq < 3 && lc < 9) Bt[0] = Bm[lc * 3 + lq];
+    G = __builtin_amdgcn_mfma_f64_16x16x4f64(Bt[0], Bt[0], zero, 0, 0, 0);     // G0 = B R^-1 B', R = I
+  }
+  d4_t eye = zero;
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    if (4 * q + lq == lc && lc < 9) eye[q] = 1.0;
   int it = 0;
   for (; it < 60; ++it) {
-    mm<false, false>(W, G, H, 9, 9, 9);
-    for (int e = l; e < 9; e += F16_WAVE) W[e * 10] += 1.0;
-    __syncthreads();
-    inverse(W, 9, Wx, f);
-    mm<false, false>(T1, A, W, 9, 9, 9);            // A W
-    mm<false, false>(T2, T1, G, 9, 9, 9);           // A W G
-    mm<false, true>(G, T2, A, 9, 9, 9, 1.0, 1.0);   // G += A W G A'
-    mm<false, false>(T2, H, W, 9, 9, 9);            // H W
-    mm<false, false>(T3, T2, A, 9, 9, 9);           // H W A
-    mm<true, false>(T2, A, T3, 9, 9, 9);            // A' H W A
+    const d4_t M = mm16(G, H, eye);                  // I + G H          (G symmetric: its own transpose)
+    const d4_t GAt = mm16(G, At, zero);              // G A'             (independent of W: overlaps the inverse)
+    d4_t W;
+    if (!inverse9_tile(M, W, scr)) { it = 60; break; }
+    const d4_t T1t = mm16(W, At, zero);              // (A W)' = W' A'   (left W' <- tile of W)
+    const d4_t HWt = mm16(W, H, zero);               // (H W)' = W' H
+    const d4_t An = mm16(T1t, A, zero);              // A W A            (left A W <- tile of (A W)')
+    const d4_t Atn = mm16(A, T1t, zero);             // (A W A)' = A' (A W)'
+    G = mm16(T1t, GAt, G);                           // G + A W G A'
+    const d4_t HWA = mm16(HWt, A, zero);             // H W A            (left H W <- tile of (H W)')
+    const d4_t dH = mm16(A, HWA, zero);              // A' H W A         (left A' <- tile of A)
     double dmax = 0.0, hmax = 0.0;
-    for (int e = l; e < 81; e += F16_WAVE) {
-      const double hn = H[e] + T2[e];
-      dmax = fmax(dmax, fabs(T2[e]));
-      hmax = fmax(hmax, fabs(hn));
-      H[e] = hn;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      H[q] += dH[q];
+      dmax = fmax(dmax, fabs(dH[q]));
+      hmax = fmax(hmax, fabs(H[q]));
     }
     dmax = wave_max(dmax);
     hmax = wave_max(hmax);
-    __syncthreads();
-    mm<false, false>(T2, T1, A, 9, 9, 9);           // A W A
-    copy(A, T2, 81);
+    A = An; At = Atn;
     if (dmax <= 1e-16 * hmax) { ++it; break; }
   }
+  // X = (H + H') / 2 through LDS (the caller wants it there)
+  double *Xt = scr;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int r = 4 * q + lq;
+    if (r < 9 && lc < 9) Xt[r * 9 + lc] = H[q];
+  }
+  __syncthreads();
   for (int e = l; e < 81; e += F16_WAVE) {
     const int i = e / 9, j = e - i * 9;
-    X[e] = 0.5 * (H[e] + H[j * 9 + i]);
+    X[e] = 0.5 * (Xt[e] + Xt[j * 9 + i]);
   }
   __syncthreads();
   return it;
@@ -371,8 +478,10 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
       xref[l] = (l >= 5 && l < 8) ? a.dem[(l - 5) * a.ld + b] : v;   // env.py:380-383 (x_ref[5:8] = demands)
     }
     __syncthreads();
+#ifndef F16_EXP_SKIP_DARE
     dare_sda_wave(A, Bm, Q, X, scr);
     lqr_gain_wave(A, Bm, X, K, scr);                  // K_dlqr; the reference uses K = -dlqr (utils.py:96)
+#endif
     // Q_bar (utils.py:100) solves X = Phi' X Phi + Q + K'RK with Phi = A + B K: for the LQR gain K that equation IS the
     // DARE, so its solution is the DARE solution X itself.  (Measured on the reference's trim models: SDA's X agrees
     // with scipy.linalg.solve_discrete_lyapunov's Q_bar to 3e-13 relative -- closer than scipy's own DARE result.)
@@ -408,7 +517,11 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
     // Block (j,l), j >= l, d = j-l:  T(j,l) = TQ(j,l) + G'_{N-1-j} Qbar G_{N-1-l},
     //   TQ(j,l) = TQ(j+1,l+1) + G'_{N-2-j} Q G_{N-2-l} (0 beyond N-2),  TS likewise with S'S and all i <= N-1.
     double *Pg = a.Ppk + (size_t)b * np, *Ag = a.Apk + (size_t)b * np;
+#ifdef F16_EXP_SKIP_PBUILD
+    for (int ch = l; ch < 0; ch += F16_WAVE) {
+#else
     for (int ch = l; ch < N * 9; ch += F16_WAVE) {       // one chain per (diagonal d, element (ra,cb))
+#endif
       const int d = ch / 9, ee = ch - 9 * d, ra = ee / 3, cb = ee - 3 * ra;
       double tq = 0.0, ts = 0.0;
       for (int j = N - 1; j >= d; --j) {
