@@ -210,11 +210,21 @@ def bench_mpc(args, dev, rank, world, fdist, barrier):
     barrier()
     dl = fdist.max_over_ranks(time.perf_counter() - t0, dev) / n
     flop_per_solve = 5.2e6 + 1.15e5 * float(np.mean(it))          # SURVEY.md 8(d) dense-form accounting
+    mfma = None
+    try:        # fp64 matrix-core counters of this same workload, recorded from the rocprofv3 --pmc pass (profiles/)
+        rec = json.load(open(os.path.join(REPO, "profiles", "mfma_mpc.json")))
+        if rec.get("batch") == B and rec.get("hzn") == args.mpc_hzn:
+            mfma = {k: rec[k] for k in ("k_mpc_fast", "k_mpc<true> (build)", "source")}
+    except Exception:
+        pass
     return {"metric": "MPC solves/sec (calc_MPC_action, N=%d, batch %d per GPU, xcg=0.35)" % (args.mpc_hzn, B),
             "value": world * B / dt, "unit": "solves/s", "ms_per_batch": dt * 1e3,
             "admm_iters": {"min": float(it.min()), "median": float(np.median(it)), "max": float(it.max())},
             "roofline": {"bound": "fp64 vector/MFMA (78.6 TF/s)", "achieved": flop_per_solve * B / dt / 1e12,
-                         "peak": 78.6, "unit": "TFLOP/s", "frac": flop_per_solve * B / dt / 78.6e12},
+                         "peak": 78.6, "unit": "TFLOP/s", "frac": flop_per_solve * B / dt / 78.6e12,
+                         "note": "dense-form FLOP accounting of SURVEY 8(d) over the measured time; the kernels use the "
+                                 "Toeplitz recursion, so issued FLOPs are lower"},
+            "admm_iters_mean": float(np.mean(it)), "mfma": mfma,
             "linearise_zoh_lqr_per_s": world * B / dl}
 
 

@@ -401,7 +401,7 @@ __device__ int dlyap_wave(const double *Phi, const double *Wm, double *X, double
 
 struct LqrArgs { const double *Ad, *Bd, *Cd; double *K, *Pare; int32_t *status; long B, ld; };
 
-__global__ __launch_bounds__(64) void k_lqr(LqrArgs a) {
+__global__ __launch_bounds__(64, 3) void k_lqr(LqrArgs a) {
   __shared__ double smem[82 * 5 + 28 * 2 + DARE_SCRATCH + 100];   // DARE scratch also serves lqr_gain_wave
   Bump al{smem};
   double *A = al.take(81), *Bm = al.take(27), *C = al.take(81), *Q = al.take(81), *X = al.take(81), *K = al.take(27);

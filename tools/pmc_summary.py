@@ -34,7 +34,6 @@ with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     for r in rows:
         r["Name"] = r["Name"][:120]
         w.writerow(r)
-kern = [r for r in rows if "k_rollout" in r["Name"]][0]
 
 
 def counter(d, name):
@@ -49,6 +48,7 @@ def counter(d, name):
 fetch, meta = counter(fetch_dir, "FETCH_SIZE")
 kname = meta["Kernel_Name"].replace("void ", "").split("(")[0].replace(",", ";")
 write, _ = counter(write_dir, "WRITE_SIZE")
+kern = [r for r in rows if kname.split("::")[-1].split("<")[0] in r["Name"] and ("4w" in kname) == ("4w" in r["Name"])][0]
 with open(os.path.join(out, f"{tag}_pmc_k_rollout.csv"), "w") as f:
     f.write("kernel,counter,launches,mean_KiB,min_KiB,max_KiB,VGPR,LDS_bytes,workgroup\n")
     for nm, v in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
