@@ -125,6 +125,9 @@ def main():
         out["mpc"] = bench_mpc(args, dev, rank, world, fdist, barrier)
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(x0, u0, T)
+        if "mpc" in out:
+            out["mpc"]["cpu_baseline"] = cpu_baseline_mpc(args.mpc_hzn)
+        out["config1_dropin_loop"] = config1_dropin_loop()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
@@ -247,6 +250,59 @@ def cpu_baseline(x0, u0, T):
             "single_thread_value": n1 * T / t1,
             "sample": f"first {nall} aircraft x {T} steps of the same workload on {cores} threads "
                       f"(single-thread figure: first {n1} aircraft); oracle/libf16_oracle.so (C restatement)"}
+
+
+def cpu_baseline_mpc(hzn, n=12):
+    """the MPC CPU baseline is the same-algorithm numpy restatement (oracle/, kind 'port') on the same
+    config-4 flight conditions -- OSQP itself cannot be timed anywhere in this pipeline (not installable offline).
+    Bounded sample: n aircraft, single thread; whole chain per solve = linearise + ZOH + setup_OSQP + ADMM."""
+    from oracle import mpc_oracle as mo
+    from f16_mpc_oop_py_amd.workload import config4_states
+    ora = mo.COracle()
+    x0, _ = config4_states(n)
+    t0 = time.perf_counter()
+    its = []
+    for b in range(n):
+        Ac, Bc, Cc, Dc = ora.linearise_na(x0[b], xcg=0.35)
+        Ad, Bd, Cd, _ = mo.c2d(Ac, Bc, Cc, Dc, 0.001)
+        P, q, A, l, u = mo.mpc_qp(x0[b], Ad, Bd, Cd, hzn, 0.001)
+        its.append(mo.admm_osqp_style(P, q, A, l, u)["iters"])
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "solves/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+            "sample": f"{n} config-4 aircraft, N={hzn}: C linearise + scipy ZOH/DARE + numpy setup_OSQP + numpy ADMM "
+                      f"(same rules as the kernel; mean {float(np.mean(its)):.0f} iterations); one Python thread, numpy/BLAS may use the cores listed"}
+
+
+def config1_dropin_loop(steps=2000):
+    """BASELINE config 1 shape (1 aircraft, lofi, open-loop Euler through the reference-style caller): a Python loop
+    over the drop-in `Nlplant` / `atmos` symbols of libf16hip.so (host pointers, one aircraft per call on the GPU) next
+    to the same loop over the C restatement on the CPU.  us per step, lower is better; not the product's use case."""
+    import ctypes
+    from f16_mpc_oop_py_amd import lib
+    from f16_mpc_oop_py_amd import parameters as P
+    from oracle import mpc_oracle as mo
+    L = lib.load()
+    L.f16_dropin_config(0.25, 0)
+    x = np.array(P.x0, dtype=np.float64) if hasattr(P, "x0") else None
+    if x is None:
+        from f16_mpc_oop_py_amd.workload import config2_states
+        x = config2_states(1)[0][0].copy()
+    xdot = np.zeros(18)
+    vp = ctypes.c_void_p
+
+    def loop(fn):
+        xx = x.copy()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn(vp(xx.ctypes.data), vp(xdot.ctypes.data), 0)
+            xx[:12] += xdot[:12] * 0.001
+        return (time.perf_counter() - t0) / steps * 1e6
+
+    gpu_us = loop(L.Nlplant)
+    ora = mo.COracle()
+    cpu_us = loop(ora.lib.Nlplant) if hasattr(ora, "lib") and hasattr(ora.lib, "Nlplant") else None
+    return {"steps": steps, "fidelity": "lofi", "us_per_step_dropin_gpu_symbol": gpu_us,
+            "us_per_step_cpu_restatement_symbol": cpu_us, "unit": "us/step"}
 
 
 if __name__ == "__main__":
