@@ -223,23 +223,44 @@ __device__ __forceinline__ double sel4(double v0, double v1, double v2, double v
   return (k & 2) ? hi : lo;
 }
 
+// Panel buffer of one block step: C[col][0..3] = M[pivot row][col] (FN x 4), then D^-1 (4 x 4, row-major) and a flag.
+constexpr int PAN_DI = FN * 4, PAN_OK = FN * 4 + 16, PAN_SIZE = FN * 4 + 18;
+
+// The wave that published pivot rows [k0, k0+4) into pan also inverts the 4x4 pivot block, once for everybody: reads the
+// block back (its own LDS writes, same wave), inverts it in registers, lanes 0..3 store one row each.
+__device__ __forceinline__ void publish_dinv(double *pan, int k0, int l) {
+  double D[4][4], Di[4][4];
+  const double2 *src = reinterpret_cast<const double2 *>(pan + k0 * 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double2 u = src[2 * i], v = src[2 * i + 1];
+    D[i][0] = u.x; D[i][1] = u.y; D[i][2] = v.x; D[i][3] = v.y;
+  }
+  const bool good = inv4_spd(D, Di);
+  if (l < 4) {
+    double2 *dst = reinterpret_cast<double2 *>(pan + PAN_DI + 4 * l);
+    dst[0] = make_double2(sel4(Di[0][0], Di[1][0], Di[2][0], Di[3][0], l), sel4(Di[0][1], Di[1][1], Di[2][1], Di[3][1], l));
+    dst[1] = make_double2(sel4(Di[0][2], Di[1][2], Di[2][2], Di[3][2], l), sel4(Di[0][3], Di[1][3], Di[2][3], Di[3][3], l));
+    if (l == 0) pan[PAN_OK] = good ? 1.0 : 0.0;
+  }
+}
+
 // One block step of the sweep: pivots 16 Kt + 4 KQ .. +3 (accumulator register KQ of tile row Kt).  cb: this step's
-// panel C[col][0..3] = M[pivot row][col]; cbn: where the NEXT step's panel is published.
+// panel (pivot rows, D^-1); cbn: where the NEXT step's panel is published.
 template <int NTT, int KQ>
 __device__ __forceinline__ void inverse_step(d4_t (&acc)[NT], const double *cb, double *cbn, int Kt, int w, int lc, int lq,
                                              bool &ok) {
   const bool pl = (lc >> 2) == KQ;                       // this lane's column (within a tile) is a pivot column
-  // ---- D and its inverse (every lane; broadcast reads)
-  double D[4][4], Di[4][4];
+  // rows of D^-1 (symmetric: row = column): row l/16 for the A operand and the pivot rows, row l%4 for the pivot columns
+  double dA[4], dC[4];
   {
-    const double2 *src = reinterpret_cast<const double2 *>(cb + (16 * Kt + 4 * KQ) * 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const double2 u = src[2 * i], v = src[2 * i + 1];
-      D[i][0] = u.x; D[i][1] = u.y; D[i][2] = v.x; D[i][3] = v.y;
-    }
+    const double2 *ra = reinterpret_cast<const double2 *>(cb + PAN_DI + 4 * lq);
+    const double2 *rc = reinterpret_cast<const double2 *>(cb + PAN_DI + 4 * (lc & 3));
+    const double2 a0 = ra[0], a1 = ra[1], c0 = rc[0], c1 = rc[1];
+    dA[0] = a0.x; dA[1] = a0.y; dA[2] = a1.x; dA[3] = a1.y;
+    dC[0] = c0.x; dC[1] = c0.y; dC[2] = c1.x; dC[3] = c1.y;
   }
-  // operands that do not depend on D^-1 first (their LDS latency overlaps the 4x4 inverse)
+  ok = ok && cb[PAN_OK] > 0.5;
   double2 ca0, ca1;
   {
     const double2 *src = reinterpret_cast<const double2 *>(cb + (16 * w + lc) * 4);
@@ -251,23 +272,14 @@ __device__ __forceinline__ void inverse_step(d4_t (&acc)[NT], const double *cb, 
     b_op[J] = cb[(16 * J + lc) * 4 + lq];
     if (J == Kt && pl) b_op[J] = 0.0;
   }
-  ok = inv4_spd(D, Di) && ok;
   // ---- A operand: -(C D^-1)[16w + lc][lq], zero on pivot rows
-  double a_op;
-  {
-    double cdr[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) cdr[k] = ca0.x * Di[0][k] + ca0.y * Di[1][k] + ca1.x * Di[2][k] + ca1.y * Di[3][k];
-    a_op = -sel4(cdr[0], cdr[1], cdr[2], cdr[3], lq);
-    if (w == Kt && pl) a_op = 0.0;
-  }
+  double a_op = -(ca0.x * dA[0] + ca0.y * dA[1] + ca1.x * dA[2] + ca1.y * dA[3]);
+  if (w == Kt && pl) a_op = 0.0;
 #pragma unroll
   for (int J = 0; J < NTT; ++J) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op[J], acc[J], 0, 0, 0);
   // ---- pivot columns of this tile row: M[i][pivot kk] = (C D^-1)[i][kk] for rows outside the pivot block
   {
-    double dC[4], cd[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dC[k] = sel4(Di[k][0], Di[k][1], Di[k][2], Di[k][3], lc & 3);
+    double cd[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const double2 *src = reinterpret_cast<const double2 *>(cb + (16 * w + 4 * q + lq) * 4);
@@ -285,10 +297,7 @@ __device__ __forceinline__ void inverse_step(d4_t (&acc)[NT], const double *cb, 
   }
   // ---- pivot rows (owner wave, register KQ): M[pivot lq][j] = (C D^-1)[j][lq], -D^-1 on the pivot block itself
   if (w == Kt) {
-    double dA[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dA[k] = sel4(Di[k][0], Di[k][1], Di[k][2], Di[k][3], lq);
-    const double mdi = -sel4(dA[0], dA[1], dA[2], dA[3], lc & 3);
+    const double mdi = -cb[PAN_DI + 4 * lq + (lc & 3)];
 #pragma unroll
     for (int J = 0; J < NTT; ++J) {
       const double2 *src = reinterpret_cast<const double2 *>(cb + (16 * J + lc) * 4);
@@ -297,21 +306,23 @@ __device__ __forceinline__ void inverse_step(d4_t (&acc)[NT], const double *cb, 
       acc[J][KQ] = (J == Kt && pl) ? mdi : cdv;
     }
   }
-  // ---- publish the next pivot rows
+  // ---- publish the next pivot rows and the inverse of their pivot block
   if (KQ < 3) {
     if (w == Kt) {
 #pragma unroll
       for (int J = 0; J < NTT; ++J) cbn[(16 * J + lc) * 4 + lq] = acc[J][(KQ + 1) & 3];
+      publish_dinv(cbn, 16 * Kt + 4 * (KQ + 1), 16 * lq + lc);
     }
-  } else if (w == Kt + 1) {
+  } else if (w == Kt + 1 && Kt + 1 < NTT) {
 #pragma unroll
     for (int J = 0; J < NTT; ++J) cbn[(16 * J + lc) * 4 + lq] = acc[J][0];
+    publish_dinv(cbn, 16 * (Kt + 1), 16 * lq + lc);
   }
 }
 
 // In-register blocked sweep over NTT x NTT tiles.  On return acc holds MINUS the inverse of P + sigma I + r A'A
 // (identity block on the padding rows n..16 NTT); tile (w,J), register q, lane l <-> element (16w + 4q + l/16, 16J + l%16).
-// Cs: LDS scratch [2][FN*4] doubles (double-buffered panel).  Return value is uniform over the workgroup.
+// Cs: LDS scratch [2][PAN_SIZE] doubles (double-buffered panel).  Return value is uniform over the workgroup.
 // Out of line on purpose: the block step wants ~200 registers of its own; as a call, the caller's live state is parked
 // once per inverse instead of being spilled and reloaded inside every block step.
 #ifndef F16_INV_ATTR
@@ -346,11 +357,12 @@ __device__ F16_INV_ATTR bool mfma_inverse(d4_t *acc_out, double *Cs, const doubl
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  double *c0 = Cs, *c1 = Cs + FN * 4;
+  double *c0 = Cs, *c1 = Cs + PAN_SIZE;
   __syncthreads();                        // previous users of Cs are done
   if (w == 0) {
 #pragma unroll
     for (int J = 0; J < NTT; ++J) c0[(16 * J + lc) * 4 + lq] = acc[J][0];
+    publish_dinv(c0, 0, l);
   }
   for (int Kt = 0; Kt < NTT; ++Kt) {
     __syncthreads();
@@ -370,7 +382,7 @@ __device__ F16_INV_ATTR bool mfma_inverse(d4_t *acc_out, double *Cs, const doubl
 // diagnostic / test entry: inverse of B packed SPD matrices through mfma_inverse (or the scalar sweep_inverse)
 __global__ __launch_bounds__(FT) void k_dbg_inverse(const double *pk, double *out, int n, long B, int use_mfma) {
   __shared__ __attribute__((aligned(16))) double Mp[FN * SLD];
-  __shared__ __attribute__((aligned(16))) double cv[2 * FN * 4];
+  __shared__ __attribute__((aligned(16))) double cv[2 * FN * 4 + 40];
   const int np = n * (n + 1) / 2, nt = (n + 15) >> 4;
   const int w = threadIdx.x >> 6, lc = threadIdx.x & 15, lq = (threadIdx.x & 63) >> 4;
   for (long b = blockIdx.x; b < B; b += gridDim.x) {
@@ -496,7 +508,7 @@ constexpr int XTP = XOFF + FN + 8;
 // where reduce6 leaves their z~), lanes 1,3,5 the command rows, 9,11,13 the rate rows, lanes 0,4,8 also own x[3 blk + c].
 template <int NTT>
 __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
-  __shared__ __attribute__((aligned(16))) double wsP[WSP], ysP[WSP], xtP[XTP], Cs[2 * FN * 4];
+  __shared__ __attribute__((aligned(16))) double wsP[WSP], ysP[WSP], xtP[XTP], Cs[2 * FN * 4 + 40];
   __shared__ double rhs[FN], wc[FN], wr[FN + 4], yc[FN], yr[FN + 4], red[8 * 8];
 
   const int N = a.N, n = 3 * N;
