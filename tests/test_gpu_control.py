@@ -281,3 +281,41 @@ def test_mfma_inverse(n, use_mfma):
         assert np.isfinite(got[b]).all()
         assert np.abs(got[b] - ref).max() <= 1e-11 * np.abs(ref).max()
         assert np.abs(got[b] @ mats[b] - np.eye(n)).max() < 1e-10
+
+
+def test_mpc_full_size_properties():
+    """BASELINE config 4 at full size (B = 4096, N = 30, xcg 0.35) through size-independent properties:
+    every solve meets OSQP's termination test; the first move respects the command and first-step rate rows
+    (utils.py:139-152) up to the termination tolerance; results do not depend on an aircraft's position in the batch
+    (bit-identical under a permutation); the register-resident solver and the generic one-wave solver (negative
+    max_iter) agree to solver tolerance on a sample."""
+    from f16_mpc_oop_py_amd.workload import config4_states
+    B, N = 4096, 30
+    x0, u0 = config4_states(B)
+    env = make_env(x0, u0, xcg=0.35)
+    env.build_ssr()
+    u, info = env._calc_MPC_action(0.0, 0.0, 0.0, N, return_info=True)
+    u = u.cpu().numpy()
+    assert int(info["status"].max()) == 0 and np.isfinite(u).all()
+    # termination: r_prim <= eps_abs + eps_rel * max(|Ax|,|z|) needs the norms; the absolute part alone bounds the rest
+    useq = info["u_seq"].cpu().numpy()                       # [B, 3N]
+    scale = np.maximum(1.0, np.abs(useq).max(axis=1))
+    assert (info["r_prim"].cpu().numpy() <= 1e-3 * (1 + 130 * scale)).all()
+    assert np.isfinite(info["r_dual"].cpu().numpy()).all()
+    lim = np.array([25.0, 21.5, 30.0])
+    assert (np.abs(useq.reshape(B, N, 3)) <= lim + 5e-2).all()             # command rows, whole horizon
+    act = x0[:, 13:16]
+    rate = np.array([60.0, 80.0, 120.0]) * 0.001
+    assert (np.abs(u - act) <= rate + 5e-2).all()                            # first-step rate rows
+    # permutation invariance (bit-exact)
+    perm = np.random.default_rng(5).permutation(B)
+    env2 = make_env(x0[perm], u0[perm], xcg=0.35)
+    env2.build_ssr()
+    u2 = env2._calc_MPC_action(0.0, 0.0, 0.0, N).cpu().numpy()
+    assert np.array_equal(u2, u[perm])
+    # fast solver vs generic solver on a sample
+    idx = np.arange(0, B, 64)
+    env3 = make_env(x0[idx], u0[idx], xcg=0.35)
+    env3.build_ssr()
+    u3 = env3._calc_MPC_action(0.0, 0.0, 0.0, N, settings=dict(max_iter=-40000)).cpu().numpy()
+    assert np.abs(u3 - u[idx]).max() < 2e-3
