@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64) void k_c2d(C2dArgs a) {
   }
 }
 
-// ------------------------------------------------------------------------------------ DARE / dlqr / dlyap
+// ------------------------------------------------------------------------------------ DARE / dlqr
 // DARE  X = A'XA - A'XB (R+B'XB)^-1 B'XA + Q  by the structure-preserving doubling algorithm (SDA):
 //   A0 = A, G0 = B R^-1 B', H0 = Q;  W = (I + G H)^-1;  A+ = A W A;  G+ = G + A W G A';  H+ = H + A' H W A.
 // H_k -> X quadratically (21 doublings at the reference's trim point; scipy.linalg.solve_discrete_are's
@@ -400,34 +400,6 @@ __device__ void lqr_gain_wave(const double *A, const double *Bm, const double *X
   mm<false, false>(K, S, BXA, 3, 3, 9);
 }
 
-// Discrete Lyapunov  X = Phi' X Phi + W  by doubling: X+ = X + F' X F, F+ = F F  (utils.py:100 with a = Phi').
-__device__ int dlyap_wave(const double *Phi, const double *Wm, double *X, double *scr) {
-  Bump al{scr};
-  double *F = al.take(81), *T1 = al.take(81), *T2 = al.take(81);
-  const int l = lane_id();
-  copy(F, Phi, 81);
-  copy(X, Wm, 81);
-  int it = 0;
-  for (; it < 60; ++it) {
-    mm<false, false>(T1, X, F, 9, 9, 9);
-    mm<true, false>(T2, F, T1, 9, 9, 9);
-    double dmax = 0.0, xmax = 0.0;
-    for (int e = l; e < 81; e += F16_WAVE) {
-      const double xn = X[e] + T2[e];
-      dmax = fmax(dmax, fabs(T2[e]));
-      xmax = fmax(xmax, fabs(xn));
-      X[e] = xn;
-    }
-    dmax = wave_max(dmax);
-    xmax = wave_max(xmax);
-    __syncthreads();
-    mm<false, false>(T1, F, F, 9, 9, 9);
-    copy(F, T1, 81);
-    if (dmax <= 1e-17 * xmax) { ++it; break; }
-  }
-  return it;
-}
-
 struct LqrArgs { const double *Ad, *Bd, *Cd; double *K, *Pare; int32_t *status; long B, ld; };
 
 __global__ __launch_bounds__(64, 3) void k_lqr(LqrArgs a) {
@@ -482,7 +454,7 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
   const int N = a.N, n = 3 * N, np = n * (n + 1) / 2, ms = 6 * N, m = 12 * N;
   const int l = lane_id();
   Bump al{smem};
-  // R0 is time-shared: DARE/dlyap scratch -> Q G_k / Qbar G_k blocks -> packed KKT inverse
+  // R0 is time-shared: DARE scratch -> Q G_k / Qbar G_k blocks -> packed KKT inverse
   const int r0 = SETUP_ONLY ? max(54 * N, 1100) : max(max(np, 54 * N), 1100);
   double *Minv = al.take(r0);
   double *G = al.take(N * 27);
@@ -507,10 +479,8 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
       xref[l] = (l >= 5 && l < 8) ? a.dem[(l - 5) * a.ld + b] : v;   // env.py:380-383 (x_ref[5:8] = demands)
     }
     __syncthreads();
-#ifndef F16_EXP_SKIP_DARE
     dare_sda_wave(A, Bm, Q, X, scr);
     lqr_gain_wave(A, Bm, X, K, scr);                  // K_dlqr; the reference uses K = -dlqr (utils.py:96)
-#endif
     // Q_bar (utils.py:100) solves X = Phi' X Phi + Q + K'RK with Phi = A + B K: for the LQR gain K that equation IS the
     // DARE, so its solution is the DARE solution X itself.  (Measured on the reference's trim models: SDA's X agrees
     // with scipy.linalg.solve_discrete_lyapunov's Q_bar to 3e-13 relative -- closer than scipy's own DARE result.)
@@ -546,11 +516,7 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
     // Block (j,l), j >= l, d = j-l:  T(j,l) = TQ(j,l) + G'_{N-1-j} Qbar G_{N-1-l},
     //   TQ(j,l) = TQ(j+1,l+1) + G'_{N-2-j} Q G_{N-2-l} (0 beyond N-2),  TS likewise with S'S and all i <= N-1.
     double *Pg = a.Ppk + (size_t)b * np, *Ag = a.Apk + (size_t)b * np;
-#ifdef F16_EXP_SKIP_PBUILD
-    for (int ch = l; ch < 0; ch += F16_WAVE) {
-#else
     for (int ch = l; ch < N * 9; ch += F16_WAVE) {       // one chain per (diagonal d, element (ra,cb))
-#endif
       const int d = ch / 9, ee = ch - 9 * d, ra = ee / 3, cb = ee - 3 * ra;
       double tq = 0.0, ts = 0.0;
       for (int j = N - 1; j >= d; --j) {

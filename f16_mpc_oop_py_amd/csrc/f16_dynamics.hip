@@ -121,125 +121,6 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DynArgs a) {
 }
 
 
-// Two-wavefront rollout for the latency regime (B <= 16,384: fewer aircraft than SIMDs x 64).  A plant step is a long
-// fp64 dependency chain; with one aircraft per lane and one wave per SIMD nothing hides it.  Here a workgroup of two
-// waves shares 64 aircraft and SPLITS THE STATE: wave 0 owns the rigid-body states x[0..11], wave 1 the actuator and
-// flap states x[12..17].  Per step
-//   wave 0: trigonometry, atmosphere, navigation + kinematic equations   ||  wave 1: table lookups, coefficient totals
-//   -- barrier --
-//   wave 0: force / moment equations, Euler + store of x[0..11]          ||  wave 1: actuator + flap models, x[12..17]
-// Two 2-wave barriers per step; what crosses (7 states + thrust at step start, 6 totals + qbar, ps at mid-step,
-// envelope / status bits) goes through lane-indexed, conflict-free LDS arrays.  Same device functions and arithmetic
-// as k_rollout.
-__global__ __launch_bounds__(128) void k_rollout_2w(DynArgs a) {
-  __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
-  __shared__ double xs[8][64], xt[8][64];     // xs: x[6..11], x[2], thrust ; xt: 6 totals, qbar, ps
-  __shared__ int xenv[2][64], xst[64];
-  {
-    const double2 *src = reinterpret_cast<const double2 *>(a.tab);
-    double2 *dst = reinterpret_cast<double2 *>(tab);
-    for (int i = threadIdx.x; i < TABLE_IMAGE_DOUBLES / 2; i += 128) dst[i] = src[i];
-    __syncthreads();
-  }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (long b0 = (long)blockIdx.x * 64; b0 < a.B; b0 += (long)gridDim.x * 64) {
-    const bool valid = b0 + lane < a.B;
-    const long b = valid ? b0 + lane : a.B - 1;           // ragged tail: shadow the last aircraft, never stored
-    double x[18], u[4];
-#pragma unroll
-    for (int k = 0; k < 18; ++k) x[k] = a.out[k * a.ld + b];   // each wave keeps ITS part current (0..11 / 12..17)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) u[k] = a.u[k * a.ld + b];
-    int st = a.status ? a.status[b] : 0;
-    const int k0 = wave == 0 ? 0 : 12, k1 = wave == 0 ? 12 : 18;
-    double *tr = a.traj ? a.traj + b : nullptr;
-    int until_store = a.traj_every;
-    for (int t = 0; t < a.nsteps; ++t) {
-      // ---- step start: envelope test on the owned states (env.py:117-124), publish what the other wave needs
-      int env = 0;
-      if (!(a.flags & FLAG_NO_ENVELOPE)) {
-        if (wave == 0)
-          env = x[2] < 0 || x[2] > 100000 || x[6] < 0 || x[6] > 900 || x[7] < -20. || x[7] > 90 || x[8] < -30. || x[8] > 30 ||
-                x[9] < -300 || x[9] > 300 || x[10] < -100 || x[10] > 100 || x[11] < -50 || x[11] > 50;
-        else
-          env = x[12] < 1000 || x[12] > 19000 || x[13] < -25 || x[13] > 25 || x[14] < -21.5 || x[14] > 21.5 || x[15] < -30. ||
-                x[15] > 30 || x[16] < 0. || x[16] > 25;
-      }
-      xenv[wave][lane] = env;
-      if (wave == 0) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) xs[k][lane] = x[6 + k];
-        xs[6][lane] = x[2];
-      } else {
-        xs[7][lane] = x[12];
-      }
-      __syncthreads();
-      if (xenv[0][lane] | xenv[1][lane]) st |= ST_ENVELOPE;
-      Pre p;
-      double xd[18];
-      if (wave == 1) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) x[6 + k] = xs[k][lane];
-        x[2] = xs[6][lane];
-        Totals tt;
-        int sa = 0;
-        aero_totals<1>((const double *)tab, a.lofi, x, a.xcg, 1, a.flags, tt, sa);
-        xt[0][lane] = tt.Cx; xt[1][lane] = tt.Cz; xt[2][lane] = tt.Cm;
-        xt[3][lane] = tt.Cy; xt[4][lane] = tt.Cn; xt[5][lane] = tt.Cl;
-        xst[lane] = sa;
-      } else {
-        x[12] = xs[7][lane];
-        plant_pre(x, p, xd);
-        xt[6][lane] = p.qbar; xt[7][lane] = p.ps;
-      }
-      __syncthreads();
-      // ---- second half: equations of motion (wave 0) || actuator models (wave 1); Euler on the owned states
-      if (!(st & ST_ENVELOPE)) {
-        if (wave == 0) {
-          Totals tt;
-          tt.Cx = xt[0][lane]; tt.Cz = xt[1][lane]; tt.Cm = xt[2][lane];
-          tt.Cy = xt[3][lane]; tt.Cn = xt[4][lane]; tt.Cl = xt[5][lane];
-          st |= xst[lane];
-          plant_post<false>(x, p, tt, xd);
-#pragma unroll
-          for (int k = 0; k < 12; ++k) x[k] += xd[k] * a.dt;   // env.py:126
-        } else {
-          actuators_dev(x, u, xt[6][lane], xt[7][lane], xd);
-#pragma unroll
-          for (int k = 12; k < 18; ++k) x[k] += xd[k] * a.dt;
-        }
-      }
-      if (tr && --until_store == 0) {
-        until_store = a.traj_every;
-        if (valid) {
-          if (wave == 0) {
-#pragma unroll
-            for (int k = 0; k < 12; ++k) __builtin_nontemporal_store(x[k], tr + k * a.ld);
-          } else {
-#pragma unroll
-            for (int k = 12; k < 18; ++k) __builtin_nontemporal_store(x[k], tr + k * a.ld);
-          }
-        }
-        tr += 18 * a.ld;
-      }
-    }
-    if (valid) {
-      bool finite = true;
-#pragma unroll
-      for (int k = 0; k < 18; ++k) if (k >= k0 && k < k1) finite = finite && isfinite(x[k]);
-      if (wave == 0) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) a.out[k * a.ld + b] = x[k];
-      } else {
-#pragma unroll
-        for (int k = 12; k < 18; ++k) a.out[k * a.ld + b] = x[k];
-      }
-      if (a.status) atomicOr(&a.status[b], st | (finite ? 0 : ST_NONFINITE));
-    }
-    __syncthreads();
-  }
-}
-
 // Four-wavefront rollout (latency regime, hifi): one workgroup = 64 aircraft on the four SIMDs of a CU; the state is
 // split by owner (every wave integrates and range-checks what it owns) and the table lookups -- the LDS-latency-bound
 // part of a step -- are spread over all four waves as four partial coefficient triples (aero_part<1..4>):
@@ -456,27 +337,14 @@ static Geometry geometry(long B, int fi) {
     else if ((g).block == 256) hipLaunchKernelGGL(KERN<256>, dim3((g).grid), dim3(256), 0, stream, args); \
     else hipLaunchKernelGGL(KERN<512>, dim3((g).grid), dim3(512), 0, stream, args);                       \
   } while (0)
-#ifndef F16_RT_FI
-#define F16_RT_FI 0
-#endif
-#ifndef F16_CT_HIFI
-#define F16_CT_HIFI 0
-#endif
-#ifndef F16_NO_2W
-#define F16_NO_2W 0
-#endif
-#ifndef F16_USE_2W
-#define F16_USE_2W 0
-#endif
 // same; the lofi model gets an instantiation with the fidelity fixed at compile time (3.94 vs 4.6 ms per 1000 steps at
 // B=4096).  For hifi the run-time-flag kernel measured FASTER than a compile-time one (4.59 vs 4.65 ms; 5.31 vs 4.85 G
 // steps/s at B=262144: the scheduler does worse on the merged basic block), so hifi keeps the run-time path.
 #define LAUNCH_BY_BLOCK_FI(KERN, g, stream, args)                                                              \
   do {                                                                                                         \
-    const int fi_ = F16_RT_FI ? 2 : (args).fi;                                                                  \
+    const int fi_ = (args).fi;                                                                                  \
     if ((g).block == 64) {                                                                                     \
       if (fi_ == 0) hipLaunchKernelGGL((KERN<64, 0>), dim3((g).grid), dim3(64), 0, stream, args);             \
-      else if (F16_CT_HIFI && fi_ == 1) hipLaunchKernelGGL((KERN<64, F16_CT_HIFI ? 1 : -1>), dim3((g).grid), dim3(64), 0, stream, args); \
       else hipLaunchKernelGGL((KERN<64, -1>), dim3((g).grid), dim3(64), 0, stream, args);                      \
     } else if ((g).block == 128) {                                                                             \
       if (fi_ == 0) hipLaunchKernelGGL((KERN<128, 0>), dim3((g).grid), dim3(128), 0, stream, args);           \
@@ -543,10 +411,9 @@ extern "C" int f16_rollout(f16_ctx *ctx, double *x, const double *u, double *tra
   a.B = B; a.ld = ld; a.nsteps = nsteps; a.traj_every = traj ? traj_every : nsteps + 1;
   a.dt = dt; a.xcg = xcg; a.fi = fi_flag; a.flags = flags;
   static const long max4w = [] { const char *e = getenv("F16_ROLLOUT_4W_MAXB"); return e ? atol(e) : 64L * 256; }();
-  if (fi_flag == 1 && B <= max4w && !F16_NO_2W) {
-    // latency regime: two wavefronts per 64 aircraft (lookups || trigonometry), one workgroup per CU
-    if (F16_USE_2W) hipLaunchKernelGGL(k_rollout_2w, dim3((unsigned)((B + 63) / 64)), dim3(128), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_rollout_4w, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a);
+  if (fi_flag == 1 && B <= max4w) {
+    // latency regime: four wavefronts per 64 aircraft, one workgroup per CU
+    hipLaunchKernelGGL(k_rollout_4w, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a);
     return hip_check(hipGetLastError(), "f16_rollout launch");
   }
   Geometry g = geometry(B, fi_flag);

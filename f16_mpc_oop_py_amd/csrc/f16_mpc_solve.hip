@@ -85,12 +85,6 @@ __device__ __attribute__((noinline)) bool sweep_inverse(double *Ms, double *cvec
   if (tid < FN + 8) cvec[FN + 8 + tid] = 0.0;
   __syncthreads();
   double *mrun = Ms + (row >= 0 ? row : 0) * SLD + j0;
-#ifdef F16_EXP_NOPIVOT
-  n = 0;
-#endif
-#ifdef F16_EXP_STAMP
-  unsigned long long t_work = 0, t_bar = 0, t0 = __builtin_amdgcn_s_memtime();
-#endif
   for (int k = 0; k < n; ++k) {
     const double *cv = cvec + (k & 1) * (FN + 8);
     double *cn = cvec + ((k + 1) & 1) * (FN + 8);
@@ -150,20 +144,8 @@ __device__ __attribute__((noinline)) bool sweep_inverse(double *Ms, double *cvec
         }
       }
     }
-#ifdef F16_EXP_STAMP
-    __builtin_amdgcn_s_waitcnt(0);
-    unsigned long long t1 = __builtin_amdgcn_s_memtime();
     __syncthreads();
-    unsigned long long t2 = __builtin_amdgcn_s_memtime();
-    t_work += t1 - t0; t_bar += t2 - t1; t0 = t2;
-#else
-    __syncthreads();
-#endif
   }
-#ifdef F16_EXP_STAMP
-  if (tid == 0) { cvec[0] = (double)t_work; cvec[1] = (double)t_bar; }
-  __syncthreads();
-#endif
   return ok;
 }
 

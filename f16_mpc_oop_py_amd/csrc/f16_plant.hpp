@@ -370,8 +370,7 @@ F16_DEV void aero_lofi(const double *__restrict__ LT, double alpha, double beta,
 }
 
 // ---- C/nlplant.c:23-457 in three pieces ------------------------------------------------------------------------
-// (the single-wave kernels run them back to back; k_rollout_2w runs aero_totals on one wavefront while a second one
-//  runs plant_pre, see f16_dynamics.hip)
+// (the single-wave kernels run them back to back; k_rollout_4w spreads them over four wavefronts, see f16_dynamics.hip)
 struct Totals { double Cx, Cz, Cm, Cy, Cn, Cl; };   // C*_tot of C/nlplant.c:333-377
 struct Pre {                                        // trigonometry, atmosphere, body velocities
   double sa, ca, sb, cb, st, ct, sphi, cphi;
