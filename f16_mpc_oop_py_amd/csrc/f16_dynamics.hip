@@ -17,6 +17,7 @@
 #include "../../include/f16_hip.h"
 #include "f16_ctx.h"
 #include "f16_plant.hpp"
+#include "f16_plant_quad.hpp"
 
 namespace f16 {
 
@@ -290,6 +291,227 @@ __global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
   }
 }
 
+// Quad rollout (B <= 4096, hifi): FOUR LANES per aircraft, 16 aircraft per workgroup, so the reference batch of 4096
+// fills all 256 CUs (the 4-wave kernel above occupies 64) and every role below runs sub-lane-parallel wherever the
+// arithmetic is uniform (f16_plant_quad.hpp): a step costs a CU far fewer wave-instructions.  Lane l = 4 a + s.
+//   wave 0  --        Cx, Cz, Cm totals on sub-lanes 0,1,2 (3-D / 2-D / 1-D longitudinal tables)
+//   wave 1  x[9..11]  Cy, Cn, Cl totals on sub-lanes 0,1,2                                   | moment equations, Euler
+//   wave 2  x[0..8]   sin/cos of phi, theta, psi, alpha on sub-lanes 0..3, beta; kinematic + navigation equations
+//                                                                                            | force equations, Euler
+//   wave 3  x[12..17] atmosphere; the four actuators on sub-lanes 0..3; flap model (Euler)
+// Owned states are replicated over the sub-lanes of their wave; two barriers per step as in k_rollout_4w.
+__global__ __launch_bounds__(256) void k_rollout_q(DynArgs a) {
+  __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
+  __shared__ double xs[17][16], xt[8][16];                 // published state; Cx Cz Cm Cy Cn Cl qbar ps
+  __shared__ int xenv[3][16], xst[2][16];
+  {
+    const double2 *src = reinterpret_cast<const double2 *>(a.tab);
+    double2 *dst = reinterpret_cast<double2 *>(tab);
+    for (int i = threadIdx.x; i < TABLE_IMAGE_DOUBLES / 2; i += 256) dst[i] = src[i];
+    __syncthreads();
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, ac = lane >> 2, s = lane & 3;
+  const bool envchk = !(a.flags & FLAG_NO_ENVELOPE);
+  for (long b0 = (long)blockIdx.x * 16; b0 < a.B; b0 += (long)gridDim.x * 16) {
+    const bool valid = b0 + ac < a.B;
+    const long b = valid ? b0 + ac : a.B - 1;              // ragged tail: shadow the last aircraft, never stored
+    double x[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) x[k] = a.out[k * a.ld + b];
+    const double ucmd = a.u[s * a.ld + b];                 // wave 3: sub-lane s drives actuator s
+    double xact = s == 0 ? x[12] : (s == 1 ? x[13] : (s == 2 ? x[14] : x[15]));   // wave 3: its actuator state
+    int st = a.status ? a.status[b] : 0;
+    double *tr = a.traj ? a.traj + b : nullptr;            // next sample to be written by THIS wave
+    int until_store = a.traj_every;
+#ifdef F16_EXP_STAMPQ
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, t0 = __builtin_amdgcn_s_memtime();
+#define QSTAMP(acc) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; }
+#else
+#define QSTAMP(acc)
+#endif
+    for (int t = 0; t < a.nsteps; ++t) {
+      // ---- step start: envelope test on the owned states (env.py:117-124), publish them
+      if (wave == 2) {
+        xenv[0][ac] = envchk && (x[2] < 0 || x[2] > 100000 || x[6] < 0 || x[6] > 900 || x[7] < -20. || x[7] > 90 ||
+                                 x[8] < -30. || x[8] > 30);
+        if (s == 0) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) xs[k][ac] = x[k];
+        }
+      } else if (wave == 1) {
+        xenv[1][ac] = envchk && (x[9] < -300 || x[9] > 300 || x[10] < -100 || x[10] > 100 || x[11] < -50 || x[11] > 50);
+        if (s < 3) xs[9 + s][ac] = s == 0 ? x[9] : (s == 1 ? x[10] : x[11]);
+      } else if (wave == 3) {
+        const double lim = s == 1 ? 25.0 : (s == 2 ? 21.5 : 30.0);
+        const bool bad = s == 0 ? (xact < 1000 || xact > 19000) : (xact < -lim || xact > lim);
+        const bool badl = x[16] < 0. || x[16] > 25;
+        // any sub-lane out of range flags the aircraft: combine over the quad through LDS writes of `true` only
+        if (s == 0) xenv[2][ac] = 0;
+        xs[12 + s][ac] = xact;
+        if (s == 0) xs[16][ac] = x[16];
+        __builtin_amdgcn_wave_barrier();
+        if (envchk && (bad || badl)) xenv[2][ac] = 1;
+      }
+      QSTAMP(tD)
+      __syncthreads();
+      QSTAMP(tA)
+      if (xenv[0][ac] | xenv[1][ac] | xenv[2][ac]) st |= ST_ENVELOPE;
+      const bool live = !(st & ST_ENVELOPE);
+      double xa[17];
+#pragma unroll
+      for (int k = 0; k < 17; ++k) xa[k] = xs[k][ac];
+      // first-half results wave 2 keeps in registers for the second half
+      double xd[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      double U = 0, V = 0, W = 0, s_t = 0, c_t = 0, s_phi = 0, c_phi = 0, cb = 0, vtc = 0, r1 = 0, r2 = 0, r3 = 0;
+      if (wave == 0) {
+        int sa_ = 0;
+        const double tot = quad_long((const double *)tab, xa, s, a.xcg, sa_);
+        if (s < 3) xt[s][ac] = tot;
+        xst[0][ac] = sa_;
+      } else if (wave == 1) {
+        int sa_ = 0;
+        const double tot = quad_lat((const double *)tab, xa, s, a.xcg, a.flags, sa_);
+        if (s < 3) xt[3 + s][ac] = tot;
+        xst[1][ac] = sa_;
+      } else if (wave == 2) {
+        // sin / cos of phi, theta, psi, alpha: one angle per sub-lane, then shared across the quad
+        const double ang = s == 0 ? xa[3] : (s == 1 ? xa[4] : (s == 2 ? xa[5] : xa[7]));
+        double sn, cs, sb;
+        F16_SINCOS(ang, &sn, &cs);
+        F16_SINCOS(xa[8], &sb, &cb);
+        s_phi = quad_bcast<0>(sn); c_phi = quad_bcast<0>(cs);
+        s_t = quad_bcast<1>(sn); c_t = quad_bcast<1>(cs);
+        const double s_psi = quad_bcast<2>(sn), c_psi = quad_bcast<2>(cs);
+        const double sal = quad_bcast<3>(sn), cal = quad_bcast<3>(cs);
+        vtc = xa[6];
+        if (vtc <= 0.01) vtc = 0.01;
+        U = vtc * cal * cb; V = vtc * sb; W = vtc * sal * cb;                       // C/nlplant.c:148-150
+        const double P = xa[9], Q = xa[10], R = xa[11];
+#ifdef F16_FAST_DIV
+        const double rct = f16_rcp(c_t);
+        const double tt = s_t * rct;
+#elif defined(F16_FAST_TAN)
+        const double rct = 0.0, tt = s_t / c_t;
+#else
+        const double rct = 0.0, tt = tan(xa[4]);
+#endif
+        xd[0] = U * (c_t * c_psi) + V * (s_phi * c_psi * s_t - c_phi * s_psi) + W * (c_phi * s_t * c_psi + s_phi * s_psi);
+        xd[1] = U * (c_t * s_psi) + V * (s_phi * s_psi * s_t + c_phi * c_psi) + W * (c_phi * s_t * s_psi - s_phi * c_psi);
+        xd[2] = U * s_t - V * (s_phi * c_t) - W * (c_phi * c_t);
+        xd[3] = P + tt * (Q * s_phi + R * c_phi);                                     // :169-176
+        xd[4] = Q * c_phi - R * s_phi;
+#ifdef F16_FAST_DIV
+        xd[5] = (Q * s_phi + R * c_phi) * rct;
+        r1 = f16_rcp(vtc); r2 = f16_rcp(U * U + W * W); r3 = f16_rcp(vtc * vtc * cb);   // divisors of :393-405, hoisted
+#else
+        xd[5] = (Q * s_phi + R * c_phi) / c_t;
+        (void)rct;
+#endif
+      } else {
+        double vt = xa[6];
+        if (vt <= 0.01) vt = 0.01;
+        double mach, qbar, ps;
+        atmos_dev(xa[2], vt, mach, qbar, ps);
+        if (s == 0) { xt[6][ac] = qbar; xt[7][ac] = ps; }
+        if (live) {
+          // utils.py:308-330: thrust on sub-lane 0, elevator / aileron / rudder on 1..3 (same form, own limits)
+          const double lim = s == 1 ? 25.0 : (s == 2 ? 21.5 : 30.0), rate = s == 1 ? 60.0 : (s == 2 ? 80.0 : 120.0);
+          const double dth = clipd(clipd(ucmd, 1000, 19000) - xact, -10000, 10000);
+          const double dsf = clipd(20.2 * (clipd(ucmd, -lim, lim) - xact), -rate, rate);
+          double lf1_dot, lf2_dot;
+          upd_lef_dev(xa[2], xa[6], xa[7], x[17], x[16], qbar, ps, lf1_dot, lf2_dot);
+          xact += (s == 0 ? dth : dsf) * a.dt;             // env.py:126 on the actuator / flap states
+          x[16] += lf2_dot * a.dt;
+          x[17] += lf1_dot * a.dt;
+        }
+        if (tr && --until_store == 0) {
+          until_store = a.traj_every;
+          if (valid) {
+            __builtin_nontemporal_store(xact, tr + (12 + s) * a.ld);
+            if (s < 2) __builtin_nontemporal_store(s == 0 ? x[16] : x[17], tr + (16 + s) * a.ld);
+          }
+          tr += 18 * a.ld;
+        }
+      }
+      QSTAMP(tB)
+      __syncthreads();
+      QSTAMP(tC)
+      // ---- second half: force equations on wave 2 || moment equations on wave 1
+      if (wave == 2) {
+        if (live) {
+          st |= xst[0][ac] | xst[1][ac];
+          const double Cx = xt[0][ac], Cz = xt[1][ac], Cy = xt[3][ac], qbar = xt[6][ac];
+          const double g = 32.17, m = 636.94, S = 300.0;
+          const double P = xa[9], Q = xa[10], R = xa[11], Thr = xa[12];
+          const double Udot = R * V - Q * W - g * s_t + F16_DIVC(qbar * S * Cx, m) + F16_DIVC(Thr, m);     // :383-387
+          const double Vdot = P * W - R * U + g * c_t * s_phi + F16_DIVC(qbar * S * Cy, m);
+          const double Wdot = Q * U - P * V + g * c_t * c_phi + F16_DIVC(qbar * S * Cz, m);
+#ifdef F16_FAST_DIV
+          xd[6] = (U * Udot + V * Vdot + W * Wdot) * r1;                                                 // :393-405
+          xd[7] = (U * Wdot - W * Udot) * r2;
+          xd[8] = (Vdot * vtc - V * xd[6]) * r3;
+#else
+          xd[6] = (U * Udot + V * Vdot + W * Wdot) / vtc;
+          xd[7] = (U * Wdot - W * Udot) / (U * U + W * W);
+          xd[8] = (Vdot * vtc - V * xd[6]) / (vtc * vtc * cb);
+#endif
+#pragma unroll
+          for (int k = 0; k < 9; ++k) x[k] += xd[k] * a.dt;   // env.py:126
+        }
+        if (tr && --until_store == 0) {
+          until_store = a.traj_every;
+          if (valid && s < 3) {                               // sub-lane s stores x[s], x[3+s], x[6+s]
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              const double v = s == 0 ? x[3 * j] : (s == 1 ? x[3 * j + 1] : x[3 * j + 2]);
+              __builtin_nontemporal_store(v, tr + (3 * j + s) * a.ld);
+            }
+          }
+          tr += 18 * a.ld;
+        }
+      } else if (wave == 1) {
+        if (live) {
+          double xm[18];
+          plant_moments(x[9], x[10], x[11], xt[6][ac], xt[5][ac], xt[2][ac], xt[4][ac], xm);
+#pragma unroll
+          for (int k = 9; k < 12; ++k) x[k] += xm[k] * a.dt;
+        }
+        if (tr && --until_store == 0) {
+          until_store = a.traj_every;
+          if (valid && s < 3) __builtin_nontemporal_store(s == 0 ? x[9] : (s == 1 ? x[10] : x[11]), tr + (9 + s) * a.ld);
+          tr += 18 * a.ld;
+        }
+      }
+    }
+#ifdef F16_EXP_STAMPQ
+    if (lane == 0 && blockIdx.x == 0 && a.traj) {   // diagnostic build: cycles per segment, per wave, into trajectory row 2
+      double *d = a.traj + 18 * a.ld * 2 + wave * 4;
+      d[0] = (double)tD; d[1] = (double)tA; d[2] = (double)tB; d[3] = (double)tC;
+    }
+#endif
+    // ---- write the final state back (owners), flags
+    if (valid) {
+      if (wave == 2 && s == 0) {
+        bool finite = true;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { finite = finite && isfinite(x[k]); a.out[k * a.ld + b] = x[k]; }
+        if (a.status) atomicOr(&a.status[b], st | (finite ? 0 : ST_NONFINITE));
+      } else if (wave == 1 && s == 0) {
+        bool finite = true;
+#pragma unroll
+        for (int k = 9; k < 12; ++k) { finite = finite && isfinite(x[k]); a.out[k * a.ld + b] = x[k]; }
+        if (a.status) atomicOr(&a.status[b], st | (finite ? 0 : ST_NONFINITE));
+      } else if (wave == 3) {
+        a.out[(12 + s) * a.ld + b] = xact;
+        bool finite = isfinite(xact);
+        if (s < 2) { const double v = s == 0 ? x[16] : x[17]; finite = finite && isfinite(v); a.out[(16 + s) * a.ld + b] = v; }
+        if (a.status) atomicOr(&a.status[b], st | (finite ? 0 : ST_NONFINITE));
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_xdot_na(DynArgs a) {
   __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
@@ -411,6 +633,12 @@ extern "C" int f16_rollout(f16_ctx *ctx, double *x, const double *u, double *tra
   a.B = B; a.ld = ld; a.nsteps = nsteps; a.traj_every = traj ? traj_every : nsteps + 1;
   a.dt = dt; a.xcg = xcg; a.fi = fi_flag; a.flags = flags;
   static const long max4w = [] { const char *e = getenv("F16_ROLLOUT_4W_MAXB"); return e ? atol(e) : 64L * 256; }();
+  static const long maxq = [] { const char *e = getenv("F16_ROLLOUT_QUAD_MAXB"); return e ? atol(e) : 16L * 256; }();
+  if (fi_flag == 1 && B <= maxq) {
+    // fewer aircraft than 16 per CU: four lanes per aircraft, one 16-aircraft workgroup per CU
+    hipLaunchKernelGGL(k_rollout_q, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a);
+    return hip_check(hipGetLastError(), "f16_rollout launch");
+  }
   if (fi_flag == 1 && B <= max4w) {
     // latency regime: four wavefronts per 64 aircraft, one workgroup per CU
     hipLaunchKernelGGL(k_rollout_4w, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a);

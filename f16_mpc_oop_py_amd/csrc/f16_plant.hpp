@@ -38,6 +38,19 @@ constexpr unsigned FLAG_FIX_CLR = 1u, FLAG_NO_ENVELOPE = 2u;
 #define F16_DIVC(x, c) ((x) / (c))
 #endif
 
+// 1/x for a normal, finite x.  Strict build: IEEE division.  Default build: v_rcp_f64 + two Newton steps (<= 1 ulp),
+// 5 instructions instead of the ~15 of the division sequence.
+__device__ __forceinline__ double f16_rcp(double x) {
+#ifdef F16_FAST_DIV
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+
 struct Axis {
   int j;       // lower node of the bracketing cell, 0 .. n-2
   double l;    // lambda = (v - X[j]) / (X[j+1] - X[j])     (mexndinterp.c:196)

@@ -1,0 +1,204 @@
+// f16_plant_quad.hpp -- the hifi aerodynamic build-up with FOUR lanes per aircraft (used by k_rollout_q).
+//
+// At the reference's batch of 4096 there are fewer aircraft than SIMD lanes on the chip, so a rollout step is bound by
+// how many wave-instructions ONE aircraft group needs, not by throughput.  Here a quad of lanes (l = 4 a + s) shares an
+// aircraft and sub-lane s evaluates ONE member of each coefficient family -- the node-major table image keeps the
+// members of a family next to each other, so the sub-lanes run the same instructions on payload offset s:
+//     longitudinal wave   s = 0,1,2  ->  Cx, Cz, Cm      (C/nlplant.c:333-347)
+//     lateral wave        s = 0,1,2  ->  Cy, Cn, Cl      (C/nlplant.c:353-377)
+// (sub-lane 3 shadows sub-lane 2).  Same terms as aero_hifi() + aero_totals(), hifi_F16_AeroData.c:1871-1934; the
+// cg-offset couplings (Cm needs Cz_tot, Cn needs Cy_tot) cross the quad with one DPP broadcast.
+#pragma once
+#include "f16_plant.hpp"
+
+namespace f16 {
+
+// value of sub-lane J of this lane's quad
+template <int J>
+F16_DEV double quad_bcast(double v) {
+  constexpr int ctrl = J | (J << 2) | (J << 4) | (J << 6);      // quad_perm:[J,J,J,J]
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// ---- lookups in three scheduling phases.  With one wavefront per SIMD nothing hides an LDS round trip, and left to
+// itself the compiler emits the lookups in source order (read four corners, wait, interpolate, next table: ~14 dependent
+// round trips per role).  Here: (1) ALL breakpoint reads, (2) cell indices -> ALL table-corner reads, with the
+// lambda divisions issued behind them, (3) the interpolation arithmetic.  Two round trips per role.
+struct BrRaw { double lo, hi, xm, xg, xg1, xp; int g; };
+template <typename TP>
+F16_DEV BrRaw br_load(TP X, int n, int guess) {                 // the six reads of bracket()
+  BrRaw r;
+  r.g = min(max(guess, 0), n - 2);
+  r.lo = X[0]; r.hi = X[n - 1];
+  r.xm = X[max(r.g - 1, 0)]; r.xg = X[r.g]; r.xg1 = X[r.g + 1]; r.xp = X[min(r.g + 2, n - 1)];
+  return r;
+}
+struct BrCell { int j; double v, x0, x1; };
+F16_DEV BrCell br_cell(const BrRaw &r, int n, double v, bool &off) {   // bracket(): clamp, cell fix-up
+  off = !(v >= r.lo && v <= r.hi);
+  v = fmin(fmax(v, r.lo), r.hi);
+  const bool down = r.g > 0 && v < r.xg, up = r.g < n - 2 && v >= r.xg1;
+  BrCell c;
+  c.j = r.g - (down ? 1 : 0) + (up ? 1 : 0);
+  c.v = v;
+  c.x0 = down ? r.xm : (up ? r.xg1 : r.xg);
+  c.x1 = down ? r.xg : (up ? r.xp : r.xg1);
+  return c;
+}
+F16_DEV Axis br_axis(const BrCell &c) {                          // lambda = (v - X[j]) / (X[j+1] - X[j]), mexndinterp.c:196
+  Axis a;
+  a.j = c.j;
+#ifdef F16_FAST_DIV
+  a.l = (c.v - c.x0) * f16_rcp(c.x1 - c.x0);
+#else
+  a.l = (c.v - c.x0) / (c.x1 - c.x0);
+#endif
+  a.m = 1 - a.l;
+  return a;
+}
+struct Q4 { double f00, f10, f01, f11; };                        // corners (a,b), (a+1,b), (a,b+1), (a+1,b+1)
+template <typename TP>
+F16_DEV Q4 ld4(TP p, int sa, int sb) { Q4 c; c.f00 = p[0]; c.f10 = p[sa]; c.f01 = p[sb]; c.f11 = p[sb + sa]; return c; }
+F16_DEV double bil4(const Q4 &c, const Axis &a, const Axis &b) {   // alpha collapsed first, then beta (mexndinterp.c:178-209)
+  return lerp(lerp(c.f00, c.f10, a), lerp(c.f01, c.f11, a), b);
+}
+#define F16_PHASE() __builtin_amdgcn_sched_barrier(0)
+
+F16_DEV int alpha_guess(double alpha) { return (int)((fmin(fmax(alpha, -20.0), 90.0) + 20.0) * 0.2); }
+F16_DEV int beta_guess(double beta) {
+  const double bc = fmin(fmax(beta, -30.0), 30.0);
+  return bc < -10.0 ? (int)((bc + 30.0) * 0.2) : (bc < 10.0 ? 4 + (int)((bc + 10.0) * 0.5) : 14 + (int)((bc - 10.0) * 0.2));
+}
+
+struct QuadIn {            // what both aerodynamic waves derive from the published state (C/nlplant.c:84-125)
+  double alpha, beta, el, dail, drud, dlef, P, Q, R, kq, kb;
+};
+F16_DEV QuadIn quad_inputs(const double *xu) {
+  const double B = 30.0, cbar = 11.32, r2d = 180.0 / 3.141592653589793;
+  QuadIn in;
+  double vt = xu[6];
+  if (vt <= 0.01) vt = 0.01;
+  in.alpha = xu[7] * r2d; in.beta = xu[8] * r2d;
+  in.P = xu[9]; in.Q = xu[10]; in.R = xu[11];
+  in.el = xu[13];
+  in.dail = F16_DIVC(xu[14], 21.5);
+  in.drud = F16_DIVC(xu[15], 30.0);
+  in.dlef = 1 - F16_DIVC(xu[16], 25.0);
+#ifdef F16_FAST_DIV
+  const double r2vt = f16_rcp(2 * vt);
+  in.kq = cbar * r2vt; in.kb = B * r2vt;
+#else
+  in.kq = cbar / (2 * vt); in.kb = B / (2 * vt);
+#endif
+  return in;
+}
+
+// Cx_tot / Cz_tot / Cm_tot on sub-lanes 0 / 1 / 2 (C/nlplant.c:333-347, hifi_C, hifi_damping, hifi_C_lef,
+// hifi_damping_lef, hifi_other_coeffs).  dZdQ uses delta_Cz_lef exactly as the reference does (:339).
+template <typename TP>
+F16_DEV double quad_long(TP T, const double *xu, int s, double xcg, int &status) {
+  const QuadIn in = quad_inputs(xu);
+  const int k = s < 2 ? s : 2;
+  // (1) breakpoints
+  const BrRaw ra = br_load(T + OFF_BP_A1, N_A1, alpha_guess(in.alpha));
+  const BrRaw rb = br_load(T + OFF_BP_B1, N_B1, beta_guess(in.beta));
+  const BrRaw rd = br_load(T + OFF_BP_D1, N_D1, (in.el >= -10.0) + (in.el >= 0.0) + (in.el >= 10.0));
+  const double a45 = T[OFF_BP_A1 + N_A2 - 1];
+  F16_PHASE();
+  bool offa, offb, offd;
+  const BrCell ca = br_cell(ra, N_A1, in.alpha, offa), cb = br_cell(rb, N_B1, in.beta, offb), cd = br_cell(rd, N_D1, in.el, offd);
+  if (offa) status |= ST_ALPHA1 | ST_ALPHA2;
+  if (offb) status |= ST_BETA;
+  if (offd) status |= ST_EL;
+  const bool hi_a = ca.j > N_A2 - 2;                             // ALPHA2 ends at 45 deg: last cell, lambda = 1
+  if (hi_a && in.alpha > a45) status |= ST_ALPHA2;
+  const int j2 = hi_a ? N_A2 - 2 : ca.j;
+  const int n1 = cb.j * N_A1 + ca.j, n2 = cb.j * N_A2 + j2;
+  // (2) every table corner this role needs
+  constexpr int SA = S_G3A, SB = S_G3A * N_A1, SD = S_G3A * N_A1 * N_B1;
+  TP p = T + OFF_G3A + n1 * SA + k;
+  const Q4 qlo = ld4(p + cd.j * SD, SA, SB), qhi = ld4(p + (cd.j + 1) * SD, SA, SB), q0 = ld4(p + D1_ZERO_NODE * SD, SA, SB);
+  const Q4 qlef = ld4(T + OFF_G2B + n2 * S_G2B + k, S_G2B, S_G2B * N_A2);
+  TP g = T + OFF_G1A + ca.j * S_G1A, h = T + OFF_G1B + j2 * S_G1B;
+  const double g0 = g[3 * k], g1 = g[S_G1A + 3 * k], m0 = g[11], m1 = g[S_G1A + 11];
+  const double h0 = h[3 * k], h1 = h[S_G1B + 3 * k];
+  const double e0 = T[OFF_ETA + cd.j], e1 = T[OFF_ETA + cd.j + 1];
+  F16_PHASE();
+  // (3) arithmetic
+  const Axis a1 = br_axis(ca), b = br_axis(cb), d1 = br_axis(cd);
+  Axis a2 = a1;
+  if (hi_a) { a2.j = N_A2 - 2; a2.l = 1.0; a2.m = 0.0; }
+  const double Cf = lerp(bil4(qlo, a1, b), bil4(qhi, a1, b), d1);
+  const double C0 = bil4(q0, a1, b);
+  const double dC = bil4(qlef, a2, b) - C0;                       // hifi_C_lef :1892-1899
+  const double Cq = lerp(g0, g1, a1), dCm = lerp(m0, m1, a1), dq = lerp(h0, h1, a2), eta = lerp(e0, e1, d1);
+  const double dql = k == 1 ? dC : dq;                            // reference quirk: dZdQ uses delta_Cz_lef
+  double tot = Cf * (k == 2 ? eta : 1.0) + dC * in.dlef + in.kq * (Cq + dql * in.dlef) * in.Q + (k == 2 ? dCm : 0.0);
+  const double Cz_tot = quad_bcast<1>(tot);
+  if (k == 2) tot += Cz_tot * (0.35 - xcg);                       // :347
+  return tot;
+}
+
+// Cy_tot / Cn_tot / Cl_tot on sub-lanes 0 / 1 / 2 (C/nlplant.c:353-377, hifi_C, hifi_damping, hifi_C_lef,
+// hifi_damping_lef, hifi_rudder, hifi_ailerons, hifi_other_coeffs).
+template <typename TP>
+F16_DEV double quad_lat(TP T, const double *xu, int s, double xcg, unsigned flags, int &status) {
+  const double B = 30.0, cbar = 11.32;
+  const QuadIn in = quad_inputs(xu);
+  const int k = s < 2 ? s : 2;
+  // (1) breakpoints
+  const BrRaw ra = br_load(T + OFF_BP_A1, N_A1, alpha_guess(in.alpha));
+  const BrRaw rb = br_load(T + OFF_BP_B1, N_B1, beta_guess(in.beta));
+  const BrRaw rd = br_load(T + OFF_BP_D2, N_D2, (int)(in.el >= 0.0));
+  const double a45 = T[OFF_BP_A1 + N_A2 - 1];
+  F16_PHASE();
+  bool offa, offb, offd;
+  const BrCell ca = br_cell(ra, N_A1, in.alpha, offa), cb = br_cell(rb, N_B1, in.beta, offb), cd = br_cell(rd, N_D2, in.el, offd);
+  if (offa) status |= ST_ALPHA1 | ST_ALPHA2;
+  if (offb) status |= ST_BETA;
+  if (offd) status |= ST_EL;
+  const bool hi_a = ca.j > N_A2 - 2;
+  if (hi_a && in.alpha > a45) status |= ST_ALPHA2;
+  const int j2 = hi_a ? N_A2 - 2 : ca.j;
+  const int n1 = cb.j * N_A1 + ca.j, n2 = cb.j * N_A2 + j2;
+  // (2) every table corner this role needs
+  constexpr int SA3 = S_G3B, SB3 = S_G3B * N_A1, SD3 = S_G3B * N_A1 * N_B1;
+  TP p3 = T + OFF_G3B + n1 * SA3 + (k > 0 ? k - 1 : 0);          // sub-lane 0 shadows Cn; its base is Cy
+  const Q4 qlo = ld4(p3 + cd.j * SD3, SA3, SB3), qhi = ld4(p3 + (cd.j + 1) * SD3, SA3, SB3), q0 = ld4(p3 + D2_ZERO_NODE * SD3, SA3, SB3);
+  constexpr int SA2 = S_G2A, SB2 = S_G2A * N_A1;
+  TP pa = T + OFF_G2A + n1 * SA2;
+  const Q4 qy = ld4(pa, SA2, SB2), qr = ld4(pa + 1 + k, SA2, SB2), qa = ld4(pa + 4 + k, SA2, SB2);
+  constexpr int SAB = S_G2B, SBB = S_G2B * N_A2;
+  TP pb = T + OFF_G2B + n2 * SAB;
+  const Q4 ql = ld4(pb + 3 + k, SAB, SBB), qal = ld4(pb + 6 + k, SAB, SBB);
+  const int ir = k == 0 ? 1 : (k == 1 ? 7 : 4), ib = k == 1 ? 9 : 10;     // CYr CYp | CNr CNp | CLr CLp; dCNbeta, dCLbeta
+  TP g = T + OFF_G1A + ca.j * S_G1A, h = T + OFF_G1B + j2 * S_G1B;
+  const double r0 = g[ir], r1 = g[S_G1A + ir], p0 = g[ir + 1], p1 = g[S_G1A + ir + 1], b0 = g[ib], b1 = g[S_G1A + ib];
+  const double hr0 = h[ir], hr1 = h[S_G1B + ir], hp0 = h[ir + 1], hp1 = h[S_G1B + ir + 1];
+  F16_PHASE();
+  // (3) arithmetic
+  const Axis a1 = br_axis(ca), b = br_axis(cb), d2 = br_axis(cd);
+  Axis a2 = a1;
+  if (hi_a) { a2.j = N_A2 - 2; a2.l = 1.0; a2.m = 0.0; }
+  const double C3 = lerp(bil4(qlo, a1, b), bil4(qhi, a1, b), d2), C30 = bil4(q0, a1, b);
+  const double Cy = bil4(qy, a1, b), Cr30 = bil4(qr, a1, b), Ca20 = bil4(qa, a1, b);
+  const double Clef = bil4(ql, a2, b), Ca20lef = bil4(qal, a2, b);
+  const double base = k == 0 ? Cy : C3, base0 = k == 0 ? Cy : C30;
+  double Cr = lerp(r0, r1, a1);
+  if (k == 2 && !(flags & FLAG_FIX_CLR)) Cr = 0.0;               // reference defect: _CLr is never loaded
+  const double Cp = lerp(p0, p1, a1), Cb = lerp(b0, b1, a1);
+  const double dCr = lerp(hr0, hr1, a2), dCp = lerp(hp0, hp1, a2);
+  const double dlefC = Clef - base0;                             // hifi_C_lef
+  const double dr30 = Cr30 - base0;                              // hifi_rudder
+  const double da20 = Ca20 - base0, da20lef = Ca20lef - Clef - da20;   // hifi_ailerons
+  double tot = base + dlefC * in.dlef + (da20 + da20lef * in.dlef) * in.dail + dr30 * in.drud +
+               in.kb * (Cr + dCr * in.dlef) * in.R + in.kb * (Cp + dCp * in.dlef) * in.P + (k == 0 ? 0.0 : Cb * in.beta);
+  const double Cy_tot = quad_bcast<0>(tot);
+  if (k == 1) tot -= Cy_tot * (0.35 - xcg) * (cbar / B);         // :367
+  return tot;
+}
+
+}  // namespace f16
