@@ -100,10 +100,10 @@ def main():
         "config": {"workload": f"BASELINE config 2: open-loop {T}-step rollout, B={B}/GPU, hifi, xcg=0.25, "
                                f"trajectory [T,18,B] stored every step", "batch_per_gpu": B, "euler_steps": T,
                    "parallelism": f"batch-sharded x{world}, no collective in the timed region"},
-        "roofline": {"bound": "hbm", "kernel": "k_rollout_4w" if B <= 16384 else "k_rollout", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_rollout_q" if B <= 4096 else ("k_rollout_4w" if B <= 16384 else "k_rollout"), "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel_ms": kern_ms, "bytes_per_launch": B * T * BYTES_PER_STORED_STEP,
-                     "note": "B=4096: 64 workgroups x 4 wavefronts on 64 of 256 CUs; bound by fp64 dependent-issue + LDS lookup latency, not HBM (DESIGN.md 4)"},
+                     "note": "B=4096: 256 workgroups of 16 aircraft (four lanes per aircraft, four role wavefronts), one per CU; bound by the per-step dependency chain (lookup round trips + fp64 issue), not HBM (DESIGN.md 4)"},
     }
 
     out["roofline"]["traffic"] = recorded_traffic(B, T)

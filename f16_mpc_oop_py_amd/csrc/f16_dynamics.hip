@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
 // Owned states are replicated over the sub-lanes of their wave; two barriers per step as in k_rollout_4w.
 __global__ __launch_bounds__(256) void k_rollout_q(DynArgs a) {
   __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
-  __shared__ double xs[17][16], xt[8][16];                 // published state; Cx Cz Cm Cy Cn Cl qbar ps
+  __shared__ double xs[18][16], xt[11][16];                // published state; Cx Cz Cm | Cy Cn Cl static | qbar ps | Cy Cn Cl damping
   __shared__ int xenv[3][16], xst[2][16];
   {
     const double2 *src = reinterpret_cast<const double2 *>(a.tab);
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void k_rollout_q(DynArgs a) {
     const double ucmd = a.u[s * a.ld + b];                 // wave 3: sub-lane s drives actuator s
     double xact = s == 0 ? x[12] : (s == 1 ? x[13] : (s == 2 ? x[14] : x[15]));   // wave 3: its actuator state
     int st = a.status ? a.status[b] : 0;
-    double *tr = a.traj ? a.traj + b : nullptr;            // next sample to be written by THIS wave
+    double *tr = a.traj ? a.traj + b : nullptr;            // next sample (written by wave 2 from the published state)
     int until_store = a.traj_every;
 #ifdef F16_EXP_STAMPQ
     unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, t0 = __builtin_amdgcn_s_memtime();
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void k_rollout_q(DynArgs a) {
 #else
 #define QSTAMP(acc)
 #endif
-    for (int t = 0; t < a.nsteps; ++t) {
+    for (int t = 0; t <= a.nsteps; ++t) {                  // the extra trip only publishes + stores the final sample
       // ---- step start: envelope test on the owned states (env.py:117-124), publish them
       if (wave == 2) {
         xenv[0][ac] = envchk && (x[2] < 0 || x[2] > 100000 || x[6] < 0 || x[6] > 900 || x[7] < -20. || x[7] > 90 ||
@@ -348,13 +348,27 @@ __global__ __launch_bounds__(256) void k_rollout_q(DynArgs a) {
         // any sub-lane out of range flags the aircraft: combine over the quad through LDS writes of `true` only
         if (s == 0) xenv[2][ac] = 0;
         xs[12 + s][ac] = xact;
-        if (s == 0) xs[16][ac] = x[16];
+        if (s < 2) xs[16 + s][ac] = s == 0 ? x[16] : x[17];
         __builtin_amdgcn_wave_barrier();
         if (envchk && (bad || badl)) xenv[2][ac] = 1;
       }
       QSTAMP(tD)
       __syncthreads();
       QSTAMP(tA)
+      // trajectory sample of the step that just finished: all 18 states straight from the published copy, by the wave
+      // with the most slack in the first half (sub-lane s stores states s, s+4, s+8, ...)
+      if (wave == 2 && tr && t > 0 && --until_store == 0) {
+        until_store = a.traj_every;
+        if (valid) {
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            const int kk = s + 4 * j;
+            if (kk < 18) __builtin_nontemporal_store(xs[kk][ac], tr + kk * a.ld);
+          }
+        }
+        tr += 18 * a.ld;
+      }
+      if (t == a.nsteps) break;
       if (xenv[0][ac] | xenv[1][ac] | xenv[2][ac]) st |= ST_ENVELOPE;
       const bool live = !(st & ST_ENVELOPE);
       double xa[17];
@@ -365,12 +379,13 @@ __global__ __launch_bounds__(256) void k_rollout_q(DynArgs a) {
       double U = 0, V = 0, W = 0, s_t = 0, c_t = 0, s_phi = 0, c_phi = 0, cb = 0, vtc = 0, r1 = 0, r2 = 0, r3 = 0;
       if (wave == 0) {
         int sa_ = 0;
-        const double tot = quad_long((const double *)tab, xa, s, a.xcg, sa_);
-        if (s < 3) xt[s][ac] = tot;
+        double latd;
+        const double tot = quad_long((const double *)tab, xa, s, a.xcg, a.flags, latd, sa_);
+        if (s < 3) { xt[s][ac] = tot; xt[8 + s][ac] = latd; }
         xst[0][ac] = sa_;
       } else if (wave == 1) {
         int sa_ = 0;
-        const double tot = quad_lat((const double *)tab, xa, s, a.xcg, a.flags, sa_);
+        const double tot = quad_lat((const double *)tab, xa, s, sa_);
         if (s < 3) xt[3 + s][ac] = tot;
         xst[1][ac] = sa_;
       } else if (wave == 2) {
@@ -424,14 +439,6 @@ __global__ __launch_bounds__(256) void k_rollout_q(DynArgs a) {
           x[16] += lf2_dot * a.dt;
           x[17] += lf1_dot * a.dt;
         }
-        if (tr && --until_store == 0) {
-          until_store = a.traj_every;
-          if (valid) {
-            __builtin_nontemporal_store(xact, tr + (12 + s) * a.ld);
-            if (s < 2) __builtin_nontemporal_store(s == 0 ? x[16] : x[17], tr + (16 + s) * a.ld);
-          }
-          tr += 18 * a.ld;
-        }
       }
       QSTAMP(tB)
       __syncthreads();
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(256) void k_rollout_q(DynArgs a) {
       if (wave == 2) {
         if (live) {
           st |= xst[0][ac] | xst[1][ac];
-          const double Cx = xt[0][ac], Cz = xt[1][ac], Cy = xt[3][ac], qbar = xt[6][ac];
+          const double Cx = xt[0][ac], Cz = xt[1][ac], Cy = xt[3][ac] + xt[8][ac], qbar = xt[6][ac];
           const double g = 32.17, m = 636.94, S = 300.0;
           const double P = xa[9], Q = xa[10], R = xa[11], Thr = xa[12];
           const double Udot = R * V - Q * W - g * s_t + F16_DIVC(qbar * S * Cx, m) + F16_DIVC(Thr, m);     // :383-387
@@ -458,28 +465,15 @@ __global__ __launch_bounds__(256) void k_rollout_q(DynArgs a) {
 #pragma unroll
           for (int k = 0; k < 9; ++k) x[k] += xd[k] * a.dt;   // env.py:126
         }
-        if (tr && --until_store == 0) {
-          until_store = a.traj_every;
-          if (valid && s < 3) {                               // sub-lane s stores x[s], x[3+s], x[6+s]
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-              const double v = s == 0 ? x[3 * j] : (s == 1 ? x[3 * j + 1] : x[3 * j + 2]);
-              __builtin_nontemporal_store(v, tr + (3 * j + s) * a.ld);
-            }
-          }
-          tr += 18 * a.ld;
-        }
       } else if (wave == 1) {
         if (live) {
           double xm[18];
-          plant_moments(x[9], x[10], x[11], xt[6][ac], xt[5][ac], xt[2][ac], xt[4][ac], xm);
+          const double Cy = xt[3][ac] + xt[8][ac];
+          const double Cn = xt[4][ac] + xt[9][ac] - Cy * (0.35 - a.xcg) * (11.32 / 30.0);   // C/nlplant.c:367
+          const double Cl = xt[5][ac] + xt[10][ac];
+          plant_moments(x[9], x[10], x[11], xt[6][ac], Cl, xt[2][ac], Cn, xm);
 #pragma unroll
           for (int k = 9; k < 12; ++k) x[k] += xm[k] * a.dt;
-        }
-        if (tr && --until_store == 0) {
-          until_store = a.traj_every;
-          if (valid && s < 3) __builtin_nontemporal_store(s == 0 ? x[9] : (s == 1 ? x[10] : x[11]), tr + (9 + s) * a.ld);
-          tr += 18 * a.ld;
         }
       }
     }

@@ -98,8 +98,10 @@ F16_DEV QuadIn quad_inputs(const double *xu) {
 
 // Cx_tot / Cz_tot / Cm_tot on sub-lanes 0 / 1 / 2 (C/nlplant.c:333-347, hifi_C, hifi_damping, hifi_C_lef,
 // hifi_damping_lef, hifi_other_coeffs).  dZdQ uses delta_Cz_lef exactly as the reference does (:339).
+// latd: the rate-damping part of the LATERAL member k (Cy, Cn, Cl) -- 1-D tables on the same alpha cell, evaluated here
+// to balance the two aerodynamic waves: kb (Cr + dCr_lef dlef) R + kb (Cp + dCp_lef dlef) P (+ dC_beta beta), :353-377.
 template <typename TP>
-F16_DEV double quad_long(TP T, const double *xu, int s, double xcg, int &status) {
+F16_DEV double quad_long(TP T, const double *xu, int s, double xcg, unsigned flags, double &latd, int &status) {
   const QuadIn in = quad_inputs(xu);
   const int k = s < 2 ? s : 2;
   // (1) breakpoints
@@ -126,6 +128,9 @@ F16_DEV double quad_long(TP T, const double *xu, int s, double xcg, int &status)
   const double g0 = g[3 * k], g1 = g[S_G1A + 3 * k], m0 = g[11], m1 = g[S_G1A + 11];
   const double h0 = h[3 * k], h1 = h[S_G1B + 3 * k];
   const double e0 = T[OFF_ETA + cd.j], e1 = T[OFF_ETA + cd.j + 1];
+  const int ir = k == 0 ? 1 : (k == 1 ? 7 : 4), ib = k == 1 ? 9 : 10;     // CYr CYp | CNr CNp | CLr CLp; dCNbeta, dCLbeta
+  const double r0 = g[ir], r1 = g[S_G1A + ir], p0 = g[ir + 1], p1 = g[S_G1A + ir + 1], b0 = g[ib], b1 = g[S_G1A + ib];
+  const double hr0 = h[ir], hr1 = h[S_G1B + ir], hp0 = h[ir + 1], hp1 = h[S_G1B + ir + 1];
   F16_PHASE();
   // (3) arithmetic
   const Axis a1 = br_axis(ca), b = br_axis(cb), d1 = br_axis(cd);
@@ -139,14 +144,19 @@ F16_DEV double quad_long(TP T, const double *xu, int s, double xcg, int &status)
   double tot = Cf * (k == 2 ? eta : 1.0) + dC * in.dlef + in.kq * (Cq + dql * in.dlef) * in.Q + (k == 2 ? dCm : 0.0);
   const double Cz_tot = quad_bcast<1>(tot);
   if (k == 2) tot += Cz_tot * (0.35 - xcg);                       // :347
+  double Cr = lerp(r0, r1, a1);
+  if (k == 2 && !(flags & FLAG_FIX_CLR)) Cr = 0.0;                // reference defect: _CLr is never loaded
+  const double Cp = lerp(p0, p1, a1), Cb = lerp(b0, b1, a1);
+  const double dCr = lerp(hr0, hr1, a2), dCp = lerp(hp0, hp1, a2);
+  latd = in.kb * (Cr + dCr * in.dlef) * in.R + in.kb * (Cp + dCp * in.dlef) * in.P + (k == 0 ? 0.0 : Cb * in.beta);
   return tot;
 }
 
-// Cy_tot / Cn_tot / Cl_tot on sub-lanes 0 / 1 / 2 (C/nlplant.c:353-377, hifi_C, hifi_damping, hifi_C_lef,
-// hifi_damping_lef, hifi_rudder, hifi_ailerons, hifi_other_coeffs).
+// Static part (3-D / 2-D tables) of Cy_tot / Cn_tot / Cl_tot on sub-lanes 0 / 1 / 2 (C/nlplant.c:353-377, hifi_C,
+// hifi_C_lef, hifi_rudder, hifi_ailerons); the damping part comes from quad_long, the cg coupling of Cn (:367) is
+// applied by the consumer once both parts of Cy_tot are known.
 template <typename TP>
-F16_DEV double quad_lat(TP T, const double *xu, int s, double xcg, unsigned flags, int &status) {
-  const double B = 30.0, cbar = 11.32;
+F16_DEV double quad_lat(TP T, const double *xu, int s, int &status) {
   const QuadIn in = quad_inputs(xu);
   const int k = s < 2 ? s : 2;
   // (1) breakpoints
@@ -174,10 +184,6 @@ F16_DEV double quad_lat(TP T, const double *xu, int s, double xcg, unsigned flag
   constexpr int SAB = S_G2B, SBB = S_G2B * N_A2;
   TP pb = T + OFF_G2B + n2 * SAB;
   const Q4 ql = ld4(pb + 3 + k, SAB, SBB), qal = ld4(pb + 6 + k, SAB, SBB);
-  const int ir = k == 0 ? 1 : (k == 1 ? 7 : 4), ib = k == 1 ? 9 : 10;     // CYr CYp | CNr CNp | CLr CLp; dCNbeta, dCLbeta
-  TP g = T + OFF_G1A + ca.j * S_G1A, h = T + OFF_G1B + j2 * S_G1B;
-  const double r0 = g[ir], r1 = g[S_G1A + ir], p0 = g[ir + 1], p1 = g[S_G1A + ir + 1], b0 = g[ib], b1 = g[S_G1A + ib];
-  const double hr0 = h[ir], hr1 = h[S_G1B + ir], hp0 = h[ir + 1], hp1 = h[S_G1B + ir + 1];
   F16_PHASE();
   // (3) arithmetic
   const Axis a1 = br_axis(ca), b = br_axis(cb), d2 = br_axis(cd);
@@ -187,18 +193,10 @@ F16_DEV double quad_lat(TP T, const double *xu, int s, double xcg, unsigned flag
   const double Cy = bil4(qy, a1, b), Cr30 = bil4(qr, a1, b), Ca20 = bil4(qa, a1, b);
   const double Clef = bil4(ql, a2, b), Ca20lef = bil4(qal, a2, b);
   const double base = k == 0 ? Cy : C3, base0 = k == 0 ? Cy : C30;
-  double Cr = lerp(r0, r1, a1);
-  if (k == 2 && !(flags & FLAG_FIX_CLR)) Cr = 0.0;               // reference defect: _CLr is never loaded
-  const double Cp = lerp(p0, p1, a1), Cb = lerp(b0, b1, a1);
-  const double dCr = lerp(hr0, hr1, a2), dCp = lerp(hp0, hp1, a2);
   const double dlefC = Clef - base0;                             // hifi_C_lef
   const double dr30 = Cr30 - base0;                              // hifi_rudder
   const double da20 = Ca20 - base0, da20lef = Ca20lef - Clef - da20;   // hifi_ailerons
-  double tot = base + dlefC * in.dlef + (da20 + da20lef * in.dlef) * in.dail + dr30 * in.drud +
-               in.kb * (Cr + dCr * in.dlef) * in.R + in.kb * (Cp + dCp * in.dlef) * in.P + (k == 0 ? 0.0 : Cb * in.beta);
-  const double Cy_tot = quad_bcast<0>(tot);
-  if (k == 1) tot -= Cy_tot * (0.35 - xcg) * (cbar / B);         // :367
-  return tot;
+  return base + dlefC * in.dlef + (da20 + da20lef * in.dlef) * in.dail + dr30 * in.drud;
 }
 
 }  // namespace f16
