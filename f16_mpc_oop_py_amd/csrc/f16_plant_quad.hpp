@@ -65,12 +65,50 @@ F16_DEV Q4 ld4(TP p, int sa, int sb) { Q4 c; c.f00 = p[0]; c.f10 = p[sa]; c.f01 
 F16_DEV double bil4(const Q4 &c, const Axis &a, const Axis &b) {   // alpha collapsed first, then beta (mexndinterp.c:178-209)
   return lerp(lerp(c.f00, c.f10, a), lerp(c.f01, c.f11, a), b);
 }
-#define F16_PHASE() __builtin_amdgcn_sched_barrier(0)
+#ifndef F16_PHASE_MASK
+#define F16_PHASE_MASK 0x7        // LDS / memory instructions stay in their phase, ALU instructions may float (2 % over 0)
+#endif
+#define F16_PHASE() __builtin_amdgcn_sched_barrier(F16_PHASE_MASK)
 
 F16_DEV int alpha_guess(double alpha) { return (int)((fmin(fmax(alpha, -20.0), 90.0) + 20.0) * 0.2); }
 F16_DEV int beta_guess(double beta) {
   const double bc = fmin(fmax(beta, -30.0), 30.0);
   return bc < -10.0 ? (int)((bc + 30.0) * 0.2) : (bc < 10.0 ? 4 + (int)((bc + 10.0) * 0.5) : 14 + (int)((bc - 10.0) * 0.2));
+}
+
+template <int J>
+F16_DEV int quad_bcast_i(int v) {
+  constexpr int ctrl = J | (J << 2) | (J << 4) | (J << 6);
+  return __builtin_amdgcn_mov_dpp(v, ctrl, 0xF, 0xF, true);
+}
+
+// The three axis brackets of a role, ONE PER SUB-LANE (0: alpha on ALPHA1, 1: beta, 2/3: elevator on DH1 or DH2), shared
+// across the quad by DPP broadcasts: first the cell indices (the table addresses need nothing else), later lambda.
+struct QuadBr { BrCell c; int ja, jb, jd; bool offa, offb, offd; };
+template <bool USE_D2, typename TP>
+F16_DEV BrRaw quad_br_load(TP T, double alpha, double beta, double el, int s, int &nX, double &vX) {
+  const int ax = s < 2 ? s : 2;
+  const int gel = USE_D2 ? (int)(el >= 0.0) : (el >= -10.0) + (el >= 0.0) + (el >= 10.0);
+  const int offX = ax == 0 ? OFF_BP_A1 : (ax == 1 ? OFF_BP_B1 : (USE_D2 ? OFF_BP_D2 : OFF_BP_D1));
+  nX = ax == 0 ? N_A1 : (ax == 1 ? N_B1 : (USE_D2 ? N_D2 : N_D1));
+  vX = ax == 0 ? alpha : (ax == 1 ? beta : el);
+  const int gX = ax == 0 ? alpha_guess(alpha) : (ax == 1 ? beta_guess(beta) : gel);
+  return br_load(T + offX, nX, gX);
+}
+F16_DEV QuadBr quad_br_cells(const BrRaw &r, int nX, double vX) {
+  QuadBr q;
+  bool off;
+  q.c = br_cell(r, nX, vX, off);
+  q.ja = quad_bcast_i<0>(q.c.j); q.jb = quad_bcast_i<1>(q.c.j); q.jd = quad_bcast_i<2>(q.c.j);
+  const int o = off ? 1 : 0;
+  q.offa = quad_bcast_i<0>(o) != 0; q.offb = quad_bcast_i<1>(o) != 0; q.offd = quad_bcast_i<2>(o) != 0;
+  return q;
+}
+F16_DEV void quad_br_axes(const QuadBr &q, Axis &a, Axis &b, Axis &d) {
+  const Axis own = br_axis(q.c);                                  // one division per lane
+  a.j = q.ja; a.l = quad_bcast<0>(own.l); a.m = quad_bcast<0>(own.m);
+  b.j = q.jb; b.l = quad_bcast<1>(own.l); b.m = quad_bcast<1>(own.m);
+  d.j = q.jd; d.l = quad_bcast<2>(own.l); d.m = quad_bcast<2>(own.m);
 }
 
 struct QuadIn {            // what both aerodynamic waves derive from the published state (C/nlplant.c:84-125)
@@ -104,21 +142,20 @@ template <typename TP>
 F16_DEV double quad_long(TP T, const double *xu, int s, double xcg, unsigned flags, double &latd, int &status) {
   const QuadIn in = quad_inputs(xu);
   const int k = s < 2 ? s : 2;
-  // (1) breakpoints
-  const BrRaw ra = br_load(T + OFF_BP_A1, N_A1, alpha_guess(in.alpha));
-  const BrRaw rb = br_load(T + OFF_BP_B1, N_B1, beta_guess(in.beta));
-  const BrRaw rd = br_load(T + OFF_BP_D1, N_D1, (in.el >= -10.0) + (in.el >= 0.0) + (in.el >= 10.0));
+  // (1) breakpoints: one axis per sub-lane
+  int nX; double vX;
+  const BrRaw rx = quad_br_load<false>(T, in.alpha, in.beta, in.el, s, nX, vX);
   const double a45 = T[OFF_BP_A1 + N_A2 - 1];
   F16_PHASE();
-  bool offa, offb, offd;
-  const BrCell ca = br_cell(ra, N_A1, in.alpha, offa), cb = br_cell(rb, N_B1, in.beta, offb), cd = br_cell(rd, N_D1, in.el, offd);
-  if (offa) status |= ST_ALPHA1 | ST_ALPHA2;
-  if (offb) status |= ST_BETA;
-  if (offd) status |= ST_EL;
-  const bool hi_a = ca.j > N_A2 - 2;                             // ALPHA2 ends at 45 deg: last cell, lambda = 1
+  const QuadBr qb = quad_br_cells(rx, nX, vX);
+  if (qb.offa) status |= ST_ALPHA1 | ST_ALPHA2;
+  if (qb.offb) status |= ST_BETA;
+  if (qb.offd) status |= ST_EL;
+  const bool hi_a = qb.ja > N_A2 - 2;                            // ALPHA2 ends at 45 deg: last cell, lambda = 1
   if (hi_a && in.alpha > a45) status |= ST_ALPHA2;
-  const int j2 = hi_a ? N_A2 - 2 : ca.j;
-  const int n1 = cb.j * N_A1 + ca.j, n2 = cb.j * N_A2 + j2;
+  const int j2 = hi_a ? N_A2 - 2 : qb.ja;
+  const int n1 = qb.jb * N_A1 + qb.ja, n2 = qb.jb * N_A2 + j2;
+  struct { int j; } ca = {qb.ja}, cd = {qb.jd};
   // (2) every table corner this role needs
   constexpr int SA = S_G3A, SB = S_G3A * N_A1, SD = S_G3A * N_A1 * N_B1;
   TP p = T + OFF_G3A + n1 * SA + k;
@@ -133,7 +170,8 @@ F16_DEV double quad_long(TP T, const double *xu, int s, double xcg, unsigned fla
   const double hr0 = h[ir], hr1 = h[S_G1B + ir], hp0 = h[ir + 1], hp1 = h[S_G1B + ir + 1];
   F16_PHASE();
   // (3) arithmetic
-  const Axis a1 = br_axis(ca), b = br_axis(cb), d1 = br_axis(cd);
+  Axis a1, b, d1;
+  quad_br_axes(qb, a1, b, d1);
   Axis a2 = a1;
   if (hi_a) { a2.j = N_A2 - 2; a2.l = 1.0; a2.m = 0.0; }
   const double Cf = lerp(bil4(qlo, a1, b), bil4(qhi, a1, b), d1);
@@ -159,21 +197,20 @@ template <typename TP>
 F16_DEV double quad_lat(TP T, const double *xu, int s, int &status) {
   const QuadIn in = quad_inputs(xu);
   const int k = s < 2 ? s : 2;
-  // (1) breakpoints
-  const BrRaw ra = br_load(T + OFF_BP_A1, N_A1, alpha_guess(in.alpha));
-  const BrRaw rb = br_load(T + OFF_BP_B1, N_B1, beta_guess(in.beta));
-  const BrRaw rd = br_load(T + OFF_BP_D2, N_D2, (int)(in.el >= 0.0));
+  // (1) breakpoints: one axis per sub-lane
+  int nX; double vX;
+  const BrRaw rx = quad_br_load<true>(T, in.alpha, in.beta, in.el, s, nX, vX);
   const double a45 = T[OFF_BP_A1 + N_A2 - 1];
   F16_PHASE();
-  bool offa, offb, offd;
-  const BrCell ca = br_cell(ra, N_A1, in.alpha, offa), cb = br_cell(rb, N_B1, in.beta, offb), cd = br_cell(rd, N_D2, in.el, offd);
-  if (offa) status |= ST_ALPHA1 | ST_ALPHA2;
-  if (offb) status |= ST_BETA;
-  if (offd) status |= ST_EL;
-  const bool hi_a = ca.j > N_A2 - 2;
+  const QuadBr qb = quad_br_cells(rx, nX, vX);
+  if (qb.offa) status |= ST_ALPHA1 | ST_ALPHA2;
+  if (qb.offb) status |= ST_BETA;
+  if (qb.offd) status |= ST_EL;
+  const bool hi_a = qb.ja > N_A2 - 2;
   if (hi_a && in.alpha > a45) status |= ST_ALPHA2;
-  const int j2 = hi_a ? N_A2 - 2 : ca.j;
-  const int n1 = cb.j * N_A1 + ca.j, n2 = cb.j * N_A2 + j2;
+  const int j2 = hi_a ? N_A2 - 2 : qb.ja;
+  const int n1 = qb.jb * N_A1 + qb.ja, n2 = qb.jb * N_A2 + j2;
+  struct { int j; } cd = {qb.jd};
   // (2) every table corner this role needs
   constexpr int SA3 = S_G3B, SB3 = S_G3B * N_A1, SD3 = S_G3B * N_A1 * N_B1;
   TP p3 = T + OFF_G3B + n1 * SA3 + (k > 0 ? k - 1 : 0);          // sub-lane 0 shadows Cn; its base is Cy
@@ -186,7 +223,8 @@ F16_DEV double quad_lat(TP T, const double *xu, int s, int &status) {
   const Q4 ql = ld4(pb + 3 + k, SAB, SBB), qal = ld4(pb + 6 + k, SAB, SBB);
   F16_PHASE();
   // (3) arithmetic
-  const Axis a1 = br_axis(ca), b = br_axis(cb), d2 = br_axis(cd);
+  Axis a1, b, d2;
+  quad_br_axes(qb, a1, b, d2);
   Axis a2 = a1;
   if (hi_a) { a2.j = N_A2 - 2; a2.l = 1.0; a2.m = 0.0; }
   const double C3 = lerp(bil4(qlo, a1, b), bil4(qhi, a1, b), d2), C30 = bil4(q0, a1, b);
