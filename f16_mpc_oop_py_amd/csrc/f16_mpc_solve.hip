@@ -452,11 +452,14 @@ __device__ __forceinline__ double reduce6(double v0, double v1, double v2, doubl
 //   stage 1 (CCs' w)_j   = sum_d Gs_d' w_{j+d}     -> row blk = j, reads the 12 contiguous doubles w_{j+2q}, w_{j+2q+1}
 //   stage 3 (CCs x~)_i   = sum_d Gs_d  x~_{i-d}    -> row blk = i, reads the 6 contiguous doubles x~_{i-2q-1}, x~_{i-2q}
 // Out-of-range blocks read zeros (the vectors are zero-padded in LDS), so there is no per-lane masking.
-__device__ __forceinline__ void stage1_partial(const double (&Gd)[2][6][3], const double *wp, double (&o)[3]) {
+// (operand loads and arithmetic are separate calls: the caller issues every LDS read of a phase first -- left alone the
+//  compiler emits read, wait, use in source order and a phase pays three or four LDS round trips instead of one)
+__device__ __forceinline__ void stage1_load(const double *wp, double (&wv)[12]) {
   const double2 *p = reinterpret_cast<const double2 *>(wp);
-  double wv[12];
 #pragma unroll
   for (int k = 0; k < 6; ++k) { const double2 t = p[k]; wv[2 * k] = t.x; wv[2 * k + 1] = t.y; }
+}
+__device__ __forceinline__ void stage1_fma(const double (&Gd)[2][6][3], const double (&wv)[12], double (&o)[3]) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     double s0 = 0.0, s1 = 0.0;
@@ -465,10 +468,11 @@ __device__ __forceinline__ void stage1_partial(const double (&Gd)[2][6][3], cons
     o[c] = s0 + s1;
   }
 }
-__device__ __forceinline__ void stage3_partial(const double (&Gd)[2][6][3], const double *xp, double (&o)[6]) {
-  double xv[6];
+__device__ __forceinline__ void stage3_load(const double *xp, double (&xv)[6]) {
 #pragma unroll
   for (int k = 0; k < 6; ++k) xv[k] = xp[k];          // x~_{i-2q-1} (3), x~_{i-2q} (3)
+}
+__device__ __forceinline__ void stage3_fma(const double (&Gd)[2][6][3], const double (&xv)[6], double (&o)[6]) {
 #pragma unroll
   for (int rr = 0; rr < 6; ++rr) {
     double s0 = 0.0, s1 = 0.0;
@@ -478,6 +482,7 @@ __device__ __forceinline__ void stage3_partial(const double (&Gd)[2][6][3], cons
   }
 }
 
+#define MPC_PHASE() __builtin_amdgcn_sched_barrier(0x7)      /* LDS / memory ops stay put, ALU may float */
 constexpr int WSP = 6 * 64;            // zero-padded state-row vectors (stage 1 reads up to block 31 + 31 + 1)
 constexpr int XOFF = 3 * 32;           // zeros in front of x~ (stage 3 reads down to block -31)
 constexpr int XTP = XOFF + FN + 8;
@@ -508,6 +513,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
   const int k3 = 3 * blk + sub;                                // index of a command / rate row
   const bool xown = inb && (lc == 0 || lc == 4 || lc == 8);
   const int xe = 3 * blk + (lc >> 2);
+  const int xec = xe < FN ? xe : FN - 1;                        // in-range index for lanes that own no variable
   double *const wdst = kind == 1 ? wsP + 6 * blk + sub : (kind == 2 ? wc + k3 : wr + k3);
   double *const ydst = kind == 1 ? ysP + 6 * blk + sub : (kind == 2 ? yc + k3 : yr + k3);
   // zero everything once: the pads are never written again
@@ -598,10 +604,13 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
       ++it;
       // ---- A: rhs = sigma x - q + A'(rho z - y)
       {
-        double o1[3];
-        stage1_partial(Gd, wsP + 6 * (blk + 2 * q), o1);
+        double wv[12], o1[3];
+        stage1_load(wsP + 6 * (blk + 2 * q), wv);
+        const double wce = wc[xec], wre = wr[xec], wrn = wr[xec + 3];
+        MPC_PHASE();
+        stage1_fma(Gd, wv, o1);
         const double t = reduce3(o1[0], o1[1], o1[2], h, g);
-        if (xown) rhs[xe] = sigma * xs - qe + (t + wc[xe] + (wr[xe] - wr[xe + 3]));
+        if (xown) rhs[xe] = sigma * xs - qe + (t + wce + (wre - wrn));
       }
       MSTAMP(0)
       __syncthreads();
@@ -609,11 +618,14 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
       // ---- B: x~ = Minv rhs from the accumulators (element (16w + 4qq + lq, 16J + lc) in acc[J][qq])
       if (w < NTT) {
         d4_t part = {0.0, 0.0, 0.0, 0.0};
+        double rj[NTT];
+#pragma unroll
+        for (int J = 0; J < NTT; ++J) rj[J] = rhs[16 * J + lc];
+        MPC_PHASE();
 #pragma unroll
         for (int J = 0; J < NTT; ++J) {
-          const double rj = rhs[16 * J + lc];
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq) part[qq] = fma(acc[J][qq], rj, part[qq]);
+          for (int qq = 0; qq < 4; ++qq) part[qq] = fma(acc[J][qq], rj[J], part[qq]);
         }
         const double v = reduce4(part, h, g);
         const int row = 16 * w + (lc & 12) + lq;
@@ -624,12 +636,15 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
       MSTAMP(3)
       // ---- C: z~ = A x~, relaxation, projection, dual update
       {
-        double o3[6];
-        stage3_partial(Gd, xtP + XOFF + 3 * (blk - 2 * q - 1), o3);
+        double xv[6], o3[6];
+        stage3_load(xtP + XOFF + 3 * (blk - 2 * q - 1), xv);
+        const double xte = xtP[XOFF + xec], xk = xtP[XOFF + k3], xkm = xtP[XOFF + k3 - 3];
+        MPC_PHASE();
+        stage3_fma(Gd, xv, o3);
         const double zs = reduce6(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], h, g, e);
-        if (xown) xs = alpha * xtP[XOFF + xe] + (1 - alpha) * xs;
+        if (xown) xs = alpha * xte + (1 - alpha) * xs;
         if (kind) {
-          const double zt = kind == 1 ? zs : (kind == 2 ? xtP[XOFF + k3] : xtP[XOFF + k3] - xtP[XOFF + k3 - 3]);
+          const double zt = kind == 1 ? zs : (kind == 2 ? xk : xk - xkm);
           const double zr = alpha * zt + (1 - alpha) * z;
           const double zn = fmin(fmax(fma(y, rinv, zr), lo), hi);
           dy = rho * (zr - zn);
@@ -645,9 +660,9 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         if (xown) xtP[XOFF + xe] = xs;
         __syncthreads();
         double o3[6], o1[3], px3[3] = {0.0, 0.0, 0.0};
-        stage3_partial(Gd, xtP + XOFF + 3 * (blk - 2 * q - 1), o3);
+        { double xv[6]; stage3_load(xtP + XOFF + 3 * (blk - 2 * q - 1), xv); stage3_fma(Gd, xv, o3); }
         const double axs = reduce6(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], h, g, e);
-        stage1_partial(Gd, ysP + 6 * (blk + 2 * q), o1);
+        { double wv[12]; stage1_load(ysP + 6 * (blk + 2 * q), wv); stage1_fma(Gd, wv, o1); }
         const double atys = reduce3(o1[0], o1[1], o1[2], h, g);
         if (inb) {                                              // P x: row blk's 16 lanes split the columns six apiece
 #pragma unroll
@@ -687,7 +702,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
           if (ndy > a.s.eps_prim_inf && supp < -a.s.eps_prim_inf * ndy) {
             if (kind) *ydst = dy;
             __syncthreads();
-            stage1_partial(Gd, ysP + 6 * (blk + 2 * q), o1);
+            { double wv[12]; stage1_load(ysP + 6 * (blk + 2 * q), wv); stage1_fma(Gd, wv, o1); }
             const double t = reduce3(o1[0], o1[1], o1[2], h, g);
             double wv[1] = {xown ? fabs(t + yc[xe] + (yr[xe] - yr[xe + 3])) : 0.0};
             const bool km[1] = {false};
