@@ -594,7 +594,7 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
       __syncthreads();
       double tp = 0.0, ta = 0.0;
       for (int e = l; e < n; e += F16_WAVE) { tp += Pg[tri(e, e)]; ta += Ag[tri(e, e)]; }
-      rho = fmin(fmax(sqrt(wave_sum(tp) / wave_sum(ta)), 1e-6), 1e6);
+      rho = fmin(fmax(RHO_AUTO_SCALE * sqrt(wave_sum(tp) / wave_sum(ta)), 1e-6), 1e6);
     }
     const double sigma = a.s.sigma, alpha = a.s.alpha;
     auto build_minv = [&](double r) {

@@ -553,7 +553,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
       double tr[2] = {xown ? Pg[tri(xe, xe)] : 0.0, xown ? Ag[tri(xe, xe)] : 0.0};
       const bool sums[2] = {true, true};
       block_reduce<2>(tr, sums, red);
-      rho = fmin(fmax(sqrt(tr[0] / tr[1]), 1e-6), 1e6);
+      rho = fmin(fmax(RHO_AUTO_SCALE * sqrt(tr[0] / tr[1]), 1e-6), 1e6);
     }
     int it = 0;
     double rp = INFINITY, rd = INFINITY;

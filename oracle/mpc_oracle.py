@@ -266,6 +266,7 @@ def mpc_qp(x_full, Ad, Bd, Cd, hzn, dt, p_dem=0.0, q_dem=0.0, r_dem=0.0):
 
 
 # ------------------------------------------------------------- QP solvers
+RHO_AUTO_SCALE = 2.0      # start value of rho when rho <= 0: RHO_AUTO_SCALE * sqrt(tr P / tr A'A) (same constant as csrc/f16_mpc.hpp)
 ADMM_DEFAULTS = dict(rho=0.0, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, eps_prim_inf=1e-4,
                      check_every=25, rho_every=100, max_iter=40000, adaptive_rho=True)
 
@@ -284,7 +285,7 @@ def admm_osqp_style(P, q, A, l, u, **kw):
     rho, sigma, alpha = o["rho"], o["sigma"], o["alpha"]
     AtA = A.T @ A
     if not rho > 0:     # automatic start value: balance the two terms of P + rho A'A (no Ruiz scaling here)
-        rho = float(min(max(np.sqrt(np.trace(P) / np.trace(AtA)), 1e-6), 1e6))
+        rho = float(min(max(RHO_AUTO_SCALE * np.sqrt(np.trace(P) / np.trace(AtA)), 1e-6), 1e6))
     cho = scipy.linalg.cho_factor(P + sigma * np.eye(n) + rho * AtA)
     x, z, y = np.zeros(n), np.zeros(mrow), np.zeros(mrow)
     it, rp, rd = 0, np.inf, np.inf
