@@ -47,6 +47,7 @@ def main():
 
     from f16_mpc_oop_py_amd import dist as fdist
     rank, world, local = fdist.init_from_env()
+    local = local % max(torch.cuda.device_count(), 1)      # (only differs in a rehearsal with more ranks than GPUs)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -27,7 +27,8 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # F16_DIST_BACKEND=gloo: rehearsal of the multi-rank paths on a box with fewer GPUs than ranks
+        backend = backend or os.environ.get("F16_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local)
