@@ -45,112 +45,10 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], const bool (&is_su
   }
 }
 
-// (P + sigma I + rho A'A)^-1 in LDS by the symmetric sweep operator (Gauss-Jordan without pivoting, stable for SPD):
-// after pivot k the lower triangle holds the partially swept matrix, after all n pivots -inverse.
-// Storage: lower triangle of a square array with leading dimension SLD (rows 16-byte aligned).  Each lane owns one
-// run of SRUN consecutive columns of one row, so a pivot step is: 6 x 16-byte reads of the pivot column run, 6 x 16-byte
-// reads + writes of its own run, 12 FMAs.  The pivot row and pivot column are lane-level special cases (no per-element
-// selects).  One barrier per pivot: while applying pivot k the lanes that produce entries of column k+1 publish them
-// (double-buffered cvec).  Out of line: its register allocation must not compete with the caller's operator registers.
-constexpr int SLD = FN + 2;    // 98: rows 16-byte aligned and NOT a multiple of the 256-byte LDS bank row
-constexpr int SRUN = 12;
-__device__ __attribute__((noinline)) bool sweep_inverse(double *Ms, double *cvec, const double *Pg, const double *Ag, double r,
-                                                        double sigma, int n, int np) {
-  const int tid = threadIdx.x;
-  bool ok = true;
-  // lane -> (row i, first column j0): rows are cut into ceil((i+1)/SRUN) runs, enumerated row by row
-  int row = -1, j0 = 0;
-  {
-    int acc = 0;
-    for (int i = 0; i < n; ++i) {
-      const int runs = (i + SRUN) / SRUN;
-      if (tid >= acc && tid < acc + runs) { row = i; j0 = (tid - acc) * SRUN; }
-      acc += runs;
-    }
-  }
-  __syncthreads();
-  for (int e = tid; e < np; e += FT) {                      // unpack P + r A'A into the square array (lower triangle)
-    int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-    while (i * (i + 1) / 2 > e) --i;
-    while ((i + 1) * (i + 2) / 2 <= e) ++i;
-    const int j = e - i * (i + 1) / 2;
-    Ms[i * SLD + j] = Pg[e] + r * Ag[e] + (i == j ? sigma : 0.0);
-  }
-  // zero the part of each row's last run that lies right of the diagonal (read by the 16-byte loads, never meaningful)
-  if (row >= 0 && j0 + SRUN > row + 1)
-    for (int j = row + 1 > j0 ? row + 1 : j0; j < j0 + SRUN && j < SLD; ++j) Ms[row * SLD + j] = 0.0;
-  __syncthreads();
-  if (tid < n) cvec[tid] = Ms[tid * SLD];                   // column 0
-  if (tid >= n && tid < FN + 8) cvec[tid] = 0.0;
-  if (tid < FN + 8) cvec[FN + 8 + tid] = 0.0;
-  __syncthreads();
-  double *mrun = Ms + (row >= 0 ? row : 0) * SLD + j0;
-  for (int k = 0; k < n; ++k) {
-    const double *cv = cvec + (k & 1) * (FN + 8);
-    double *cn = cvec + ((k + 1) & 1) * (FN + 8);
-    const double piv = cv[k];
-    if (!(piv > 0.0)) ok = false;
-    const double d = 1.0 / piv;
-    if (row >= 0) {
-      double2 cj[SRUN / 2], mv[SRUN / 2];
-      const double2 *cp = reinterpret_cast<const double2 *>(cv + j0);
-      double2 *mp = reinterpret_cast<double2 *>(mrun);
-#pragma unroll
-      for (int q = 0; q < SRUN / 2; ++q) { cj[q] = cp[q]; mv[q] = mp[q]; }
-      const double ci = cv[row];
-      // generic element: m - (c_i d) c_j ; pivot row (a handful of lanes): c_j d.  Entries right of the diagonal in the
-      // last run of a row are scratch: they stay finite and are never read as matrix entries.
-      const double cid = (row == k) ? -d : ci * d;
-#pragma unroll
-      for (int q = 0; q < SRUN / 2; ++q) {
-        const double bx = (row == k) ? 0.0 : mv[q].x, by = (row == k) ? 0.0 : mv[q].y;
-        mv[q].x = bx - cid * cj[q].x;
-        mv[q].y = by - cid * cj[q].y;
-      }
-      const int kk = k - j0;                                 // pivot column / diagonal inside this run (register fix-up)
-      if (kk >= 0 && kk < SRUN && row >= k) {
-        const double fix = (row == k) ? -d : ci * d;
-#pragma unroll
-        for (int q = 0; q < SRUN / 2; ++q) {
-          if (2 * q == kk) mv[q].x = fix;
-          if (2 * q + 1 == kk) mv[q].y = fix;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < SRUN / 2; ++q) mp[q] = mv[q];
-      // publish column k+1 for the next pivot, straight from registers (no LDS read-back on the critical path)
-      if (row == k + 1) {
-        if (j0 + SRUN <= row + 1) {
-          double2 *cnp = reinterpret_cast<double2 *>(cn + j0);
-#pragma unroll
-          for (int q = 0; q < SRUN / 2; ++q) cnp[q] = mv[q];
-        } else {
-#pragma unroll
-          for (int q = 0; q < SRUN / 2; ++q) {
-            if (j0 + 2 * q <= row) cn[j0 + 2 * q] = mv[q].x;
-            if (j0 + 2 * q + 1 <= row) cn[j0 + 2 * q + 1] = mv[q].y;
-          }
-        }
-      } else if (row > k + 1) {
-        const int k1 = k + 1 - j0;
-        if (k1 >= 0 && k1 < SRUN) {
-          double val = 0.0;
-#pragma unroll
-          for (int q = 0; q < SRUN / 2; ++q) {
-            if (2 * q == k1) val = mv[q].x;
-            if (2 * q + 1 == k1) val = mv[q].y;
-          }
-          cn[row] = val;
-        }
-      }
-    }
-    __syncthreads();
-  }
-  return ok;
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// Blocked form of the same sweep on the fp64 matrix cores (v_mfma_f64_16x16x4_f64): the matrix lives in MFMA
+// (P + sigma I + rho A'A)^-1 by the symmetric sweep operator (Gauss-Jordan without pivoting, stable for SPD: after
+// sweeping all pivots the array holds MINUS the inverse), in blocked form on the fp64 matrix cores
+// (v_mfma_f64_16x16x4_f64): the matrix lives in MFMA
 // accumulators -- wave w owns tile row w (rows 16w..16w+15, all six 16x16 tiles: 24 fp64 per lane) -- and a block step
 // sweeps FOUR pivots at once:
 //     M_rest <- M_rest - (C D^-1) C'      one 16x16x4 MFMA per tile        (C = the 4 pivot columns, D = 4x4 pivot block)
@@ -361,32 +259,23 @@ __device__ F16_INV_ATTR bool mfma_inverse(d4_t *acc_out, double *Cs, const doubl
   return __syncthreads_and(ok) != 0;      // uniform over the workgroup (only the tile-row waves looked at pivots)
 }
 
-// diagnostic / test entry: inverse of B packed SPD matrices through mfma_inverse (or the scalar sweep_inverse)
-__global__ __launch_bounds__(FT) void k_dbg_inverse(const double *pk, double *out, int n, long B, int use_mfma) {
-  __shared__ __attribute__((aligned(16))) double Mp[FN * SLD];
+// diagnostic / test entry: inverse of B packed SPD matrices through mfma_inverse
+__global__ __launch_bounds__(FT) void k_dbg_inverse(const double *pk, double *out, int n, long B) {
   __shared__ __attribute__((aligned(16))) double cv[2 * FN * 4 + 40];
   const int np = n * (n + 1) / 2, nt = (n + 15) >> 4;
   const int w = threadIdx.x >> 6, lc = threadIdx.x & 15, lq = (threadIdx.x & 63) >> 4;
   for (long b = blockIdx.x; b < B; b += gridDim.x) {
     const double *Pg = pk + (size_t)b * np;
     double *o = out + (size_t)b * n * n;
-    if (use_mfma) {
-      d4_t acc[NT];
-      const bool ok = mfma_inverse<NT>(acc, cv, Pg, Pg, 0.0, 0.0, n);
+    d4_t acc[NT];
+    const bool ok = mfma_inverse<NT>(acc, cv, Pg, Pg, 0.0, 0.0, n);
 #pragma unroll
-      for (int J = 0; J < NT; ++J)
+    for (int J = 0; J < NT; ++J)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int i = 16 * w + 4 * q + lq, j = 16 * J + lc;
-          if (w < nt && J < nt && i < n && j < n) o[i * n + j] = ok ? -acc[J][q] : NAN;
-        }
-    } else {
-      const bool ok = sweep_inverse(Mp, cv, Pg, Pg, 0.0, 0.0, n, np);
-      for (int e = threadIdx.x; e < n * n; e += FT) {
-        const int i = e / n, j = e - i * n;
-        o[e] = ok ? -(i >= j ? Mp[i * SLD + j] : Mp[j * SLD + i]) : NAN;
+      for (int q = 0; q < 4; ++q) {
+        const int i = 16 * w + 4 * q + lq, j = 16 * J + lc;
+        if (w < nt && J < nt && i < n && j < n) o[i * n + j] = ok ? -acc[J][q] : NAN;
       }
-    }
     __syncthreads();
   }
 }
@@ -765,10 +654,10 @@ int mpc_fast_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
 
 }  // namespace f16
 
-extern "C" int f16_debug_spd_inverse(f16_ctx *ctx, const double *packed, double *out, int n, long B, int use_mfma, void *stream) {
+extern "C" int f16_debug_spd_inverse(f16_ctx *ctx, const double *packed, double *out, int n, long B, void *stream) {
   using namespace f16;
   if (!ctx || !packed || !out || n < 1 || n > FN || B < 0) return set_error(F16_EINVAL, "bad argument");
   if (B == 0) return F16_OK;
-  hipLaunchKernelGGL(k_dbg_inverse, dim3((unsigned)(B < 512 ? B : 512)), dim3(FT), 0, (hipStream_t)stream, packed, out, n, B, use_mfma);
+  hipLaunchKernelGGL(k_dbg_inverse, dim3((unsigned)(B < 512 ? B : 512)), dim3(FT), 0, (hipStream_t)stream, packed, out, n, B);
   return hip_check(hipGetLastError(), "f16_debug_spd_inverse launch");
 }

@@ -93,7 +93,7 @@ def load():
         L.f16_qp_default_settings.restype = None
         L.f16_mpc_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, l, l, i, d, ctypes.POINTER(QPSettings), vp]
         L.f16_mpc_qp_debug.argtypes = [vp, vp, vp, vp, vp, vp, l, l, i, d, vp, vp, vp, vp, vp]
-        L.f16_debug_spd_inverse.argtypes = [vp, vp, vp, i, l, i, vp]
+        L.f16_debug_spd_inverse.argtypes = [vp, vp, vp, i, l, vp]
     _LIB = L
     return L
 

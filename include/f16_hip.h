@@ -138,9 +138,9 @@ int f16_mpc_qp_debug(f16_ctx *ctx, const double *Ad, const double *Bd, const dou
                      double *h_P, double *h_q, double *h_A, double *h_l, double *h_u);
 
 /* Tests: inverse of B packed (lower triangle, row-major) SPD n x n matrices, n <= 96, on the device through the
- * KKT-inverse routine of the MPC solver: use_mfma = 1 the blocked fp64-MFMA sweep (v_mfma_f64_16x16x4_f64),
- * 0 the scalar sweep.  packed [B][n(n+1)/2], out [B][n*n] (device pointers); NaN where a pivot was not positive. */
-int f16_debug_spd_inverse(f16_ctx *ctx, const double *packed, double *out, int n, long B, int use_mfma, void *stream);
+ * KKT-inverse routine of the MPC solver (blocked sweep on the fp64 matrix cores, v_mfma_f64_16x16x4_f64).
+ * packed [B][n(n+1)/2], out [B][n*n] (device pointers); NaN where a pivot block was not positive definite. */
+int f16_debug_spd_inverse(f16_ctx *ctx, const double *packed, double *out, int n, long B, void *stream);
 
 #ifdef __cplusplus
 }

@@ -253,10 +253,9 @@ def test_config5_closed_loop_rollout_single_rank():
 
 
 @pytest.mark.parametrize("n", [3, 12, 30, 47, 90, 96])
-@pytest.mark.parametrize("use_mfma", [1, 0])
-def test_mfma_inverse(n, use_mfma):
-    """KKT-inverse routine of the MPC solver on its own: blocked fp64-MFMA sweep (and the scalar sweep it replaced)
-    against numpy.linalg.inv on random SPD matrices shaped like P + sigma I + rho A'A (condition ~1e3)."""
+def test_mfma_inverse(n):
+    """KKT-inverse routine of the MPC solver on its own: blocked fp64-MFMA sweep against numpy.linalg.inv on random
+    SPD matrices shaped like P + sigma I + rho A'A (condition ~1e3)."""
     from f16_mpc_oop_py_amd import lib
     L = lib.load()
     ctx = lib.Context()
@@ -273,7 +272,7 @@ def test_mfma_inverse(n, use_mfma):
     pk = torch.tensor(np.stack(packed), dtype=torch.float64, device="cuda")
     out = torch.empty((Bn, n * n), dtype=torch.float64, device="cuda")
     lib.check(L.f16_debug_spd_inverse(ctx.handle, ctypes.c_void_p(pk.data_ptr()), ctypes.c_void_p(out.data_ptr()), n, Bn,
-                                      use_mfma, None), L)
+                                      None), L)
     torch.cuda.synchronize()
     got = out.cpu().numpy().reshape(Bn, n, n)
     for b in range(Bn):
