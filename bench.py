@@ -124,6 +124,7 @@ def main():
         out["roofline_large_batch"] = bench_large(args, dev, rank)
     if not args.no_mpc:
         out["mpc"] = bench_mpc(args, dev, rank, world, fdist, barrier)
+        out["config5_closed_loop"] = bench_closed_loop(args, dev, rank, world, fdist, barrier)
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(x0, u0, T)
         if "mpc" in out:
@@ -230,6 +231,36 @@ def bench_mpc(args, dev, rank, world, fdist, barrier):
                                  "Toeplitz recursion, so issued FLOPs are lower"},
             "admm_iters_mean": float(np.mean(it)), "mfma": mfma,
             "linearise_zoh_lqr_per_s": world * B / dl}
+
+
+def bench_closed_loop(args, dev, rank, world, fdist, barrier, B=8192, T=20):
+    """BASELINE config 5 shape per GPU: B = 8192 aircraft, closed loop (calc_MPC_action N = 30, then one Euler step),
+    T steps, trajectory kept on the device ([T,18,B]; the one all-gather is timed in the open-loop leg).  The model is
+    frozen at construction as in the reference (env.py:49-60), so the model-only part of the QP is a prepared plan;
+    the one-shot figure (everything rebuilt per call, as the reference does) is measured beside it."""
+    import torch
+    from f16_mpc_oop_py_amd import F16Batch
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(B * world)
+    sl = slice(rank * B, (rank + 1) * B)
+    res = {}
+    for name, use_plan, steps in (("prepared_plan", True, T), ("one_shot", False, max(4, T // 4))):
+        env = F16Batch(x0[sl], u0[sl], xcg=0.35, device=dev)
+        env.build_ssr()
+        if use_plan:
+            env.prepare_MPC(args.mpc_hzn)
+        fdist.closed_loop_mpc_rollout(env, steps=2, hzn=args.mpc_hzn, gather=False, use_plan=use_plan)
+        barrier()
+        t0 = time.perf_counter()
+        traj = fdist.closed_loop_mpc_rollout(env, steps=steps, hzn=args.mpc_hzn, gather=False, use_plan=use_plan)
+        barrier()
+        dt = fdist.max_over_ranks(time.perf_counter() - t0, dev)
+        assert bool(torch.isfinite(traj).all()) and fdist.or_status(env.status) & ~(64 | 128) == 0
+        res[name] = {"aircraft_steps_per_s": world * B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps}
+        del env, traj
+    res["batch_per_gpu"] = B
+    res["hzn"] = args.mpc_hzn
+    return res
 
 
 def cpu_baseline(x0, u0, T):

@@ -467,27 +467,43 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
   double *QG = Minv, *QbG = Minv + N * 27;
 
   for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
+    // a prepared plan (mode 2) already holds everything that depends on the model only: A, Q, Qbar, G_k, P, A'A;
+    // what is left per call is the state-dependent part, pred_i = A^(i+1) x and q
+    const bool update_only = SETUP_ONLY && a.mode == 2;
+    double *exm = a.ext ? a.ext + (size_t)b * mpc_ext_doubles(N) + mpc_ext_model(N) : nullptr;
+    if (update_only) {
+      for (int e = l; e < 81; e += F16_WAVE) { A[e] = exm[e]; Q[e] = exm[81 + e]; Qb[e] = exm[162 + e]; }
+      const double *Gg = a.ext + (size_t)b * mpc_ext_doubles(N) + n;
+      for (int e = l; e < N * 27; e += F16_WAVE) G[e] = Gg[e];
+      __syncthreads();
+    } else {
     // ---------------- model + weights (utils.py:82-105)
     load_soa(A, a.Ad, 81, a.ld, b);
     load_soa(Bm, a.Bd, 27, a.ld, b);
     load_soa(Qb, a.Cd, 81, a.ld, b);                  // Cd staged in Qb
     mm<true, false>(Q, Qb, Qb, 9, 9, 9);              // Q = C'C (env.py:389)
+    }
     if (l < 9) {
       const int MX[9] = {3, 4, 7, 8, 9, 10, 11, 17, 16};
-      const double v = a.x[MX[l] * a.ld + b];
+      const double v = a.x ? a.x[MX[l] * a.ld + b] : 0.0;            // (no state when a plan is prepared)
       x9[l] = v;
-      xref[l] = (l >= 5 && l < 8) ? a.dem[(l - 5) * a.ld + b] : v;   // env.py:380-383 (x_ref[5:8] = demands)
+      xref[l] = (l >= 5 && l < 8 && a.dem) ? a.dem[(l - 5) * a.ld + b] : v;   // env.py:380-383 (x_ref[5:8] = demands)
     }
     __syncthreads();
+    if (!update_only) {
     dare_sda_wave(A, Bm, Q, X, scr);
     lqr_gain_wave(A, Bm, X, K, scr);                  // K_dlqr; the reference uses K = -dlqr (utils.py:96)
     // Q_bar (utils.py:100) solves X = Phi' X Phi + Q + K'RK with Phi = A + B K: for the LQR gain K that equation IS the
     // DARE, so its solution is the DARE solution X itself.  (Measured on the reference's trim models: SDA's X agrees
     // with scipy.linalg.solve_discrete_lyapunov's Q_bar to 3e-13 relative -- closer than scipy's own DARE result.)
     copy(Qb, X, 81);
+    if (exm) {
+      for (int e = l; e < 81; e += F16_WAVE) { exm[e] = A[e]; exm[81 + e] = Q[e]; exm[162 + e] = Qb[e]; }
+    }
     // ---------------- prediction blocks G_k = A^k B, pred_i = A^(i+1) x (utils.py:171-197 without forming CC/MM)
     copy(G, Bm, 27);
     for (int k = 1; k < N; ++k) mm<false, false>(G + k * 27, A, G + (k - 1) * 27, 9, 9, 3);
+    }
     for (int i = 0; i < N; ++i) {
       const double *prev = i == 0 ? x9 : pred + (i - 1) * 9;
       if (l < 9) {
@@ -498,7 +514,7 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
       __syncthreads();
     }
     // QG_k = Q G_k, QbG_k = Qbar G_k
-    for (int k = 0; k < N; ++k) {
+    for (int k = 0; k < (update_only ? 0 : N); ++k) {
       for (int e = l; e < 27; e += F16_WAVE) {
         const int r = e / 3, c = e - 3 * r;
         double s1 = 0.0, s2 = 0.0;
@@ -516,7 +532,7 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
     // Block (j,l), j >= l, d = j-l:  T(j,l) = TQ(j,l) + G'_{N-1-j} Qbar G_{N-1-l},
     //   TQ(j,l) = TQ(j+1,l+1) + G'_{N-2-j} Q G_{N-2-l} (0 beyond N-2),  TS likewise with S'S and all i <= N-1.
     double *Pg = a.Ppk + (size_t)b * np, *Ag = a.Apk + (size_t)b * np;
-    for (int ch = l; ch < N * 9; ch += F16_WAVE) {       // one chain per (diagonal d, element (ra,cb))
+    for (int ch = l; ch < (update_only ? 0 : N * 9); ch += F16_WAVE) {       // one chain per (diagonal d, element (ra,cb))
       const int d = ch / 9, ee = ch - 9 * d, ra = ee / 3, cb = ee - 3 * ra;
       double tq = 0.0, ts = 0.0;
       for (int j = N - 1; j >= d; --j) {
@@ -584,7 +600,7 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
     if (a.ext) {   // per-aircraft extras for the register-resident solver / the debug entry point
       double *ex = a.ext + (size_t)b * mpc_ext_doubles(N);
       for (int e = l; e < n; e += F16_WAVE) ex[e] = qv[e];
-      for (int e = l; e < N * 27; e += F16_WAVE) ex[n + e] = G[e];
+      if (!update_only) { for (int e = l; e < N * 27; e += F16_WAVE) ex[n + e] = G[e]; }
       for (int e = l; e < 9 * N; e += F16_WAVE) ex[n + N * 27 + e] = pred[e];
     }
     if (SETUP_ONLY) { __syncthreads(); continue; }
@@ -865,6 +881,72 @@ extern "C" int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, c
   const bool generic = hzn > FAST_MAXN || a.s.max_iter < 0;
   if (a.s.max_iter < 0) a.s.max_iter = -a.s.max_iter;
   return mpc_launch(ctx, a, stream, generic ? 0 : 2);
+}
+
+// ---- prepared plans: everything of calc_MPC_action that depends on the model only (the reference freezes the model at
+// construction, env.py:49-60, but rebuilds the whole QP on every call) is computed once; a solve then costs the
+// state-dependent vectors + the ADMM iterations.
+struct f16_mpc_plan {
+  f16_ctx *ctx;
+  long B, ld;
+  int N;
+  double dt;
+  f16_qp_settings s;
+  double *buf;
+  MpcArgs a;
+};
+
+static int plan_launch_build(f16_mpc_plan *p, MpcArgs &a, void *stream) {
+  const size_t lds = mpc_lds_doubles(p->N, true) * sizeof(double);
+  if (int rc = hip_check(hipFuncSetAttribute((const void *)k_mpc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"))
+    return rc;
+  hipLaunchKernelGGL(k_mpc<true>, dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
+  return hip_check(hipGetLastError(), "f16_mpc_plan build launch");
+}
+
+extern "C" int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const double *Ad, const double *Bd, const double *Cd,
+                                   long B, long ld, int hzn, double dt, const f16_qp_settings *s, void *stream) {
+  if (!ctx || !plan || !Ad || !Bd || !Cd || B < 1 || ld < B) return set_error(F16_EINVAL, "bad argument to f16_mpc_plan_create");
+  if (hzn < 1 || hzn > FAST_MAXN) return set_error(F16_EINVAL, "prepared plans need 1 <= hzn <= 32");
+  f16_mpc_plan *p = new f16_mpc_plan();
+  p->ctx = ctx; p->B = B; p->ld = ld; p->N = hzn; p->dt = dt;
+  if (s) p->s = *s; else f16_qp_default_settings(&p->s);
+  if (p->s.check_every < 1 || p->s.rho_every < 1 || !(p->s.rho >= 0) || !(p->s.sigma > 0) || p->s.max_iter < 1) {
+    delete p;
+    return set_error(F16_EINVAL, "bad QP settings");
+  }
+  const size_t np = (size_t)(3 * hzn) * (3 * hzn + 1) / 2;
+  const size_t per = 2 * np + mpc_ext_doubles(hzn) + MPC_TILE_DOUBLES;
+  if (int rc = hip_check(hipMalloc(&p->buf, per * (size_t)B * sizeof(double)), "hipMalloc MPC plan")) { delete p; return rc; }
+  MpcArgs &a = p->a;
+  a = MpcArgs{};
+  a.Ad = Ad; a.Bd = Bd; a.Cd = Cd; a.B = B; a.ld = ld; a.N = hzn; a.dt = dt; a.s = p->s;
+  a.Ppk = p->buf; a.Apk = a.Ppk + np * (size_t)B; a.ext = a.Apk + np * (size_t)B;
+  a.tiles = a.ext + mpc_ext_doubles(hzn) * (size_t)B;
+  a.mode = 1;
+  int rc = plan_launch_build(p, a, stream);
+  if (!rc) rc = mpc_fast_solve_launch(ctx, a, stream);
+  a.Ad = a.Bd = a.Cd = nullptr;                        // not retained
+  if (rc) { (void)hipFree(p->buf); delete p; return rc; }
+  *plan = p;
+  return F16_OK;
+}
+
+extern "C" int f16_mpc_plan_solve(f16_mpc_plan *p, const double *x, const double *dem, double *u_cmd, double *u_seq,
+                                  double *info, int32_t *status, void *stream) {
+  if (!p || !x || !dem || !u_cmd) return set_error(F16_EINVAL, "bad argument to f16_mpc_plan_solve");
+  MpcArgs a = p->a;
+  a.x = x; a.dem = dem; a.ucmd = u_cmd; a.useq = u_seq; a.info = info; a.status = status;
+  a.mode = 2;
+  if (int rc = plan_launch_build(p, a, stream)) return rc;
+  return mpc_fast_solve_launch(p->ctx, a, stream);
+}
+
+extern "C" void f16_mpc_plan_destroy(f16_mpc_plan *p) {
+  if (!p) return;
+  (void)hipDeviceSynchronize();
+  (void)hipFree(p->buf);
+  delete p;
 }
 
 extern "C" int f16_mpc_qp_debug(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,

@@ -26,7 +26,9 @@ struct MpcArgs {
   double *ucmd, *useq, *info;
   int32_t *status;
   double *Ppk, *Apk;          // workspace [B][np] packed P and A'A
-  double *ext;                // workspace [B][mpc_ext_doubles(N)]: q | G | pred (setup kernel -> fast solver / debug)
+  double *ext;                // workspace [B][mpc_ext_doubles(N)]: q | G | pred | A | Q | Qbar | rho (setup kernel -> fast solver / debug)
+  double *tiles;              // prepared plans: [B][MPC_TILE_DOUBLES] KKT-inverse tiles in accumulator layout
+  int mode;                   // 0 one-shot; 1 prepare (build + factor, keep everything, no iterations); 2 solve from a plan
   long B, ld;
   int N;
   double dt;
@@ -34,8 +36,10 @@ struct MpcArgs {
 };
 
 
-// per-aircraft extras written by the setup kernel: q[n] | G[27N] | pred[9N]
-__host__ __device__ inline size_t mpc_ext_doubles(int N) { return (size_t)3 * N + 27 * N + 9 * N; }
+// per-aircraft extras written by the setup kernel: q[n] | G[27N] | pred[9N] | A[81] Q[81] Qbar[81] | rho, pad
+__host__ __device__ inline size_t mpc_ext_doubles(int N) { return (size_t)3 * N + 27 * N + 9 * N + 243 + 2; }
+__host__ __device__ inline size_t mpc_ext_model(int N) { return (size_t)3 * N + 27 * N + 9 * N; }      // offset of A | Q | Qbar | rho
+constexpr int MPC_TILE_DOUBLES = 6 * 6 * 4 * 64;   // six tile rows x six tiles x four accumulator registers x 64 lanes
 
 // f16_mpc_solve.hip
 constexpr int FAST_MAXN = 32;

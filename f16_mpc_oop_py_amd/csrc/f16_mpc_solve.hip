@@ -432,12 +432,14 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
       lo = ULB[sub]; hi = UUB[sub];
     } else if (kind == 3) {
       if (blk == 0) {
-        const double act = a.x[(13 + sub) * a.ld + b];
+        const double act = a.x ? a.x[(13 + sub) * a.ld + b] : 0.0;      // (no state when a plan is prepared)
         lo = act + RLB[sub] * a.dt; hi = act + RUB[sub] * a.dt;
       } else { lo = RLB[sub]; hi = RUB[sub]; }               // reference quirk: not scaled by dt (utils.py:151-152)
     }
     if (kind) *wdst = 0.0;                                     // w = rho z - y of the start point
-    double rho = a.s.rho;
+    double *const exm = const_cast<double *>(ex) + mpc_ext_model(N);      // A | Q | Qbar | rho of a prepared plan
+    double *const tl = a.tiles ? a.tiles + (size_t)b * MPC_TILE_DOUBLES + (size_t)(w * NT * 4) * 64 + l : nullptr;
+    double rho = a.mode == 2 ? exm[243] : a.s.rho;
     if (!(rho > 0.0)) {   // automatic: balance the two terms of P + rho A'A (our QP is not Ruiz-scaled as OSQP's would be)
       double tr[2] = {xown ? Pg[tri(xe, xe)] : 0.0, xown ? Ag[tri(xe, xe)] : 0.0};
       const bool sums[2] = {true, true};
@@ -448,6 +450,8 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
     double rp = INFINITY, rd = INFINITY;
     bool converged = false, infeasible = false, ok = true;
     bool done = a.s.max_iter < 0;                              // (max_iter == 0: factor only, used for timing)
+    bool from_plan = a.mode == 2;                              // first factorisation comes out of the plan
+    if (from_plan && !(exm[244] > 0.5)) ok = false;
 #ifdef F16_EXP_STAMPM
     unsigned long long tS[6] = {0, 0, 0, 0, 0, 0}, tP1 = 0, tP2 = 0, t0 = 0;
 #define MSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t1 = __builtin_amdgcn_s_memtime(); tS[i] += t1 - t0; t0 = t1; }
@@ -463,10 +467,28 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         __builtin_amdgcn_s_waitcnt(0);
         tP1 = __builtin_amdgcn_s_memtime();
 #endif
-        d4_t tmp[NT];                                          // the call hands the tiles over in memory: copy them into
-        ok = mfma_inverse<NTT>(tmp, Cs, Pg, Ag, rho, sigma, n) && ok;   // an array whose address never escapes
+        if (from_plan) {                                        // tiles [w][J][q][lane]: 512-byte runs per load
+          from_plan = false;
 #pragma unroll
-        for (int J = 0; J < NTT; ++J) acc[J] = tmp[J];
+          for (int J = 0; J < NTT; ++J)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) acc[J][qq] = w < NTT ? tl[(J * 4 + qq) * 64] : 0.0;
+        } else {
+          d4_t tmp[NT];                                        // the call hands the tiles over in memory: copy them into
+          ok = mfma_inverse<NTT>(tmp, Cs, Pg, Ag, rho, sigma, n) && ok;   // an array whose address never escapes
+#pragma unroll
+          for (int J = 0; J < NTT; ++J) acc[J] = tmp[J];
+          if (a.mode == 1) {                                   // prepare: keep the factorisation and its rho, no iterations
+            if (w < NTT) {
+#pragma unroll
+              for (int J = 0; J < NTT; ++J)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) tl[(J * 4 + qq) * 64] = acc[J][qq];
+            }
+            if (tid == 0) { exm[243] = rho; exm[244] = ok ? 1.0 : 0.0; }
+            done = true;
+          }
+        }
 #ifdef F16_EXP_STAMPM
         tP2 = __builtin_amdgcn_s_memtime();
         t0 = tP2;
@@ -617,6 +639,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
     }
 
     // res.x[0:3] (env.py:424); OSQP hands back NaN for a problem it certifies infeasible
+    if (a.mode == 1) return;                                   // a plan has no solution yet
     if (xown) {
       if (xe < 3) a.ucmd[xe * a.ld + b] = infeasible ? NAN : xs;
       if (a.useq) a.useq[xe * a.ld + b] = infeasible ? NAN : xs;

@@ -86,14 +86,16 @@ def or_status(status):
     return int(sum(int(b) << k for k, b in enumerate(t.tolist())))
 
 
-def closed_loop_mpc_rollout(env, steps, hzn, p_dem=0.0, q_dem=0.0, r_dem=0.0, traj_every=1, gather=True):
+def closed_loop_mpc_rollout(env, steps, hzn, p_dem=0.0, q_dem=0.0, r_dem=0.0, traj_every=1, gather=True, use_plan=True):
     """BASELINE config 5 / test_env.py:480-495 pattern on this rank's shard, then one all-gather:
     per step  cmd = calc_MPC_action(p,q,r,hzn); u.values[1:] = cmd; step(u.values).
+    use_plan: the model is frozen (env.py:49-60), so the model-only part of the QP is prepared once
+    (F16Batch.prepare_MPC) -- same commands bit for bit, about half the time per step.
     Returns the collated trajectory [steps//traj_every, 18, B_total] (or the local shard if gather=False)."""
     T = steps // traj_every
     traj = torch.empty((T, 18, env.B), dtype=torch.float64, device=env.device)
     for k in range(steps):
-        cmd = env._calc_MPC_action(p_dem, q_dem, r_dem, hzn)
+        cmd = env._calc_MPC_action(p_dem, q_dem, r_dem, hzn, use_plan=use_plan)
         env._u[1:4] = cmd.t()
         env.rollout(1)
         if (k + 1) % traj_every == 0:

@@ -247,6 +247,7 @@ class F16Batch:
 
     def build_ssr(self, eps=1e-5):
         """env.py:49-60: reduced discrete model per aircraft, frozen until called again."""
+        self.release_MPC_plan()                 # a new model invalidates a prepared plan
         self.linearise(eps)
         Ad, Bd = self.discretise()
         self.ssr = (Ad, Bd, self._lin[2])
@@ -271,7 +272,38 @@ class F16Batch:
         return -(K @ (x_ref - x).unsqueeze(-1)).squeeze(-1) + u0
 
     # ------------------------------------------------------------------ env.py:373-424
-    def _calc_MPC_action(self, p_dem, q_dem, r_dem, hzn, settings=None, return_info=False, relinearise=False):
+    def prepare_MPC(self, hzn, settings=None):
+        """Prepare the model-only part of calc_MPC_action for horizon hzn from the frozen reduced model self.ssr
+        (env.py:49-60 freezes it; the reference still rebuilds the QP on every call): DARE, terminal weight, prediction
+        blocks, P, A'A, start rho and the KKT factorisation stay on the device.  `_calc_MPC_action(..., use_plan=True)`
+        then only forms the state-dependent vectors and iterates; results are bit-identical to the one-shot call."""
+        if self.ssr is None:
+            self.build_ssr()
+        self.release_MPC_plan()
+        Ad, Bd, Cd = self.ssr
+        s = _lib.QPSettings()
+        self.lib.f16_qp_default_settings(ctypes.byref(s))
+        for k, v in (settings or {}).items():
+            setattr(s, k, v)
+        h = ctypes.c_void_p()
+        self._check(self.lib.f16_mpc_plan_create(self.ctx.handle, ctypes.byref(h), _vp(Ad), _vp(Bd), _vp(Cd), self.B, self.B,
+                                                 int(hzn), self.dt, ctypes.byref(s), self._stream))
+        self._plan, self._plan_hzn = h, int(hzn)
+        return self
+
+    def release_MPC_plan(self):
+        if getattr(self, "_plan", None) is not None:
+            self.lib.f16_mpc_plan_destroy(self._plan)
+        self._plan, self._plan_hzn = None, None
+
+    def __del__(self):
+        try:
+            self.release_MPC_plan()
+        except Exception:
+            pass
+
+    def _calc_MPC_action(self, p_dem, q_dem, r_dem, hzn, settings=None, return_info=False, relinearise=False,
+                         use_plan=False):
         """First MPC move [B,3] (dh,da,dr commands) for demands p,q,r (scalars or [B]) over horizon hzn, from the
         frozen reduced model self.ssr (env.py:385-387) and the current state.  The QP of utils.py:21-167 is solved
         on the GPU by OSQP-style ADMM (the reference calls the `osqp` package, env.py:420-422)."""
@@ -287,6 +319,17 @@ class F16Batch:
         info = torch.empty((4, self.B), dtype=torch.float64, device=self.device)
         useq = torch.empty((3 * hzn, self.B), dtype=torch.float64, device=self.device) if return_info else None
         st = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        if use_plan:
+            if relinearise or settings:
+                raise ValueError("a prepared plan fixes the model and the QP settings (prepare_MPC)")
+            if getattr(self, "_plan", None) is None or self._plan_hzn != int(hzn):
+                self.prepare_MPC(hzn)
+            self._check(self.lib.f16_mpc_plan_solve(self._plan, _vp(self._x), _vp(dem), _vp(ucmd), _vp(useq), _vp(info), _vp(st),
+                                                    self._stream))
+            self.last_status = st
+            if return_info:
+                return ucmd.t(), dict(iters=info[0], r_prim=info[1], r_dual=info[2], rho=info[3], u_seq=useq.t(), status=st)
+            return ucmd.t()
         s = _lib.QPSettings()
         self.lib.f16_qp_default_settings(ctypes.byref(s))
         for k, v in (settings or {}).items():

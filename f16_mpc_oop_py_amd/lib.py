@@ -94,6 +94,10 @@ def load():
         L.f16_mpc_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, l, l, i, d, ctypes.POINTER(QPSettings), vp]
         L.f16_mpc_qp_debug.argtypes = [vp, vp, vp, vp, vp, vp, l, l, i, d, vp, vp, vp, vp, vp]
         L.f16_debug_spd_inverse.argtypes = [vp, vp, vp, i, l, vp]
+        L.f16_mpc_plan_create.argtypes = [vp, ctypes.POINTER(vp), vp, vp, vp, l, l, i, d, ctypes.POINTER(QPSettings), vp]
+        L.f16_mpc_plan_solve.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+        L.f16_mpc_plan_destroy.argtypes = [vp]
+        L.f16_mpc_plan_destroy.restype = None
     _LIB = L
     return L
 

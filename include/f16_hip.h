@@ -131,6 +131,19 @@ void f16_qp_default_settings(f16_qp_settings *s);
 int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
                   const double *dem, double *u_cmd, double *u_seq, double *info, int32_t *status,
                   long B, long ld, int hzn, double dt, const f16_qp_settings *s, void *stream);
+/* Prepared plans.  The reference freezes (Ad,Bd,Cd) at construction (env.py:49-60) yet rebuilds the whole QP on every
+ * _calc_MPC_action call (utils.py:21-167 inside env.py:373-424).  A plan computes the model-only part once -- DARE,
+ * terminal weight, prediction blocks, P, A'A, the start value of rho and the factorisation of the KKT matrix (kept as
+ * matrix-core accumulator tiles, 73.7 KB per aircraft) -- and f16_mpc_plan_solve does what is left per call: the
+ * state-dependent vectors and the ADMM iterations.  Results are bit-identical to f16_mpc_batch with the same
+ * settings.  hzn <= 32.  (Ad,Bd,Cd) are read during f16_mpc_plan_create only. */
+typedef struct f16_mpc_plan f16_mpc_plan;
+int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const double *Ad, const double *Bd, const double *Cd,
+                        long B, long ld, int hzn, double dt, const f16_qp_settings *s, void *stream);
+int f16_mpc_plan_solve(f16_mpc_plan *plan, const double *x, const double *dem, double *u_cmd, double *u_seq,
+                       double *info, int32_t *status, void *stream);
+void f16_mpc_plan_destroy(f16_mpc_plan *plan);
+
 /* utils.py:21-167 setup_OSQP alone for aircraft b (tests): h_P[n*n] h_q[n] h_A[(m rows)*n] h_l h_u on the
  * host, n = 3*hzn, rows = 15*hzn, reference row order. */
 int f16_mpc_qp_debug(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,

@@ -318,3 +318,32 @@ def test_mpc_full_size_properties():
     env3.build_ssr()
     u3 = env3._calc_MPC_action(0.0, 0.0, 0.0, N, settings=dict(max_iter=-40000)).cpu().numpy()
     assert np.abs(u3 - u[idx]).max() < 2e-3
+
+
+@pytest.mark.parametrize("N", [10, 30])
+def test_prepared_plan_is_bit_identical_and_closed_loop(N):
+    """f16_mpc_plan_*: the model-only part of calc_MPC_action prepared once (the reference freezes the model,
+    env.py:49-60) -- commands, iteration counts and residuals equal the one-shot call bit for bit, also after the state
+    has moved; a closed loop driven through the plan equals the one driven through one-shot calls."""
+    from f16_mpc_oop_py_amd.workload import config4_states
+    from f16_mpc_oop_py_amd import dist as fdist
+    x0, u0 = config4_states(300, seed=11)
+    env = make_env(x0, u0, xcg=0.35)
+    env.build_ssr()
+    dem = (0.03, -0.01, 0.02)
+    u1, i1 = env._calc_MPC_action(*dem, N, return_info=True)
+    env.prepare_MPC(N)
+    u2, i2 = env._calc_MPC_action(*dem, N, return_info=True, use_plan=True)
+    assert torch.equal(u1, u2) and torch.equal(i1["iters"], i2["iters"]) and torch.equal(i1["u_seq"], i2["u_seq"])
+    assert torch.equal(i1["r_prim"], i2["r_prim"]) and torch.equal(i1["rho"], i2["rho"])
+    env.rollout(25)                                            # move the state, keep the plan
+    u3 = env._calc_MPC_action(*dem, N)
+    u4 = env._calc_MPC_action(*dem, N, use_plan=True)
+    assert torch.equal(u3, u4)
+    with pytest.raises(ValueError):
+        env._calc_MPC_action(*dem, N, use_plan=True, settings=dict(max_iter=50))
+    ea = make_env(x0[:64], u0[:64], xcg=0.35); ea.build_ssr()
+    eb = make_env(x0[:64], u0[:64], xcg=0.35); eb.build_ssr()
+    ta = fdist.closed_loop_mpc_rollout(ea, steps=8, hzn=N, gather=False, use_plan=False)
+    tb = fdist.closed_loop_mpc_rollout(eb, steps=8, hzn=N, gather=False, use_plan=True)
+    assert torch.equal(ta, tb)
