@@ -898,8 +898,10 @@ struct f16_mpc_plan {
 
 static int plan_launch_build(f16_mpc_plan *p, MpcArgs &a, void *stream) {
   const size_t lds = mpc_lds_doubles(p->N, true) * sizeof(double);
-  if (int rc = hip_check(hipFuncSetAttribute((const void *)k_mpc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"))
-    return rc;
+  if (a.mode == 1) {      // once, when the plan is created (the solve path may run under stream capture)
+    if (int rc = hip_check(hipFuncSetAttribute((const void *)k_mpc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"))
+      return rc;
+  }
   hipLaunchKernelGGL(k_mpc<true>, dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
   return hip_check(hipGetLastError(), "f16_mpc_plan build launch");
 }

@@ -90,12 +90,17 @@ def closed_loop_mpc_rollout(env, steps, hzn, p_dem=0.0, q_dem=0.0, r_dem=0.0, tr
     """BASELINE config 5 / test_env.py:480-495 pattern on this rank's shard, then one all-gather:
     per step  cmd = calc_MPC_action(p,q,r,hzn); u.values[1:] = cmd; step(u.values).
     use_plan: the model is frozen (env.py:49-60), so the model-only part of the QP is prepared once
-    (F16Batch.prepare_MPC) -- same commands bit for bit, about half the time per step.
+    (F16Batch.prepare_MPC) -- same commands bit for bit, about two thirds of the time per step.
+    (A HIP-graph replay of the step was measured and is SLOWER than the six eager launches on ROCm 7.2: 0.50 vs
+    0.19 ms per step at B = 256, 3.36 vs 3.15 ms at B = 8192 -- the step is kept capture-safe but launched eagerly.)
     Returns the collated trajectory [steps//traj_every, 18, B_total] (or the local shard if gather=False)."""
     T = steps // traj_every
     traj = torch.empty((T, 18, env.B), dtype=torch.float64, device=env.device)
+    dem = torch.empty((3, env.B), dtype=torch.float64, device=env.device)      # demands on the device once
+    for k, v in enumerate((p_dem, q_dem, r_dem)):
+        dem[k] = torch.as_tensor(v, dtype=torch.float64, device=env.device)
     for k in range(steps):
-        cmd = env._calc_MPC_action(p_dem, q_dem, r_dem, hzn, use_plan=use_plan)
+        cmd = env._calc_MPC_action(dem, None, None, hzn, use_plan=use_plan)
         env._u[1:4] = cmd.t()
         env.rollout(1)
         if (k + 1) % traj_every == 0:

@@ -312,9 +312,12 @@ class F16Batch:
         if self.ssr is None or relinearise:
             self.build_ssr()
         Ad, Bd, Cd = self.ssr
-        dem = torch.empty((3, self.B), dtype=torch.float64, device=self.device)
-        for k, v in enumerate((p_dem, q_dem, r_dem)):
-            dem[k] = torch.as_tensor(v, dtype=torch.float64, device=self.device)
+        if torch.is_tensor(p_dem) and p_dem.dim() == 2:       # demands already on the device as [3,B] (graph capture)
+            dem = p_dem
+        else:
+            dem = torch.empty((3, self.B), dtype=torch.float64, device=self.device)
+            for k, v in enumerate((p_dem, q_dem, r_dem)):
+                dem[k] = torch.as_tensor(v, dtype=torch.float64, device=self.device)
         ucmd = torch.empty((3, self.B), dtype=torch.float64, device=self.device)
         info = torch.empty((4, self.B), dtype=torch.float64, device=self.device)
         useq = torch.empty((3 * hzn, self.B), dtype=torch.float64, device=self.device) if return_info else None
