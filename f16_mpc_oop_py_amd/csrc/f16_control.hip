@@ -826,7 +826,7 @@ extern "C" int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, c
 
 extern "C" void f16_qp_default_settings(f16_qp_settings *s) {
   // OSQP defaults with the deterministic schedule of SURVEY.md 8(d) config 4
-  s->rho = 0.0;   // 0 = automatic sqrt(tr P / tr A'A) (OSQP's 0.1 presumes its Ruiz scaling); > 0 = fixed start value
+  s->rho = 0.0;   // 0 = automatic 2 sqrt(tr P / tr A'A) (OSQP's 0.1 presumes its Ruiz scaling); > 0 = fixed start value
   s->sigma = 1e-6; s->alpha = 1.6; s->eps_abs = 1e-3; s->eps_rel = 1e-3; s->eps_prim_inf = 1e-4;
   s->max_iter = 40000;            // env.py:421
   s->check_every = 25; s->rho_every = 100; s->adaptive_rho = 1;

@@ -121,7 +121,7 @@ int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double
 /* env.py:373-424 _calc_MPC_action for B aircraft: per aircraft (Ad,Bd,Cd) + current state x[18][ld]
  * + demands dem[3][ld] (p,q,r; written to x_ref[5:8] exactly as the reference does) -> first move
  * u_cmd[3][ld].  Dense condensed QP of horizon hzn (utils.py:21-167) solved by OSQP-style ADMM with the
- * settings in f16_qp_settings (rho = 0 selects the automatic start value sqrt(tr P / tr A'A)).  u_seq (may be NULL) gets the full [3*hzn][ld] sequence,
+ * settings in f16_qp_settings (rho = 0 selects the automatic start value 2 sqrt(tr P / tr A'A)).  u_seq (may be NULL) gets the full [3*hzn][ld] sequence,
  * info (may be NULL) gets [4][ld] = iterations, r_prim, r_dual, rho. */
 typedef struct f16_qp_settings {
   double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf;
