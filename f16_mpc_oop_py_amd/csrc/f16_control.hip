@@ -458,11 +458,14 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
   const int r0 = SETUP_ONLY ? max(54 * N, 1100) : max(max(np, 54 * N), 1100);
   double *Minv = al.take(r0);
   double *G = al.take(N * 27);
-  double *A = al.take(81), *Bm = al.take(27), *Q = al.take(81), *Qb = al.take(81), *K = al.take(27);
-  double *xs = al.take(n), *xt = al.take(n), *rhs = al.take(n), *qv = al.take(n), *tv = al.take(n);
-  double *wbuf = al.take(m);
+  double *A = al.take(81), *Q = al.take(81), *Qb = al.take(81);
+  double *qv = al.take(n);
+  double *wbuf = al.take(SETUP_ONLY ? 9 * N : m);
   double *pred = al.take(9 * N);      // MM x: A^(i+1) x
+  double *Bm = pred;                  // B is dead once G_0 is copied out, before pred is first written
   double *x9 = al.take(9), *xref = al.take(9);
+  double *xs = nullptr, *xt = nullptr, *rhs = nullptr, *tv = nullptr;      // generic solver only
+  if (!SETUP_ONLY) { xs = al.take(n); xt = al.take(n); rhs = al.take(n); tv = al.take(n); }
   double *scr = Minv, *X = Minv + 760;                  // DARE scratch (748 doubles), then X (82)
   double *QG = Minv, *QbG = Minv + N * 27;
 
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
     __syncthreads();
     if (!update_only) {
     dare_sda_wave(A, Bm, Q, X, scr);
-    lqr_gain_wave(A, Bm, X, K, scr);                  // K_dlqr; the reference uses K = -dlqr (utils.py:96)
+    // (the gain K = -dlqr of utils.py:96 is not needed itself: it only enters through Q_bar)
     // Q_bar (utils.py:100) solves X = Phi' X Phi + Q + K'RK with Phi = A + B K: for the LQR gain K that equation IS the
     // DARE, so its solution is the DARE solution X itself.  (Measured on the reference's trim models: SDA's X agrees
     // with scipy.linalg.solve_discrete_lyapunov's Q_bar to 3e-13 relative -- closer than scipy's own DARE result.)
@@ -756,7 +759,7 @@ static size_t mpc_lds_doubles(int N, bool setup_only) {
   auto ev = [](int v) { return (size_t)((v + 1) & ~1); };
   int r0 = (!setup_only && np > 54 * N) ? np : 54 * N;
   if (r0 < 1100) r0 = 1100;
-  return ev(r0) + ev(N * 27) + ev(81) * 3 + ev(27) * 2 + ev(n) * 5 + ev(m) + ev(9 * N) + ev(9) * 2;
+  return ev(r0) + ev(N * 27) + ev(81) * 3 + ev(n) + ev(setup_only ? 9 * N : m) + ev(9 * N) + ev(9) * 2 + (setup_only ? 0 : 4 * ev(n));
 }
 
 }  // namespace f16
