@@ -61,6 +61,9 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], const bool (&is_su
 // B operand: lane l -> B[l/16][l%16].  The four pivot rows of a block step are therefore ONE accumulator register
 // (q = p%4) across the whole wave.
 typedef double d4_t __attribute__((ext_vector_type(4)));
+#ifdef F16_EXP_STAMPM
+__device__ double g_inv_stamp[16];      // diagnostic build: per-wave work / barrier-wait cycles of the factorisation
+#endif
 constexpr int NT = FN / 16;   // 6 tile rows / columns
 
 // 1/x to <= 1 ulp without the division sequence (v_rcp_f64 + two Newton steps); x is a positive, normal pivot minor
@@ -244,16 +247,33 @@ __device__ F16_INV_ATTR bool mfma_inverse(d4_t *acc_out, double *Cs, const doubl
     for (int J = 0; J < NTT; ++J) c0[(16 * J + lc) * 4 + lq] = acc[J][0];
     publish_dinv(c0, 0, l);
   }
+#ifdef F16_EXP_STAMPM
+  unsigned long long tw = 0, tb = 0, ts0 = __builtin_amdgcn_s_memtime();
+#define ISTAMP(acc_) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t1_ = __builtin_amdgcn_s_memtime(); acc_ += t1_ - ts0; ts0 = t1_; }
+#else
+#define ISTAMP(acc_)
+#endif
   for (int Kt = 0; Kt < NTT; ++Kt) {
     __syncthreads();
+    ISTAMP(tb)
     if (w < NTT) inverse_step<NTT, 0>(acc, c0, c1, Kt, w, lc, lq, ok);
+    ISTAMP(tw)
     __syncthreads();
+    ISTAMP(tb)
     if (w < NTT) inverse_step<NTT, 1>(acc, c1, c0, Kt, w, lc, lq, ok);
+    ISTAMP(tw)
     __syncthreads();
+    ISTAMP(tb)
     if (w < NTT) inverse_step<NTT, 2>(acc, c0, c1, Kt, w, lc, lq, ok);
+    ISTAMP(tw)
     __syncthreads();
+    ISTAMP(tb)
     if (w < NTT) inverse_step<NTT, 3>(acc, c1, c0, Kt, w, lc, lq, ok);
+    ISTAMP(tw)
   }
+#ifdef F16_EXP_STAMPM
+  if (blockIdx.x == 0 && l == 0) { g_inv_stamp[2 * w] = (double)tw; g_inv_stamp[2 * w + 1] = (double)tb; }
+#endif
 #pragma unroll
   for (int J = 0; J < NTT; ++J) acc_out[J] = acc[J];
   return __syncthreads_and(ok) != 0;      // uniform over the workgroup (only the tile-row waves looked at pivots)
@@ -658,6 +678,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
     __syncthreads();      // diagnostic build: aircraft 0's u_seq column is replaced by the stamps
     if ((tid & 63) == 0 && a.useq && b == 0) for (int i = 0; i < 6; ++i) a.useq[(6 * (tid >> 6) + i) * a.ld] = (double)tS[i] / it;
     if (tid == 0 && a.useq && b == 0) { a.useq[48 * a.ld] = (double)(tP1 - tP0); a.useq[49 * a.ld] = (double)(tP2 - tP1); }
+    if (tid < 16 && a.useq && b == 0) a.useq[(50 + tid) * a.ld] = g_inv_stamp[tid];
 #endif
   }
 }

@@ -16,4 +16,5 @@ s = info["u_seq"][0, :48].cpu().numpy().reshape(8, 6)      # aircraft 0 column h
 np.set_printoptions(linewidth=200, precision=0, suppress=True)
 print("cycles per iteration, rows = waves, cols = A, bar1, B, bar2, C, bar3 (s_memtime ticks @100MHz => x24 for 2.4GHz)")
 print(s, s.sum(1))
+print("factorisation, per wave (work, barrier wait) cycles:", info["u_seq"][0, 50:66].cpu().numpy().reshape(8, 2))
 print("prologue (loads, rho) / inverse cycles:", info["u_seq"][0, 48:50].cpu().numpy())
