@@ -300,19 +300,23 @@ __global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
 //                                                                                            | force equations, Euler
 //   wave 3  x[12..17] atmosphere; the four actuators on sub-lanes 0..3; flap model (Euler)
 // Owned states are replicated over the sub-lanes of their wave; two barriers per step as in k_rollout_4w.
-__global__ __launch_bounds__(256) void k_rollout_q(DynArgs a) {
+// GROUPS = 2 (4096 < B <= 8192): two independent 16-aircraft groups per workgroup share the LDS table image, one role
+// wave of each on every SIMD -- the two dependency chains interleave.
+template <int GROUPS>
+__global__ __launch_bounds__(256 * GROUPS) void k_rollout_q(DynArgs a) {
+  constexpr int NA = 16 * GROUPS;
   __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
-  __shared__ double xs[18][16], xt[11][16];                // published state; Cx Cz Cm | Cy Cn Cl static | qbar ps | Cy Cn Cl damping
-  __shared__ int xenv[3][16], xst[2][16];
+  __shared__ double xs[18][NA], xt[11][NA];                // published state; Cx Cz Cm | Cy Cn Cl static | qbar ps | Cy Cn Cl damping
+  __shared__ int xenv[3][NA], xst[2][NA];
   {
     const double2 *src = reinterpret_cast<const double2 *>(a.tab);
     double2 *dst = reinterpret_cast<double2 *>(tab);
-    for (int i = threadIdx.x; i < TABLE_IMAGE_DOUBLES / 2; i += 256) dst[i] = src[i];
+    for (int i = threadIdx.x; i < TABLE_IMAGE_DOUBLES / 2; i += 256 * GROUPS) dst[i] = src[i];
     __syncthreads();
   }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, ac = lane >> 2, s = lane & 3;
+  const int wave = (threadIdx.x >> 6) & 3, grp = threadIdx.x >> 8, lane = threadIdx.x & 63, ac = 16 * grp + (lane >> 2), s = lane & 3;
   const bool envchk = !(a.flags & FLAG_NO_ENVELOPE);
-  for (long b0 = (long)blockIdx.x * 16; b0 < a.B; b0 += (long)gridDim.x * 16) {
+  for (long b0 = (long)blockIdx.x * NA; b0 < a.B; b0 += (long)gridDim.x * NA) {
     const bool valid = b0 + ac < a.B;
     const long b = valid ? b0 + ac : a.B - 1;              // ragged tail: shadow the last aircraft, never stored
     double x[18];
@@ -629,10 +633,16 @@ extern "C" int f16_rollout(f16_ctx *ctx, double *x, const double *u, double *tra
   static const long max4w = [] { const char *e = getenv("F16_ROLLOUT_4W_MAXB"); return e ? atol(e) : 64L * 256; }();
   static const long maxq = [] { const char *e = getenv("F16_ROLLOUT_QUAD_MAXB"); return e ? atol(e) : 16L * 256; }();
   if (fi_flag == 1 && B <= maxq) {
-    // fewer aircraft than 16 per CU: four lanes per aircraft, one 16-aircraft workgroup per CU
-    hipLaunchKernelGGL(k_rollout_q, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a);
+    // at most 16 aircraft per CU: four lanes per aircraft, one 16-aircraft workgroup per CU
+    hipLaunchKernelGGL(k_rollout_q<1>, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a);
     return hip_check(hipGetLastError(), "f16_rollout launch");
   }
+  if (fi_flag == 1 && B <= 2 * maxq) {
+    // at most 32 per CU: two 16-aircraft groups per workgroup
+    hipLaunchKernelGGL(k_rollout_q<2>, dim3((unsigned)((B + 31) / 32)), dim3(512), 0, (hipStream_t)stream, a);
+    return hip_check(hipGetLastError(), "f16_rollout launch");
+  }
+  // (three groups per workgroup leave 168 registers per lane: the roles spill, 3.96 ms against the 4-wave kernel's 2.13)
   if (fi_flag == 1 && B <= max4w) {
     // latency regime: four wavefronts per 64 aircraft, one workgroup per CU
     hipLaunchKernelGGL(k_rollout_4w, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a);
