@@ -896,6 +896,8 @@ struct f16_mpc_plan {
   double dt;
   f16_qp_settings s;
   double *buf;
+  double *warm;        // x, z, y of the previous solve (allocated when warm start is switched on)
+  bool warm_on, have_prev;
   MpcArgs a;
 };
 
@@ -915,6 +917,7 @@ extern "C" int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const doub
   if (hzn < 1 || hzn > FAST_MAXN) return set_error(F16_EINVAL, "prepared plans need 1 <= hzn <= 32");
   f16_mpc_plan *p = new f16_mpc_plan();
   p->ctx = ctx; p->B = B; p->ld = ld; p->N = hzn; p->dt = dt;
+  p->warm = nullptr; p->warm_on = false; p->have_prev = false;
   if (s) p->s = *s; else f16_qp_default_settings(&p->s);
   if (p->s.check_every < 1 || p->s.rho_every < 1 || !(p->s.rho >= 0) || !(p->s.sigma > 0) || p->s.max_iter < 1) {
     delete p;
@@ -943,14 +946,29 @@ extern "C" int f16_mpc_plan_solve(f16_mpc_plan *p, const double *x, const double
   MpcArgs a = p->a;
   a.x = x; a.dem = dem; a.ucmd = u_cmd; a.useq = u_seq; a.info = info; a.status = status;
   a.mode = 2;
+  a.warm = p->warm_on ? p->warm : nullptr;
+  a.warm_load = p->warm_on && p->have_prev;
   if (int rc = plan_launch_build(p, a, stream)) return rc;
-  return mpc_fast_solve_launch(p->ctx, a, stream);
+  if (int rc = mpc_fast_solve_launch(p->ctx, a, stream)) return rc;
+  p->have_prev = p->warm_on;
+  return F16_OK;
+}
+
+extern "C" int f16_mpc_plan_warm_start(f16_mpc_plan *p, int on) {
+  if (!p) return set_error(F16_EINVAL, "bad argument to f16_mpc_plan_warm_start");
+  if (on && !p->warm) {
+    if (int rc = hip_check(hipMalloc(&p->warm, (size_t)p->B * MPC_WARM_DOUBLES * sizeof(double)), "hipMalloc warm start")) return rc;
+  }
+  p->warm_on = on != 0;
+  p->have_prev = false;
+  return F16_OK;
 }
 
 extern "C" void f16_mpc_plan_destroy(f16_mpc_plan *p) {
   if (!p) return;
   (void)hipDeviceSynchronize();
   (void)hipFree(p->buf);
+  if (p->warm) (void)hipFree(p->warm);
   delete p;
 }
 

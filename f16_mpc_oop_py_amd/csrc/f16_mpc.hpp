@@ -29,6 +29,8 @@ struct MpcArgs {
   double *ext;                // workspace [B][mpc_ext_doubles(N)]: q | G | pred | A | Q | Qbar | rho (setup kernel -> fast solver / debug)
   double *tiles;              // prepared plans: [B][MPC_TILE_DOUBLES] KKT-inverse tiles in accumulator layout
   int mode;                   // 0 one-shot; 1 prepare (build + factor, keep everything, no iterations); 2 solve from a plan
+  double *warm;               // plans with warm start: [B][MPC_WARM_DOUBLES] x, z, y of the previous solve (per lane)
+  int warm_load;              // start from them (else from zero, as the reference's fresh OSQP object does)
   long B, ld;
   int N;
   double dt;
@@ -39,6 +41,7 @@ struct MpcArgs {
 // per-aircraft extras written by the setup kernel: q[n] | G[27N] | pred[9N] | A[81] Q[81] Qbar[81] | rho, pad
 __host__ __device__ inline size_t mpc_ext_doubles(int N) { return (size_t)3 * N + 27 * N + 9 * N + 243 + 2; }
 __host__ __device__ inline size_t mpc_ext_model(int N) { return (size_t)3 * N + 27 * N + 9 * N; }      // offset of A | Q | Qbar | rho
+constexpr int MPC_WARM_DOUBLES = 3 * 512;
 constexpr int MPC_TILE_DOUBLES = 6 * 6 * 4 * 64;   // six tile rows x six tiles x four accumulator registers x 64 lanes
 
 // f16_mpc_solve.hip

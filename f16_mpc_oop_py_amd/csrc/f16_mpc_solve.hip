@@ -456,10 +456,15 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         lo = act + RLB[sub] * a.dt; hi = act + RUB[sub] * a.dt;
       } else { lo = RLB[sub]; hi = RUB[sub]; }               // reference quirk: not scaled by dt (utils.py:151-152)
     }
-    if (kind) *wdst = 0.0;                                     // w = rho z - y of the start point
+    double *const wm = a.warm ? a.warm + (size_t)b * MPC_WARM_DOUBLES + tid : nullptr;
+    if (wm && a.warm_load) {                                   // warm start: x, z, y of the previous solve of this plan
+      const double x0 = wm[0], z0 = wm[FT], y0 = wm[2 * FT];
+      if (isfinite(x0) && isfinite(z0) && isfinite(y0)) { xs = x0; z = z0; y = y0; }
+    }
     double *const exm = const_cast<double *>(ex) + mpc_ext_model(N);      // A | Q | Qbar | rho of a prepared plan
     double *const tl = a.tiles ? a.tiles + (size_t)b * MPC_TILE_DOUBLES + (size_t)(w * NT * 4) * 64 + l : nullptr;
     double rho = a.mode == 2 ? exm[243] : a.s.rho;
+    if (kind) *wdst = (a.mode == 2 ? rho : 0.0) * z - y;       // w = rho z - y of the start point (zero unless warm)
     if (!(rho > 0.0)) {   // automatic: balance the two terms of P + rho A'A (our QP is not Ruiz-scaled as OSQP's would be)
       double tr[2] = {xown ? Pg[tri(xe, xe)] : 0.0, xown ? Ag[tri(xe, xe)] : 0.0};
       const bool sums[2] = {true, true};
@@ -660,6 +665,10 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
 
     // res.x[0:3] (env.py:424); OSQP hands back NaN for a problem it certifies infeasible
     if (a.mode == 1) return;                                   // a plan has no solution yet
+    if (wm) {                                                  // keep the solution for the next warm start
+      const bool good = converged && !infeasible;
+      wm[0] = good ? xs : NAN; wm[FT] = good ? z : NAN; wm[2 * FT] = good ? y : NAN;
+    }
     if (xown) {
       if (xe < 3) a.ucmd[xe * a.ld + b] = infeasible ? NAN : xs;
       if (a.useq) a.useq[xe * a.ld + b] = infeasible ? NAN : xs;

@@ -272,7 +272,7 @@ class F16Batch:
         return -(K @ (x_ref - x).unsqueeze(-1)).squeeze(-1) + u0
 
     # ------------------------------------------------------------------ env.py:373-424
-    def prepare_MPC(self, hzn, settings=None):
+    def prepare_MPC(self, hzn, settings=None, warm_start=False):
         """Prepare the model-only part of calc_MPC_action for horizon hzn from the frozen reduced model self.ssr
         (env.py:49-60 freezes it; the reference still rebuilds the QP on every call): DARE, terminal weight, prediction
         blocks, P, A'A, start rho and the KKT factorisation stay on the device.  `_calc_MPC_action(..., use_plan=True)`
@@ -289,6 +289,8 @@ class F16Batch:
         self._check(self.lib.f16_mpc_plan_create(self.ctx.handle, ctypes.byref(h), _vp(Ad), _vp(Bd), _vp(Cd), self.B, self.B,
                                                  int(hzn), self.dt, ctypes.byref(s), self._stream))
         self._plan, self._plan_hzn = h, int(hzn)
+        if warm_start:      # OSQP's in-object default; the reference starts cold on every call (new object), so: opt-in
+            self._check(self.lib.f16_mpc_plan_warm_start(h, 1))
         return self
 
     def release_MPC_plan(self):

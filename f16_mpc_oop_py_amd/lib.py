@@ -96,6 +96,7 @@ def load():
         L.f16_debug_spd_inverse.argtypes = [vp, vp, vp, i, l, vp]
         L.f16_mpc_plan_create.argtypes = [vp, ctypes.POINTER(vp), vp, vp, vp, l, l, i, d, ctypes.POINTER(QPSettings), vp]
         L.f16_mpc_plan_solve.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+        L.f16_mpc_plan_warm_start.argtypes = [vp, i]
         L.f16_mpc_plan_destroy.argtypes = [vp]
         L.f16_mpc_plan_destroy.restype = None
     _LIB = L

@@ -142,6 +142,11 @@ int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const double *Ad, con
                         long B, long ld, int hzn, double dt, const f16_qp_settings *s, void *stream);
 int f16_mpc_plan_solve(f16_mpc_plan *plan, const double *x, const double *dem, double *u_cmd, double *u_seq,
                        double *info, int32_t *status, void *stream);
+/* Optional: start each solve of the plan from the previous solve's x, z, y (what OSQP does by default inside ONE
+ * solver object; the reference builds a new object per call, i.e. always starts cold -- so this is off by default and
+ * results then differ from the cold start within the termination tolerance).  Switching it on or off forgets the
+ * stored solution; a solve that did not converge is not reused. */
+int f16_mpc_plan_warm_start(f16_mpc_plan *plan, int on);
 void f16_mpc_plan_destroy(f16_mpc_plan *plan);
 
 /* utils.py:21-167 setup_OSQP alone for aircraft b (tests): h_P[n*n] h_q[n] h_A[(m rows)*n] h_l h_u on the

@@ -347,3 +347,26 @@ def test_prepared_plan_is_bit_identical_and_closed_loop(N):
     ta = fdist.closed_loop_mpc_rollout(ea, steps=8, hzn=N, gather=False, use_plan=False)
     tb = fdist.closed_loop_mpc_rollout(eb, steps=8, hzn=N, gather=False, use_plan=True)
     assert torch.equal(ta, tb)
+
+
+def test_plan_warm_start_closed_loop():
+    """Opt-in warm start of a prepared plan (OSQP's in-object default; the reference always starts cold): the closed
+    loop stays within solver tolerance of the cold-started one and needs fewer iterations per step."""
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(256, seed=3)
+    runs = {}
+    for warm in (False, True):
+        env = make_env(x0, u0, xcg=0.35)
+        env.build_ssr()
+        env.prepare_MPC(30, warm_start=warm)
+        its = []
+        for _ in range(12):
+            cmd, info = env._calc_MPC_action(0.0, 0.0, 0.0, 30, return_info=True, use_plan=True)
+            assert int(info["status"].max()) == 0
+            its.append(float(info["iters"].mean()))
+            env._u[1:4] = cmd.t()
+            env.rollout(1)
+        runs[warm] = (env.x_values.cpu().numpy(), np.array(its))
+    assert runs[True][1][0] == runs[False][1][0]                # the first solve has nothing to start from
+    assert runs[True][1][1:].mean() < 0.8 * runs[False][1][1:].mean()
+    assert np.abs(runs[True][0] - runs[False][0]).max() < 1e-2 * max(1.0, np.abs(runs[False][0]).max()) * 1e-2 + 5e-3
