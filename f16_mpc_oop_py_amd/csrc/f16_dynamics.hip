@@ -533,15 +533,16 @@ __global__ __launch_bounds__(BLOCK) void k_xdot_na(DynArgs a) {
 
 // ------------------------------------------------------------------------------------ launchers
 // One lane per aircraft; with the table image in LDS a CU holds one workgroup, so the workgroup size decides how many
-// waves share a SIMD.  hifi: the plant wants ~256 VGPRs, and at two waves per SIMD (512-lane workgroups, 256 unified
-// registers each) the allocator falls back to AGPR spill moves -- measured 5.7 G steps/s against 14-16 G steps/s with
-// ONE wave per SIMD (256 lanes) at B >= 131,072 -- so hifi never exceeds 256 lanes; lofi (small plant) gains from 512.
+// waves share a SIMD: fill all 256 CUs first (64 / 128 / 256 lanes), then two waves per SIMD (512 lanes) from 131,072
+// aircraft on -- the phased lookups (aero_totals_phased) keep a hifi step inside 256 registers there; measured with
+// every step stored: 15.8 (256 lanes) vs 17.1 (512) G steps/s at B = 262,144, 17.9 vs 21.5 at B = 1,048,576.
 struct Geometry { int block, grid; };
 static Geometry geometry(long B, int fi) {
   Geometry g;
+  (void)fi;
   if (B <= 64L * 256) g.block = 64;          // <= 256 one-wave workgroups: one per CU
   else if (B <= 128L * 256) g.block = 128;   // fill all 256 CUs before stacking waves on a CU
-  else if (B <= 256L * 256 || fi == 1) g.block = 256;   // one wave per SIMD
+  else if (B < 512L * 256) g.block = 256;    // one wave per SIMD
   else g.block = 512;                        // two waves per SIMD
   static const int force = [] { const char *e = getenv("F16_DYN_BLOCK"); return e ? atoi(e) : 0; }();   // tuning knob
   if (force == 64 || force == 128 || force == 256 || force == 512) g.block = force;

@@ -296,6 +296,183 @@ F16_DEV void aero_hifi(TP T, double alpha, double beta, double el, unsigned flag
   c.eta_el = lerp(T[OFF_ETA + d1.j], T[OFF_ETA + d1.j + 1], d1);
 }
 
+// ---- lookups in scheduling phases (k_rollout_q; optional for the one-lane kernels).  With one wavefront per SIMD nothing hides an LDS round trip, and left to
+// itself the compiler emits the lookups in source order (read four corners, wait, interpolate, next table: ~14 dependent
+// round trips per role).  Here: (1) ALL breakpoint reads, (2) cell indices -> ALL table-corner reads, with the
+// lambda divisions issued behind them, (3) the interpolation arithmetic.  Two round trips per role.
+struct BrRaw { double lo, hi, xm, xg, xg1, xp; int g; };
+template <typename TP>
+F16_DEV BrRaw br_load(TP X, int n, int guess) {                 // the six reads of bracket()
+  BrRaw r;
+  r.g = min(max(guess, 0), n - 2);
+  r.lo = X[0]; r.hi = X[n - 1];
+  r.xm = X[max(r.g - 1, 0)]; r.xg = X[r.g]; r.xg1 = X[r.g + 1]; r.xp = X[min(r.g + 2, n - 1)];
+  return r;
+}
+struct BrCell { int j; double v, x0, x1; };
+F16_DEV BrCell br_cell(const BrRaw &r, int n, double v, bool &off) {   // bracket(): clamp, cell fix-up
+  off = !(v >= r.lo && v <= r.hi);
+  v = fmin(fmax(v, r.lo), r.hi);
+  const bool down = r.g > 0 && v < r.xg, up = r.g < n - 2 && v >= r.xg1;
+  BrCell c;
+  c.j = r.g - (down ? 1 : 0) + (up ? 1 : 0);
+  c.v = v;
+  c.x0 = down ? r.xm : (up ? r.xg1 : r.xg);
+  c.x1 = down ? r.xg : (up ? r.xp : r.xg1);
+  return c;
+}
+F16_DEV Axis br_axis(const BrCell &c) {                          // lambda = (v - X[j]) / (X[j+1] - X[j]), mexndinterp.c:196
+  Axis a;
+  a.j = c.j;
+#ifdef F16_FAST_DIV
+  a.l = (c.v - c.x0) * f16_rcp(c.x1 - c.x0);
+#else
+  a.l = (c.v - c.x0) / (c.x1 - c.x0);
+#endif
+  a.m = 1 - a.l;
+  return a;
+}
+struct Q4 { double f00, f10, f01, f11; };                        // corners (a,b), (a+1,b), (a,b+1), (a+1,b+1)
+template <typename TP>
+F16_DEV Q4 ld4(TP p, int sa, int sb) { Q4 c; c.f00 = p[0]; c.f10 = p[sa]; c.f01 = p[sb]; c.f11 = p[sb + sa]; return c; }
+F16_DEV double bil4(const Q4 &c, const Axis &a, const Axis &b) {   // alpha collapsed first, then beta (mexndinterp.c:178-209)
+  return lerp(lerp(c.f00, c.f10, a), lerp(c.f01, c.f11, a), b);
+}
+#ifndef F16_PHASE_MASK
+#define F16_PHASE_MASK 0x7        // LDS / memory instructions stay in their phase, ALU instructions may float (2 % over 0)
+#endif
+#define F16_PHASE() __builtin_amdgcn_sched_barrier(F16_PHASE_MASK)
+
+F16_DEV int alpha_guess(double alpha) { return (int)((fmin(fmax(alpha, -20.0), 90.0) + 20.0) * 0.2); }
+F16_DEV int beta_guess(double beta) {
+  const double bc = fmin(fmax(beta, -30.0), 30.0);
+  return bc < -10.0 ? (int)((bc + 30.0) * 0.2) : (bc < 10.0 ? 4 + (int)((bc + 10.0) * 0.5) : 14 + (int)((bc - 10.0) * 0.2));
+}
+
+
+// The six totals of C/nlplant.c:333-377 for ONE lane = one aircraft, in four load / compute phases whose live ranges
+// stay inside the register file (with the monolithic aero_hifi() below, all 168 vertex reads are hoisted to the top of
+// the step and the allocator parks ~200 values in AGPRs: ~360 accvgpr moves per step, and a 512-lane workgroup spills
+// to scratch).  Same terms, same differences-first order.  Measured at B = 262,144: 14.2 -> 15.8 G steps/s with 256-lane
+// workgroups, 5.7 -> 17.1 with 512-lane ones (two waves per SIMD).
+struct TotalsOut { double Cx, Cz, Cm, Cy, Cn, Cl; };
+template <typename TP>
+F16_DEV void aero_totals_phased(TP T, const double *xu, double xcg, unsigned flags, TotalsOut &t, int &status) {
+  const double B = 30.0, cbar = 11.32, xcgr = 0.35, r2d = 180.0 / 3.141592653589793;
+  double vt = xu[6];
+  if (vt <= 0.01) vt = 0.01;
+  const double alpha = xu[7] * r2d, beta = xu[8] * r2d, P = xu[9], Q = xu[10], R = xu[11], el = xu[13];
+  const double dail = F16_DIVC(xu[14], 21.5), drud = F16_DIVC(xu[15], 30.0), dlef = 1 - F16_DIVC(xu[16], 25.0);
+  const double r2vt = f16_rcp(2 * vt), kq = cbar * r2vt, kb = B * r2vt;
+  // (1) breakpoints
+  const BrRaw ra = br_load(T + OFF_BP_A1, N_A1, alpha_guess(alpha));
+  const BrRaw rb = br_load(T + OFF_BP_B1, N_B1, beta_guess(beta));
+  const BrRaw r1 = br_load(T + OFF_BP_D1, N_D1, (el >= -10.0) + (el >= 0.0) + (el >= 10.0));
+  const BrRaw r2 = br_load(T + OFF_BP_D2, N_D2, (int)(el >= 0.0));
+  const double a45 = T[OFF_BP_A1 + N_A2 - 1];
+  F16_PHASE();
+  bool offa, offb, off1, off2;
+  const BrCell ca = br_cell(ra, N_A1, alpha, offa), cb = br_cell(rb, N_B1, beta, offb);
+  const BrCell c1 = br_cell(r1, N_D1, el, off1), c2 = br_cell(r2, N_D2, el, off2);
+  if (offa) status |= ST_ALPHA1 | ST_ALPHA2;
+  if (offb) status |= ST_BETA;
+  if (off1) status |= ST_EL;
+  const bool hi_a = ca.j > N_A2 - 2;
+  if (hi_a && alpha > a45) status |= ST_ALPHA2;
+  const int j2 = hi_a ? N_A2 - 2 : ca.j;
+  const int n1 = cb.j * N_A1 + ca.j, n2 = cb.j * N_A2 + j2;
+  const Axis a1 = br_axis(ca), b = br_axis(cb), d1 = br_axis(c1), d2 = br_axis(c2);
+  Axis a2 = a1;
+  if (hi_a) { a2.j = N_A2 - 2; a2.l = 1.0; a2.m = 0.0; }
+  TP g = T + OFF_G1A + ca.j * S_G1A, h = T + OFF_G1B + j2 * S_G1B;
+  // (2) longitudinal: G3A (3-D + el = 0 plane), G2B lef, pitch damping, eta_el
+  {
+    constexpr int SA = S_G3A, SB = S_G3A * N_A1, SD = S_G3A * N_A1 * N_B1;
+    TP p = T + OFF_G3A + n1 * SA;
+    Q4 qlo[3], qhi[3], q0[3], ql[3];
+    double g0[3], g1[3], h0[3], h1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      qlo[k] = ld4(p + k + c1.j * SD, SA, SB); qhi[k] = ld4(p + k + (c1.j + 1) * SD, SA, SB);
+      q0[k] = ld4(p + k + D1_ZERO_NODE * SD, SA, SB);
+      ql[k] = ld4(T + OFF_G2B + n2 * S_G2B + k, S_G2B, S_G2B * N_A2);
+      g0[k] = g[3 * k]; g1[k] = g[S_G1A + 3 * k]; h0[k] = h[3 * k]; h1[k] = h[S_G1B + 3 * k];
+    }
+    const double m0 = g[11], m1 = g[S_G1A + 11], e0 = T[OFF_ETA + c1.j], e1 = T[OFF_ETA + c1.j + 1];
+    F16_PHASE();
+    double tot[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double Cf = lerp(bil4(qlo[k], a1, b), bil4(qhi[k], a1, b), d1);
+      const double dC = bil4(ql[k], a2, b) - bil4(q0[k], a1, b);             // hifi_C_lef
+      const double Cq = lerp(g0[k], g1[k], a1), dq = lerp(h0[k], h1[k], a2);
+      const double dql = k == 1 ? dC : dq;                                     // reference quirk (:339)
+      tot[k] = (k == 2 ? Cf * lerp(e0, e1, d1) : Cf) + dC * dlef + kq * (Cq + dql * dlef) * Q;
+    }
+    t.Cx = tot[0]; t.Cz = tot[1];
+    t.Cm = tot[2] + lerp(m0, m1, a1) + t.Cz * (xcgr - xcg);                    // :347 (+ dCm)
+  }
+  F16_PHASE();
+  // (3) lateral, first half: G3B (3-D + plane), G2A
+  double base[3], base0[3], dr30[3], da20[3];
+  {
+    constexpr int SA3 = S_G3B, SB3 = S_G3B * N_A1, SD3 = S_G3B * N_A1 * N_B1;
+    TP p3 = T + OFF_G3B + n1 * SA3;
+    Q4 qlo[2], qhi[2], q0[2], qa[7];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      qlo[k] = ld4(p3 + k + c2.j * SD3, SA3, SB3); qhi[k] = ld4(p3 + k + (c2.j + 1) * SD3, SA3, SB3);
+      q0[k] = ld4(p3 + k + D2_ZERO_NODE * SD3, SA3, SB3);
+    }
+    TP pa = T + OFF_G2A + n1 * S_G2A;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) qa[k] = ld4(pa + k, S_G2A, S_G2A * N_A1);
+    F16_PHASE();
+    const double Cy = bil4(qa[0], a1, b);
+    base[0] = Cy; base0[0] = Cy;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      base[k + 1] = lerp(bil4(qlo[k], a1, b), bil4(qhi[k], a1, b), d2);
+      base0[k + 1] = bil4(q0[k], a1, b);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      dr30[k] = bil4(qa[1 + k], a1, b) - base0[k];                              // hifi_rudder
+      da20[k] = bil4(qa[4 + k], a1, b) - base0[k];                              // hifi_ailerons
+    }
+  }
+  F16_PHASE();
+  // (4) lateral, second half: G2B lef tables, yaw / roll damping, sideslip corrections
+  {
+    TP pb = T + OFF_G2B + n2 * S_G2B;
+    Q4 ql[3], qal[3];
+    double r0[3], r1v[3], p0[3], p1[3], hr0[3], hr1[3], hp0[3], hp1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      ql[k] = ld4(pb + 3 + k, S_G2B, S_G2B * N_A2); qal[k] = ld4(pb + 6 + k, S_G2B, S_G2B * N_A2);
+      const int ir = k == 0 ? 1 : (k == 1 ? 7 : 4);
+      r0[k] = g[ir]; r1v[k] = g[S_G1A + ir]; p0[k] = g[ir + 1]; p1[k] = g[S_G1A + ir + 1];
+      hr0[k] = h[ir]; hr1[k] = h[S_G1B + ir]; hp0[k] = h[ir + 1]; hp1[k] = h[S_G1B + ir + 1];
+    }
+    const double nb0 = g[9], nb1 = g[S_G1A + 9], lb0 = g[10], lb1 = g[S_G1A + 10];
+    F16_PHASE();
+    double tot[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double Clef = bil4(ql[k], a2, b), Ca20lef = bil4(qal[k], a2, b);
+      double Cr = lerp(r0[k], r1v[k], a1);
+      if (k == 2 && !(flags & FLAG_FIX_CLR)) Cr = 0.0;                          // reference defect: _CLr never loaded
+      const double Cp = lerp(p0[k], p1[k], a1), dCr = lerp(hr0[k], hr1[k], a2), dCp = lerp(hp0[k], hp1[k], a2);
+      const double dlefC = Clef - base0[k], da20lef = Ca20lef - Clef - da20[k];
+      tot[k] = base[k] + dlefC * dlef + (da20[k] + da20lef * dlef) * dail + dr30[k] * drud +
+               kb * (Cr + dCr * dlef) * R + kb * (Cp + dCp * dlef) * P;
+    }
+    t.Cy = tot[0];
+    t.Cn = tot[1] + lerp(nb0, nb1, a1) * beta - t.Cy * (xcgr - xcg) * (cbar / B);   // :367
+    t.Cl = tot[2] + lerp(lb0, lb1, a1) * beta;
+  }
+}
+
 // ---- lofi (C/lofi_F16_AeroData.c), tables in global/constant memory ---------------------------
 F16_DEV int sgn_i(double v) { return (v > 0) - (v < 0); }
 F16_DEV int fix_i(double v) { return (int)trunc(v); }
@@ -410,6 +587,12 @@ F16_DEV void aero_totals(TP T, const double *__restrict__ LT, const double *xu, 
 
   Aero c;
   const bool hifi = FI < 0 ? fi_flag == 1 : FI == 1;
+  if (hifi && PART == 0) {
+    TotalsOut o;
+    aero_totals_phased(T, xu, xcg, flags, o, status);
+    t.Cx = o.Cx; t.Cz = o.Cz; t.Cm = o.Cm; t.Cy = o.Cy; t.Cn = o.Cn; t.Cl = o.Cl;
+    return;
+  }
   if (hifi) {
     aero_hifi(T, alpha, beta, el, flags, c, status);
   } else {

@@ -23,59 +23,6 @@ F16_DEV double quad_bcast(double v) {
   return __hiloint2double(hi, lo);
 }
 
-// ---- lookups in three scheduling phases.  With one wavefront per SIMD nothing hides an LDS round trip, and left to
-// itself the compiler emits the lookups in source order (read four corners, wait, interpolate, next table: ~14 dependent
-// round trips per role).  Here: (1) ALL breakpoint reads, (2) cell indices -> ALL table-corner reads, with the
-// lambda divisions issued behind them, (3) the interpolation arithmetic.  Two round trips per role.
-struct BrRaw { double lo, hi, xm, xg, xg1, xp; int g; };
-template <typename TP>
-F16_DEV BrRaw br_load(TP X, int n, int guess) {                 // the six reads of bracket()
-  BrRaw r;
-  r.g = min(max(guess, 0), n - 2);
-  r.lo = X[0]; r.hi = X[n - 1];
-  r.xm = X[max(r.g - 1, 0)]; r.xg = X[r.g]; r.xg1 = X[r.g + 1]; r.xp = X[min(r.g + 2, n - 1)];
-  return r;
-}
-struct BrCell { int j; double v, x0, x1; };
-F16_DEV BrCell br_cell(const BrRaw &r, int n, double v, bool &off) {   // bracket(): clamp, cell fix-up
-  off = !(v >= r.lo && v <= r.hi);
-  v = fmin(fmax(v, r.lo), r.hi);
-  const bool down = r.g > 0 && v < r.xg, up = r.g < n - 2 && v >= r.xg1;
-  BrCell c;
-  c.j = r.g - (down ? 1 : 0) + (up ? 1 : 0);
-  c.v = v;
-  c.x0 = down ? r.xm : (up ? r.xg1 : r.xg);
-  c.x1 = down ? r.xg : (up ? r.xp : r.xg1);
-  return c;
-}
-F16_DEV Axis br_axis(const BrCell &c) {                          // lambda = (v - X[j]) / (X[j+1] - X[j]), mexndinterp.c:196
-  Axis a;
-  a.j = c.j;
-#ifdef F16_FAST_DIV
-  a.l = (c.v - c.x0) * f16_rcp(c.x1 - c.x0);
-#else
-  a.l = (c.v - c.x0) / (c.x1 - c.x0);
-#endif
-  a.m = 1 - a.l;
-  return a;
-}
-struct Q4 { double f00, f10, f01, f11; };                        // corners (a,b), (a+1,b), (a,b+1), (a+1,b+1)
-template <typename TP>
-F16_DEV Q4 ld4(TP p, int sa, int sb) { Q4 c; c.f00 = p[0]; c.f10 = p[sa]; c.f01 = p[sb]; c.f11 = p[sb + sa]; return c; }
-F16_DEV double bil4(const Q4 &c, const Axis &a, const Axis &b) {   // alpha collapsed first, then beta (mexndinterp.c:178-209)
-  return lerp(lerp(c.f00, c.f10, a), lerp(c.f01, c.f11, a), b);
-}
-#ifndef F16_PHASE_MASK
-#define F16_PHASE_MASK 0x7        // LDS / memory instructions stay in their phase, ALU instructions may float (2 % over 0)
-#endif
-#define F16_PHASE() __builtin_amdgcn_sched_barrier(F16_PHASE_MASK)
-
-F16_DEV int alpha_guess(double alpha) { return (int)((fmin(fmax(alpha, -20.0), 90.0) + 20.0) * 0.2); }
-F16_DEV int beta_guess(double beta) {
-  const double bc = fmin(fmax(beta, -30.0), 30.0);
-  return bc < -10.0 ? (int)((bc + 30.0) * 0.2) : (bc < 10.0 ? 4 + (int)((bc + 10.0) * 0.5) : 14 + (int)((bc - 10.0) * 0.2));
-}
-
 template <int J>
 F16_DEV int quad_bcast_i(int v) {
   constexpr int ctrl = J | (J << 2) | (J << 4) | (J << 6);
