@@ -59,28 +59,6 @@ struct Axis {
 
 F16_DEV double lerp(double f1, double f2, const Axis &a) { return a.l * f2 + a.m * f1; }  // mexndinterp.c:197
 
-// Bracket v on breakpoints X[0..n-1] (monotone).  `guess` must be within one cell of the true cell (the arithmetic
-// guesses below are exact up to a rounding at a node).  All breakpoint reads (the ends and the four around the guess)
-// are independent, so the search costs ONE LDS round trip; the cell is then fixed up with compares and selects.
-template <typename TP>
-F16_DEV Axis bracket(TP X, int n, double v, int guess, bool &off) {
-  const int g = min(max(guess, 0), n - 2);
-  const int gm = max(g - 1, 0), gp = min(g + 2, n - 1);
-  const double lo = X[0], hi = X[n - 1];
-  const double xm = X[gm], xg = X[g], xg1 = X[g + 1], xp = X[gp];
-  off = !(v >= lo && v <= hi);
-  v = fmin(fmax(v, lo), hi);
-  const bool down = g > 0 && v < xg;                 // true cell is g-1
-  const bool up = g < n - 2 && v >= xg1;             // true cell is g+1
-  Axis a;
-  a.j = g - (down ? 1 : 0) + (up ? 1 : 0);
-  const double x0 = down ? xm : (up ? xg1 : xg);
-  const double x1 = down ? xg : (up ? xp : xg1);
-  a.l = (v - x0) / (x1 - x0);
-  a.m = 1 - a.l;
-  return a;
-}
-
 // C/nlplant.c:467-490
 F16_DEV void atmos_dev(double alt, double vt, double &mach, double &qbar, double &ps) {
   const double rho0 = 2.377e-3;
@@ -142,167 +120,18 @@ struct Aero {  // everything C/nlplant.c:185-240 (or :245-323) hands to the coef
   double dCnbeta, dClbeta, dCm, eta_el;
 };
 
-// 2-D bilinear on a node-major group: alpha collapsed first, then beta (mexndinterp.c:178-209).
-template <typename TP>
-F16_DEV double bil(TP p, int sa, int sb, const Axis &a, const Axis &b) {
-  const double t0 = lerp(p[0], p[sa], a);
-  const double t1 = lerp(p[sb], p[sb + sa], a);
-  return lerp(t0, t1, b);
-}
-
-// hifi lookups: hifi_C, hifi_damping, hifi_C_lef, hifi_damping_lef, hifi_rudder, hifi_ailerons,
-// hifi_other_coeffs (C/hifi_F16_AeroData.c:1871-1934) fused.  T = table image (LDS or global).
-template <typename TP>
-F16_DEV void aero_hifi(TP T, double alpha, double beta, double el, unsigned flags, Aero &c, int &status) {
-  bool off;
-  // alpha on ALPHA1: 5-degree spacing up to 60, then 70, 80, 90
-  const Axis a1 = bracket(T + OFF_BP_A1, N_A1, alpha, (int)((fmin(fmax(alpha, -20.0), 90.0) + 20.0) * 0.2), off);
-  if (off) status |= ST_ALPHA1;
-  // ALPHA2 is the first 14 nodes of ALPHA1 (checked when the image is built): same cell, or -- from
-  // 45 degrees up -- the last ALPHA2 cell with lambda = 1 (the 45-degree node; beyond it: clamped + flagged)
-  Axis a2 = a1;
-  if (off) status |= ST_ALPHA2;
-  if (a1.j > N_A2 - 2) {
-    if (alpha > T[OFF_BP_A1 + N_A2 - 1]) status |= ST_ALPHA2;
-    a2.j = N_A2 - 2;
-    a2.l = 1.0;
-    a2.m = 0.0;
-  }
-  const double bc = fmin(fmax(beta, -30.0), 30.0);
-  const int gb = bc < -10.0 ? (int)((bc + 30.0) * 0.2) : (bc < 10.0 ? 4 + (int)((bc + 10.0) * 0.5) : 14 + (int)((bc - 10.0) * 0.2));
-  const Axis b = bracket(T + OFF_BP_B1, N_B1, beta, gb, off);
-  if (off) status |= ST_BETA;
-  const Axis d1 = bracket(T + OFF_BP_D1, N_D1, el, (el >= -10.0) + (el >= 0.0) + (el >= 10.0), off);
-  if (off) status |= ST_EL;
-  bool off2;
-  const Axis d2 = bracket(T + OFF_BP_D2, N_D2, el, (int)(el >= 0.0), off2);
-
-  const int n1 = b.j * N_A1 + a1.j;   // cell corner on ALPHA1 x BETA1
-  const int n2 = b.j * N_A2 + a2.j;   // cell corner on ALPHA2 x BETA1
-
-  // ---- G3A: Cx, Cz, Cm at (alpha,beta,el) and on the el = 0 plane
-  {
-    constexpr int SA = S_G3A, SB = S_G3A * N_A1, SD = S_G3A * N_A1 * N_B1;
-    TP p = T + OFF_G3A + n1 * SA;
-    TP plo = p + d1.j * SD;
-    TP p0 = p + D1_ZERO_NODE * SD;
-    double v[3], v0[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const double r0 = bil(plo + k, SA, SB, a1, b);
-      const double r1 = bil(plo + SD + k, SA, SB, a1, b);
-      v[k] = lerp(r0, r1, d1);
-      v0[k] = bil(p0 + k, SA, SB, a1, b);
-    }
-    c.Cx = v[0]; c.Cz = v[1]; c.Cm = v[2];
-    c.dCx_lef = v0[0]; c.dCz_lef = v0[1]; c.dCm_lef = v0[2];   // finished below: lef table - this
-  }
-  // ---- G3B: Cn, Cl at (alpha,beta,el) and on the el = 0 plane
-  double Cn0, Cl0;
-  {
-    constexpr int SA = S_G3B, SB = S_G3B * N_A1, SD = S_G3B * N_A1 * N_B1;
-    TP p = T + OFF_G3B + n1 * SA;
-    TP plo = p + d2.j * SD;
-    TP p0 = p + D2_ZERO_NODE * SD;
-    double v[2], v0[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const double r0 = bil(plo + k, SA, SB, a1, b);
-      const double r1 = bil(plo + SD + k, SA, SB, a1, b);
-      v[k] = lerp(r0, r1, d2);
-      v0[k] = bil(p0 + k, SA, SB, a1, b);
-    }
-    c.Cn = v[0]; c.Cl = v[1];
-    Cn0 = v0[0]; Cl0 = v0[1];
-  }
-  // ---- G2A: Cy, r30 and a20 increments on ALPHA1 x BETA1
-  double Cy_r30, Cn_r30, Cl_r30, Cy_a20, Cn_a20, Cl_a20;
-  {
-    constexpr int SA = S_G2A, SB = S_G2A * N_A1;
-    TP p = T + OFF_G2A + n1 * SA;
-    c.Cy = bil(p + 0, SA, SB, a1, b);
-    Cy_r30 = bil(p + 1, SA, SB, a1, b);
-    Cn_r30 = bil(p + 2, SA, SB, a1, b);
-    Cl_r30 = bil(p + 3, SA, SB, a1, b);
-    Cy_a20 = bil(p + 4, SA, SB, a1, b);
-    Cn_a20 = bil(p + 5, SA, SB, a1, b);
-    Cl_a20 = bil(p + 6, SA, SB, a1, b);
-  }
-  // ---- G2B: lef tables on ALPHA2 x BETA1
-  double Cy_lef, Cn_lef, Cl_lef;
-  {
-    constexpr int SA = S_G2B, SB = S_G2B * N_A2;
-    TP p = T + OFF_G2B + n2 * SA;
-    const double Cx_lef = bil(p + 0, SA, SB, a2, b);
-    const double Cz_lef = bil(p + 1, SA, SB, a2, b);
-    const double Cm_lef = bil(p + 2, SA, SB, a2, b);
-    Cy_lef = bil(p + 3, SA, SB, a2, b);
-    Cn_lef = bil(p + 4, SA, SB, a2, b);
-    Cl_lef = bil(p + 5, SA, SB, a2, b);
-    const double Cy_a20_lef = bil(p + 6, SA, SB, a2, b);
-    const double Cn_a20_lef = bil(p + 7, SA, SB, a2, b);
-    const double Cl_a20_lef = bil(p + 8, SA, SB, a2, b);
-    // hifi_C_lef :1892-1899
-    c.dCx_lef = Cx_lef - c.dCx_lef;
-    c.dCz_lef = Cz_lef - c.dCz_lef;
-    c.dCm_lef = Cm_lef - c.dCm_lef;
-    c.dCy_lef = Cy_lef - c.Cy;
-    c.dCn_lef = Cn_lef - Cn0;
-    c.dCl_lef = Cl_lef - Cl0;
-    // hifi_rudder :1913-1917
-    c.dCy_r30 = Cy_r30 - c.Cy;
-    c.dCn_r30 = Cn_r30 - Cn0;
-    c.dCl_r30 = Cl_r30 - Cl0;
-    // hifi_ailerons :1919-1926
-    c.dCy_a20 = Cy_a20 - c.Cy;
-    c.dCy_a20_lef = Cy_a20_lef - Cy_lef - c.dCy_a20;
-    c.dCn_a20 = Cn_a20 - Cn0;
-    c.dCn_a20_lef = Cn_a20_lef - Cn_lef - c.dCn_a20;
-    c.dCl_a20 = Cl_a20 - Cl0;
-    c.dCl_a20_lef = Cl_a20_lef - Cl_lef - c.dCl_a20;
-  }
-  // ---- G1A: damping derivatives + brett corrections on ALPHA1
-  {
-    TP p = T + OFF_G1A + a1.j * S_G1A;
-    c.Cxq = lerp(p[0], p[S_G1A + 0], a1);
-    c.Cyr = lerp(p[1], p[S_G1A + 1], a1);
-    c.Cyp = lerp(p[2], p[S_G1A + 2], a1);
-    c.Czq = lerp(p[3], p[S_G1A + 3], a1);
-    // reference defect kept by default: _CLr's table is never read from disk
-    // (C/hifi_F16_AeroData.c:964-972: the fscanf loop is the body of `if(fp==NULL)`), so the
-    // reference interpolates uninitialised heap memory (observed ~1e-310) == 0 numerically.
-    c.Clr = (flags & FLAG_FIX_CLR) ? lerp(p[4], p[S_G1A + 4], a1) : 0.0;
-    c.Clp = lerp(p[5], p[S_G1A + 5], a1);
-    c.Cmq = lerp(p[6], p[S_G1A + 6], a1);
-    c.Cnr = lerp(p[7], p[S_G1A + 7], a1);
-    c.Cnp = lerp(p[8], p[S_G1A + 8], a1);
-    c.dCnbeta = lerp(p[9], p[S_G1A + 9], a1);
-    c.dClbeta = lerp(p[10], p[S_G1A + 10], a1);
-    c.dCm = lerp(p[11], p[S_G1A + 11], a1);
-  }
-  // ---- G1B: lef damping increments on ALPHA2
-  {
-    TP p = T + OFF_G1B + a2.j * S_G1B;
-    c.dCxq_lef = lerp(p[0], p[S_G1B + 0], a2);
-    c.dCyr_lef = lerp(p[1], p[S_G1B + 1], a2);
-    c.dCyp_lef = lerp(p[2], p[S_G1B + 2], a2);
-    c.dCzq_lef = lerp(p[3], p[S_G1B + 3], a2);
-    c.dClr_lef = lerp(p[4], p[S_G1B + 4], a2);
-    c.dClp_lef = lerp(p[5], p[S_G1B + 5], a2);
-    c.dCmq_lef = lerp(p[6], p[S_G1B + 6], a2);
-    c.dCnr_lef = lerp(p[7], p[S_G1B + 7], a2);
-    c.dCnp_lef = lerp(p[8], p[S_G1B + 8], a2);
-  }
-  c.eta_el = lerp(T[OFF_ETA + d1.j], T[OFF_ETA + d1.j + 1], d1);
-}
-
-// ---- lookups in scheduling phases (k_rollout_q; optional for the one-lane kernels).  With one wavefront per SIMD nothing hides an LDS round trip, and left to
-// itself the compiler emits the lookups in source order (read four corners, wait, interpolate, next table: ~14 dependent
-// round trips per role).  Here: (1) ALL breakpoint reads, (2) cell indices -> ALL table-corner reads, with the
-// lambda divisions issued behind them, (3) the interpolation arithmetic.  Two round trips per role.
+// ---- hifi lookups: hifi_C, hifi_damping, hifi_C_lef, hifi_damping_lef, hifi_rudder, hifi_ailerons, hifi_other_coeffs
+// (C/hifi_F16_AeroData.c:1871-1934) fused, in scheduling phases.  With one wavefront per SIMD nothing hides an LDS
+// round trip, and left to itself the compiler emits lookups in source order (read four corners, wait, interpolate, next
+// table: ~14 dependent round trips per role).  Here: (1) ALL breakpoint reads, (2) cell indices -> ALL table-corner
+// reads, with the lambda divisions issued behind them, (3) the interpolation arithmetic.
+//
+// Bracketing v on breakpoints X[0..n-1] (monotone): `guess` must be within one cell of the true cell (the arithmetic
+// guesses are exact up to a rounding at a node); the ends and the four breakpoints around the guess are read at once
+// (one LDS round trip), the cell is then fixed up with compares and selects.
 struct BrRaw { double lo, hi, xm, xg, xg1, xp; int g; };
 template <typename TP>
-F16_DEV BrRaw br_load(TP X, int n, int guess) {                 // the six reads of bracket()
+F16_DEV BrRaw br_load(TP X, int n, int guess) {                 // the six breakpoint reads
   BrRaw r;
   r.g = min(max(guess, 0), n - 2);
   r.lo = X[0]; r.hi = X[n - 1];
@@ -310,7 +139,7 @@ F16_DEV BrRaw br_load(TP X, int n, int guess) {                 // the six reads
   return r;
 }
 struct BrCell { int j; double v, x0, x1; };
-F16_DEV BrCell br_cell(const BrRaw &r, int n, double v, bool &off) {   // bracket(): clamp, cell fix-up
+F16_DEV BrCell br_cell(const BrRaw &r, int n, double v, bool &off) {   // clamp to the grid, cell fix-up
   off = !(v >= r.lo && v <= r.hi);
   v = fmin(fmax(v, r.lo), r.hi);
   const bool down = r.g > 0 && v < r.xg, up = r.g < n - 2 && v >= r.xg1;
@@ -351,7 +180,7 @@ F16_DEV int beta_guess(double beta) {
 
 
 // The six totals of C/nlplant.c:333-377 for ONE lane = one aircraft, in four load / compute phases whose live ranges
-// stay inside the register file (with the monolithic aero_hifi() below, all 168 vertex reads are hoisted to the top of
+// stay inside the register file (written as one expression tree, all 168 vertex reads are hoisted to the top of
 // the step and the allocator parks ~200 values in AGPRs: ~360 accvgpr moves per step, and a 512-lane workgroup spills
 // to scratch).  Same terms, same differences-first order.  Measured at B = 262,144: 14.2 -> 15.8 G steps/s with 256-lane
 // workgroups, 5.7 -> 17.1 with 512-lane ones (two waves per SIMD).
@@ -400,17 +229,18 @@ F16_DEV void aero_totals_phased(TP T, const double *xu, double xcg, unsigned fla
     }
     const double m0 = g[11], m1 = g[S_G1A + 11], e0 = T[OFF_ETA + c1.j], e1 = T[OFF_ETA + c1.j + 1];
     F16_PHASE();
-    double tot[3];
+    double Cf[3], dC[3], dQ[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const double Cf = lerp(bil4(qlo[k], a1, b), bil4(qhi[k], a1, b), d1);
-      const double dC = bil4(ql[k], a2, b) - bil4(q0[k], a1, b);             // hifi_C_lef
+      Cf[k] = lerp(bil4(qlo[k], a1, b), bil4(qhi[k], a1, b), d1);
+      dC[k] = bil4(ql[k], a2, b) - bil4(q0[k], a1, b);                         // hifi_C_lef
       const double Cq = lerp(g0[k], g1[k], a1), dq = lerp(h0[k], h1[k], a2);
-      const double dql = k == 1 ? dC : dq;                                     // reference quirk (:339)
-      tot[k] = (k == 2 ? Cf * lerp(e0, e1, d1) : Cf) + dC * dlef + kq * (Cq + dql * dlef) * Q;
+      dQ[k] = kq * (Cq + (k == 1 ? dC[k] : dq) * dlef);                        // dXdQ, dZdQ (reference quirk :339), dMdQ
     }
-    t.Cx = tot[0]; t.Cz = tot[1];
-    t.Cm = tot[2] + lerp(m0, m1, a1) + t.Cz * (xcgr - xcg);                    // :347 (+ dCm)
+    // same order of additions as C/nlplant.c:333-347
+    t.Cx = Cf[0] + dC[0] * dlef + dQ[0] * Q;
+    t.Cz = Cf[1] + dC[1] * dlef + dQ[1] * Q;
+    t.Cm = Cf[2] * lerp(e0, e1, d1) + t.Cz * (xcgr - xcg) + dC[2] * dlef + dQ[2] * Q + lerp(m0, m1, a1);
   }
   F16_PHASE();
   // (3) lateral, first half: G3B (3-D + plane), G2A
@@ -456,20 +286,153 @@ F16_DEV void aero_totals_phased(TP T, const double *xu, double xcg, unsigned fla
     }
     const double nb0 = g[9], nb1 = g[S_G1A + 9], lb0 = g[10], lb1 = g[S_G1A + 10];
     F16_PHASE();
-    double tot[3];
+    double dl[3], dA[3], dR[3], dP[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const double Clef = bil4(ql[k], a2, b), Ca20lef = bil4(qal[k], a2, b);
       double Cr = lerp(r0[k], r1v[k], a1);
       if (k == 2 && !(flags & FLAG_FIX_CLR)) Cr = 0.0;                          // reference defect: _CLr never loaded
       const double Cp = lerp(p0[k], p1[k], a1), dCr = lerp(hr0[k], hr1[k], a2), dCp = lerp(hp0[k], hp1[k], a2);
-      const double dlefC = Clef - base0[k], da20lef = Ca20lef - Clef - da20[k];
-      tot[k] = base[k] + dlefC * dlef + (da20[k] + da20lef * dlef) * dail + dr30[k] * drud +
-               kb * (Cr + dCr * dlef) * R + kb * (Cp + dCp * dlef) * P;
+      dl[k] = Clef - base0[k];                                                  // hifi_C_lef
+      dA[k] = da20[k] + (Ca20lef - Clef - da20[k]) * dlef;                      // dYdail, dNdail, dLdail
+      dR[k] = kb * (Cr + dCr * dlef);
+      dP[k] = kb * (Cp + dCp * dlef);
     }
-    t.Cy = tot[0];
-    t.Cn = tot[1] + lerp(nb0, nb1, a1) * beta - t.Cy * (xcgr - xcg) * (cbar / B);   // :367
-    t.Cl = tot[2] + lerp(lb0, lb1, a1) * beta;
+    // same order of additions as C/nlplant.c:353-377
+    t.Cy = base[0] + dl[0] * dlef + dA[0] * dail + dr30[0] * drud + dR[0] * R + dP[0] * P;
+    t.Cn = base[1] + dl[1] * dlef - t.Cy * (xcgr - xcg) * (cbar / B) + dA[1] * dail + dr30[1] * drud + dR[1] * R + dP[1] * P +
+           lerp(nb0, nb1, a1) * beta;
+    t.Cl = base[2] + dl[2] * dlef + dA[2] * dail + dr30[2] * drud + dR[2] * R + dP[2] * P + lerp(lb0, lb1, a1) * beta;
+  }
+}
+
+// The same totals as sums of four partial triples, so that four wavefronts can each look up one table family
+// (k_rollout_4w), every part in load / compute phases:
+//   PART 1  longitudinal, 3-D / 2-D tables  {Cx, Cz, Cm}_s        PART 3  longitudinal damping (1-D)  {Cx, Cz, Cm}_d
+//   PART 2  lateral, 3-D / 2-D tables       {Cy, Cn, Cl}_s        PART 4  lateral damping (1-D)       {Cy, Cn, Cl}_d
+// compose_totals() adds them and applies the cg-offset couplings of C/nlplant.c:347,367.  The terms are exactly those
+// of C/nlplant.c:333-377; only the order of the additions differs from the single-expression form (ulp level).
+template <int PART, typename TP>
+F16_DEV void aero_part(TP T, const double *xu, unsigned flags, double *out, int &status) {
+  const double B = 30.0, cbar = 11.32, r2d = 180.0 / 3.141592653589793;
+  double vt = xu[6];
+  if (vt <= 0.01) vt = 0.01;
+  const double alpha = xu[7] * r2d, beta = xu[8] * r2d, P = xu[9], Q = xu[10], R = xu[11], el = xu[13];
+  const double dail = F16_DIVC(xu[14], 21.5), drud = F16_DIVC(xu[15], 30.0), dlef = 1 - F16_DIVC(xu[16], 25.0);
+  const double r2vt = f16_rcp(2 * vt), kq = cbar * r2vt, kb = B * r2vt;
+  constexpr bool TWO_D = PART == 1 || PART == 2;                 // needs beta (and an elevator axis)
+  // (1) breakpoints
+  const BrRaw ra = br_load(T + OFF_BP_A1, N_A1, alpha_guess(alpha));
+  const double a45 = T[OFF_BP_A1 + N_A2 - 1];
+  BrRaw rb = ra, rd = ra;
+  if (TWO_D) {
+    rb = br_load(T + OFF_BP_B1, N_B1, beta_guess(beta));
+    rd = PART == 1 ? br_load(T + OFF_BP_D1, N_D1, (el >= -10.0) + (el >= 0.0) + (el >= 10.0))
+                   : br_load(T + OFF_BP_D2, N_D2, (int)(el >= 0.0));
+  }
+  F16_PHASE();
+  bool offa, offb = false, offd = false;
+  const BrCell ca = br_cell(ra, N_A1, alpha, offa);
+  BrCell cb = ca, cd = ca;
+  if (TWO_D) { cb = br_cell(rb, N_B1, beta, offb); cd = br_cell(rd, PART == 1 ? N_D1 : N_D2, el, offd); }
+  if (offa) status |= ST_ALPHA1 | ST_ALPHA2;
+  if (offb) status |= ST_BETA;
+  if (offd) status |= ST_EL;
+  const bool hi_a = ca.j > N_A2 - 2;
+  if (hi_a && alpha > a45) status |= ST_ALPHA2;
+  const int j2 = hi_a ? N_A2 - 2 : ca.j;
+  const int n1 = cb.j * N_A1 + ca.j, n2 = cb.j * N_A2 + j2;
+  TP g = T + OFF_G1A + ca.j * S_G1A, h = T + OFF_G1B + j2 * S_G1B;
+  if (PART == 1) {
+    constexpr int SA = S_G3A, SB = S_G3A * N_A1, SD = S_G3A * N_A1 * N_B1;
+    TP p = T + OFF_G3A + n1 * SA;
+    Q4 qlo[3], qhi[3], q0[3], ql[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      qlo[k] = ld4(p + k + cd.j * SD, SA, SB); qhi[k] = ld4(p + k + (cd.j + 1) * SD, SA, SB);
+      q0[k] = ld4(p + k + D1_ZERO_NODE * SD, SA, SB);
+      ql[k] = ld4(T + OFF_G2B + n2 * S_G2B + k, S_G2B, S_G2B * N_A2);
+    }
+    const double e0 = T[OFF_ETA + cd.j], e1 = T[OFF_ETA + cd.j + 1];
+    F16_PHASE();
+    const Axis a1 = br_axis(ca), b = br_axis(cb), d1 = br_axis(cd);
+    Axis a2 = a1;
+    if (hi_a) { a2.j = N_A2 - 2; a2.l = 1.0; a2.m = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double Cf = lerp(bil4(qlo[k], a1, b), bil4(qhi[k], a1, b), d1);
+      const double dC = bil4(ql[k], a2, b) - bil4(q0[k], a1, b);             // hifi_C_lef :1892-1899
+      out[k] = (k == 2 ? Cf * lerp(e0, e1, d1) : Cf) + dC * dlef + (k == 1 ? kq * (dC * dlef) * Q : 0.0);   // dZdQ quirk
+    }
+  } else if (PART == 3) {
+    double g0[3], g1[3], h0[3], h1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { g0[k] = g[3 * k]; g1[k] = g[S_G1A + 3 * k]; h0[k] = h[3 * k]; h1[k] = h[S_G1B + 3 * k]; }
+    const double m0 = g[11], m1 = g[S_G1A + 11];
+    F16_PHASE();
+    const Axis a1 = br_axis(ca);
+    Axis a2 = a1;
+    if (hi_a) { a2.j = N_A2 - 2; a2.l = 1.0; a2.m = 0.0; }
+    out[0] = kq * (lerp(g0[0], g1[0], a1) + lerp(h0[0], h1[0], a2) * dlef) * Q;
+    out[1] = kq * lerp(g0[1], g1[1], a1) * Q;
+    out[2] = kq * (lerp(g0[2], g1[2], a1) + lerp(h0[2], h1[2], a2) * dlef) * Q + lerp(m0, m1, a1);
+  } else if (PART == 2) {
+    constexpr int SA3 = S_G3B, SB3 = S_G3B * N_A1, SD3 = S_G3B * N_A1 * N_B1;
+    TP p3 = T + OFF_G3B + n1 * SA3;
+    Q4 qlo[2], qhi[2], q0[2], qa[7];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      qlo[k] = ld4(p3 + k + cd.j * SD3, SA3, SB3); qhi[k] = ld4(p3 + k + (cd.j + 1) * SD3, SA3, SB3);
+      q0[k] = ld4(p3 + k + D2_ZERO_NODE * SD3, SA3, SB3);
+    }
+    TP pa = T + OFF_G2A + n1 * S_G2A;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) qa[k] = ld4(pa + k, S_G2A, S_G2A * N_A1);
+    F16_PHASE();
+    const Axis a1 = br_axis(ca), b = br_axis(cb), d2 = br_axis(cd);
+    Axis a2 = a1;
+    if (hi_a) { a2.j = N_A2 - 2; a2.l = 1.0; a2.m = 0.0; }
+    double base[3], base0[3], dr30[3], da20[3];
+    base[0] = base0[0] = bil4(qa[0], a1, b);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      base[k + 1] = lerp(bil4(qlo[k], a1, b), bil4(qhi[k], a1, b), d2);
+      base0[k + 1] = bil4(q0[k], a1, b);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { dr30[k] = bil4(qa[1 + k], a1, b) - base0[k]; da20[k] = bil4(qa[4 + k], a1, b) - base0[k]; }
+    F16_PHASE();
+    TP pb = T + OFF_G2B + n2 * S_G2B;
+    Q4 ql[3], qal[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ql[k] = ld4(pb + 3 + k, S_G2B, S_G2B * N_A2); qal[k] = ld4(pb + 6 + k, S_G2B, S_G2B * N_A2); }
+    F16_PHASE();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double Clef = bil4(ql[k], a2, b), Ca20lef = bil4(qal[k], a2, b);
+      out[k] = base[k] + (Clef - base0[k]) * dlef + (da20[k] + (Ca20lef - Clef - da20[k]) * dlef) * dail + dr30[k] * drud;
+    }
+  } else {
+    double r0[3], r1v[3], p0[3], p1[3], hr0[3], hr1[3], hp0[3], hp1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int ir = k == 0 ? 1 : (k == 1 ? 7 : 4);
+      r0[k] = g[ir]; r1v[k] = g[S_G1A + ir]; p0[k] = g[ir + 1]; p1[k] = g[S_G1A + ir + 1];
+      hr0[k] = h[ir]; hr1[k] = h[S_G1B + ir]; hp0[k] = h[ir + 1]; hp1[k] = h[S_G1B + ir + 1];
+    }
+    const double nb0 = g[9], nb1 = g[S_G1A + 9], lb0 = g[10], lb1 = g[S_G1A + 10];
+    F16_PHASE();
+    const Axis a1 = br_axis(ca);
+    Axis a2 = a1;
+    if (hi_a) { a2.j = N_A2 - 2; a2.l = 1.0; a2.m = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double Cr = lerp(r0[k], r1v[k], a1);
+      if (k == 2 && !(flags & FLAG_FIX_CLR)) Cr = 0.0;                          // reference defect: _CLr never loaded
+      out[k] = kb * (Cr + lerp(hr0[k], hr1[k], a2) * dlef) * R + kb * (lerp(p0[k], p1[k], a1) + lerp(hp0[k], hp1[k], a2) * dlef) * P;
+    }
+    out[1] += lerp(nb0, nb1, a1) * beta;
+    out[2] += lerp(lb0, lb1, a1) * beta;
   }
 }
 
@@ -569,37 +532,29 @@ struct Pre {                                        // trigonometry, atmosphere,
 
 // Table lookups + coefficient build-up (C/nlplant.c:183-377).  Needs xu[6..11], xu[13..16] only.
 // FI: 1 / 0 = fidelity fixed at compile time, -1 = decided by fi_flag at run time.
-// PART: 0 = all six totals; 1 = longitudinal only (Cx, Cz, Cm); 2 = lateral-directional only (Cy, Cn, Cl) -- the lookups
-// the other half needs are dead code and are dropped by the compiler (k_rollout_4w runs the halves on two wavefronts).
-template <int FI = -1, int PART = 0, typename TP>
+// hifi: the phased lookups above; lofi: Stevens & Lewis tables + the same totals with every lef term zero (:295-319).
+template <int FI = -1, typename TP>
 F16_DEV void aero_totals(TP T, const double *__restrict__ LT, const double *xu, double xcg, int fi_flag, unsigned flags,
                          Totals &t, int &status) {
+  const bool hifi = FI < 0 ? fi_flag == 1 : FI == 1;
+  if (hifi) {
+    TotalsOut o;
+    aero_totals_phased(T, xu, xcg, flags, o, status);
+    t.Cx = o.Cx; t.Cz = o.Cz; t.Cm = o.Cm; t.Cy = o.Cy; t.Cn = o.Cn; t.Cl = o.Cl;
+    return;
+  }
   const double B = 30.0, cbar = 11.32, xcgr = 0.35;
   const double r2d = 180.0 / 3.141592653589793;   // 180.0/acos(-1)
   double vt = xu[6];
   const double alpha = xu[7] * r2d, beta = xu[8] * r2d;
   const double P = xu[9], Q = xu[10], R = xu[11];
   if (vt <= 0.01) vt = 0.01;
-  const double el = xu[13], ail = xu[14], rud = xu[15], lef = xu[16];
+  const double el = xu[13], ail = xu[14], rud = xu[15];
   const double dail = F16_DIVC(ail, 21.5);
   const double drud = F16_DIVC(rud, 30.0);
-  double dlef = (1 - F16_DIVC(lef, 25.0));
-
+  const double dlef = 0.0;
   Aero c;
-  const bool hifi = FI < 0 ? fi_flag == 1 : FI == 1;
-  if (hifi && PART == 0) {
-    TotalsOut o;
-    aero_totals_phased(T, xu, xcg, flags, o, status);
-    t.Cx = o.Cx; t.Cz = o.Cz; t.Cm = o.Cm; t.Cy = o.Cy; t.Cn = o.Cn; t.Cl = o.Cl;
-    return;
-  }
-  if (hifi) {
-    aero_hifi(T, alpha, beta, el, flags, c, status);
-  } else {
-    dlef = 0.0;
-    aero_lofi(LT, alpha, beta, el, dail, drud, c, status);
-  }
-
+  aero_lofi(LT, alpha, beta, el, dail, drud, c, status);
   // totals, C/nlplant.c:333-377 (dZdQ uses delta_Cz_lef, as the reference does)
 #ifdef F16_FAST_DIV
   const double r2vt = 1.0 / (2 * vt);
@@ -607,75 +562,27 @@ F16_DEV void aero_totals(TP T, const double *__restrict__ LT, const double *xu, 
 #else
   const double kq = cbar / (2 * vt), kb = B / (2 * vt);
 #endif
-  if (PART != 2) {
-    const double dXdQ = kq * (c.Cxq + c.dCxq_lef * dlef);
-    t.Cx = c.Cx + c.dCx_lef * dlef + dXdQ * Q;
-    const double dZdQ = kq * (c.Czq + c.dCz_lef * dlef);
-    t.Cz = c.Cz + c.dCz_lef * dlef + dZdQ * Q;
-    const double dMdQ = kq * (c.Cmq + c.dCmq_lef * dlef);
-    t.Cm = c.Cm * c.eta_el + t.Cz * (xcgr - xcg) + c.dCm_lef * dlef + dMdQ * Q + c.dCm;
-  }
-  if (PART != 1) {
-    const double dYdail = c.dCy_a20 + c.dCy_a20_lef * dlef;
-    const double dYdR = kb * (c.Cyr + c.dCyr_lef * dlef);
-    const double dYdP = kb * (c.Cyp + c.dCyp_lef * dlef);
-    t.Cy = c.Cy + c.dCy_lef * dlef + dYdail * dail + c.dCy_r30 * drud + dYdR * R + dYdP * P;
-    const double dNdail = c.dCn_a20 + c.dCn_a20_lef * dlef;
-    const double dNdR = kb * (c.Cnr + c.dCnr_lef * dlef);
-    const double dNdP = kb * (c.Cnp + c.dCnp_lef * dlef);
-    t.Cn = c.Cn + c.dCn_lef * dlef - t.Cy * (xcgr - xcg) * (cbar / B) + dNdail * dail + c.dCn_r30 * drud + dNdR * R + dNdP * P +
-           c.dCnbeta * beta;
-    const double dLdail = c.dCl_a20 + c.dCl_a20_lef * dlef;
-    const double dLdR = kb * (c.Clr + c.dClr_lef * dlef);
-    const double dLdP = kb * (c.Clp + c.dClp_lef * dlef);
-    t.Cl = c.Cl + c.dCl_lef * dlef + dLdail * dail + c.dCl_r30 * drud + dLdR * R + dLdP * P + c.dClbeta * beta;
-  }
+  const double dXdQ = kq * (c.Cxq + c.dCxq_lef * dlef);
+  t.Cx = c.Cx + c.dCx_lef * dlef + dXdQ * Q;
+  const double dZdQ = kq * (c.Czq + c.dCz_lef * dlef);
+  t.Cz = c.Cz + c.dCz_lef * dlef + dZdQ * Q;
+  const double dMdQ = kq * (c.Cmq + c.dCmq_lef * dlef);
+  t.Cm = c.Cm * c.eta_el + t.Cz * (xcgr - xcg) + c.dCm_lef * dlef + dMdQ * Q + c.dCm;
+  const double dYdail = c.dCy_a20 + c.dCy_a20_lef * dlef;
+  const double dYdR = kb * (c.Cyr + c.dCyr_lef * dlef);
+  const double dYdP = kb * (c.Cyp + c.dCyp_lef * dlef);
+  t.Cy = c.Cy + c.dCy_lef * dlef + dYdail * dail + c.dCy_r30 * drud + dYdR * R + dYdP * P;
+  const double dNdail = c.dCn_a20 + c.dCn_a20_lef * dlef;
+  const double dNdR = kb * (c.Cnr + c.dCnr_lef * dlef);
+  const double dNdP = kb * (c.Cnp + c.dCnp_lef * dlef);
+  t.Cn = c.Cn + c.dCn_lef * dlef - t.Cy * (xcgr - xcg) * (cbar / B) + dNdail * dail + c.dCn_r30 * drud + dNdR * R + dNdP * P +
+         c.dCnbeta * beta;
+  const double dLdail = c.dCl_a20 + c.dCl_a20_lef * dlef;
+  const double dLdR = kb * (c.Clr + c.dClr_lef * dlef);
+  const double dLdP = kb * (c.Clp + c.dClp_lef * dlef);
+  t.Cl = c.Cl + c.dCl_lef * dlef + dLdail * dail + c.dCl_r30 * drud + dLdR * R + dLdP * P + c.dClbeta * beta;
 }
 
-
-// The six totals as sums of four partial triples, so that four wavefronts can each look up one table family:
-//   PART 1  longitudinal, 3-D / 2-D tables  {Cx, Cz, Cm}_s        PART 3  longitudinal damping (1-D)  {Cx, Cz, Cm}_d
-//   PART 2  lateral, 3-D / 2-D tables       {Cy, Cn, Cl}_s        PART 4  lateral damping (1-D)       {Cy, Cn, Cl}_d
-// compose_totals() adds them and applies the cg-offset couplings of C/nlplant.c:347,367.  The terms are exactly those
-// of C/nlplant.c:333-377; only the order of the additions differs from the single-expression form (ulp level).
-template <int PART, typename TP>
-F16_DEV void aero_part(TP T, const double *xu, unsigned flags, double *out, int &status) {
-  const double B = 30.0, cbar = 11.32;
-  const double r2d = 180.0 / 3.141592653589793;
-  double vt = xu[6];
-  const double alpha = xu[7] * r2d, beta = xu[8] * r2d;
-  const double P = xu[9], Q = xu[10], R = xu[11];
-  if (vt <= 0.01) vt = 0.01;
-  const double el = xu[13], ail = xu[14], rud = xu[15], lef = xu[16];
-  const double dail = F16_DIVC(ail, 21.5);
-  const double drud = F16_DIVC(rud, 30.0);
-  const double dlef = (1 - F16_DIVC(lef, 25.0));
-  Aero c;
-  aero_hifi(T, alpha, beta, el, flags, c, status);     // lookups not used by this PART are dead code
-#ifdef F16_FAST_DIV
-  const double r2vt = 1.0 / (2 * vt);
-  const double kq = cbar * r2vt, kb = B * r2vt;
-#else
-  const double kq = cbar / (2 * vt), kb = B / (2 * vt);
-#endif
-  if (PART == 1) {
-    out[0] = c.Cx + c.dCx_lef * dlef;
-    out[1] = c.Cz + c.dCz_lef * dlef + kq * (c.dCz_lef * dlef) * Q;     // the dZdQ quirk keeps a 2-D term here
-    out[2] = c.Cm * c.eta_el + c.dCm_lef * dlef;
-  } else if (PART == 3) {
-    out[0] = kq * (c.Cxq + c.dCxq_lef * dlef) * Q;
-    out[1] = kq * c.Czq * Q;
-    out[2] = kq * (c.Cmq + c.dCmq_lef * dlef) * Q + c.dCm;
-  } else if (PART == 2) {
-    out[0] = c.Cy + c.dCy_lef * dlef + (c.dCy_a20 + c.dCy_a20_lef * dlef) * dail + c.dCy_r30 * drud;
-    out[1] = c.Cn + c.dCn_lef * dlef + (c.dCn_a20 + c.dCn_a20_lef * dlef) * dail + c.dCn_r30 * drud;
-    out[2] = c.Cl + c.dCl_lef * dlef + (c.dCl_a20 + c.dCl_a20_lef * dlef) * dail + c.dCl_r30 * drud;
-  } else {
-    out[0] = kb * (c.Cyr + c.dCyr_lef * dlef) * R + kb * (c.Cyp + c.dCyp_lef * dlef) * P;
-    out[1] = kb * (c.Cnr + c.dCnr_lef * dlef) * R + kb * (c.Cnp + c.dCnp_lef * dlef) * P + c.dCnbeta * beta;
-    out[2] = kb * (c.Clr + c.dClr_lef * dlef) * R + kb * (c.Clp + c.dClp_lef * dlef) * P + c.dClbeta * beta;
-  }
-}
 
 F16_DEV void compose_totals(const double *ls, const double *ld, const double *ts, const double *td, double xcg, Totals &t) {
   const double B = 30.0, cbar = 11.32, xcgr = 0.35;

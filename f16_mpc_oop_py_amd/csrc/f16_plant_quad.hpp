@@ -6,7 +6,7 @@
 // members of a family next to each other, so the sub-lanes run the same instructions on payload offset s:
 //     longitudinal wave   s = 0,1,2  ->  Cx, Cz, Cm      (C/nlplant.c:333-347)
 //     lateral wave        s = 0,1,2  ->  Cy, Cn, Cl      (C/nlplant.c:353-377)
-// (sub-lane 3 shadows sub-lane 2).  Same terms as aero_hifi() + aero_totals(), hifi_F16_AeroData.c:1871-1934; the
+// (sub-lane 3 shadows sub-lane 2).  Same terms as aero_totals_phased(), hifi_F16_AeroData.c:1871-1934; the
 // cg-offset couplings (Cm needs Cz_tot, Cn needs Cy_tot) cross the quad with one DPP broadcast.
 #pragma once
 #include "f16_plant.hpp"
