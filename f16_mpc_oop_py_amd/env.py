@@ -154,14 +154,21 @@ class F16Batch:
         return out.t()
 
     # ------------------------------------------------------------------ env.py:105-130
-    def step(self, action=None):
+    def step(self, action=None, auto_reset=False):
         """One explicit-Euler step of every aircraft (env.py:126).  Returns (obs [B,10], reward, done, info) like
         the reference; where the reference exit()s on an envelope violation (env.py:121-124) the aircraft is frozen
-        and `done[b]` is set (status bit F16_ST_ENVELOPE)."""
+        and `done[b]` is set (status bit F16_ST_ENVELOPE).
+        auto_reset (vectorised-env convention): aircraft that are done are put back on their initial
+        condition (env.py:132-135 `reset` for those aircraft only) after the step; the returned observation is the
+        post-reset one and `info["terminal_observation"]` holds the last pre-reset observation of every aircraft."""
         self.rollout(1, action)
         done = (self.status & _lib.F16_ST["ENVELOPE"]) != 0
         reward = torch.ones(self.B, dtype=torch.float64, device=self.device)
-        info = {"fidelity": "high" if self.fi_flag == 1 else "low", "status": self.status}
+        info = {"fidelity": "high" if self.fi_flag == 1 else "low", "status": self.status.clone() if auto_reset else self.status}
+        if auto_reset:
+            info["terminal_observation"] = self.get_obs().clone()
+            self._x[:, done] = self._x_init[:, done]
+            self.status[done] = 0
         return self.get_obs(), reward, done, info
 
     def rollout(self, nsteps, action=None, traj_every=None):
