@@ -214,6 +214,16 @@ def bench_mpc(args, dev, rank, world, fdist, barrier):
         env._calc_LQR_gain()
     barrier()
     dl = fdist.max_over_ranks(time.perf_counter() - t0, dev) / n
+    # the same solves with OSQP's fixed start value rho = 0.1 (the literal config-4 setting of SURVEY.md 8d; the default
+    # above starts from 2 sqrt(tr P / tr A'A) because the QP is not Ruiz-scaled -- DESIGN.md 4)
+    env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn, settings=dict(rho=0.1))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        _, info01 = env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn, settings=dict(rho=0.1), return_info=True)
+    barrier()
+    d01 = fdist.max_over_ranks(time.perf_counter() - t0, dev) / 2
+    it01 = info01["iters"].cpu().numpy()
     flop_per_solve = 5.2e6 + 1.15e5 * float(np.mean(it))          # SURVEY.md 8(d) dense-form accounting
     mfma = None
     try:        # fp64 matrix-core counters of this same workload, recorded from the rocprofv3 --pmc pass (profiles/)
@@ -230,6 +240,10 @@ def bench_mpc(args, dev, rank, world, fdist, barrier):
                          "note": "dense-form FLOP accounting of SURVEY 8(d) over the measured time; the kernels use the "
                                  "Toeplitz recursion, so issued FLOPs are lower"},
             "admm_iters_mean": float(np.mean(it)), "mfma": mfma,
+            "rho_start_0p1": {"value": world * B / d01, "unit": "solves/s", "ms_per_batch": d01 * 1e3,
+                              "admm_iters": {"min": float(it01.min()), "median": float(np.median(it01)),
+                                             "max": float(it01.max()), "mean": float(it01.mean())},
+                              "status_or": int(fdist.or_status(info01["status"]))},
             "linearise_zoh_lqr_per_s": world * B / dl}
 
 

@@ -428,11 +428,14 @@ __device__ __forceinline__ void conv_adjoint(double *out, const double *G, const
   for (int e = lane_id(); e < 3 * N; e += F16_WAVE) {
     const int j = e / 3, c = e - 3 * j;
     double s = 0.0;
-    for (int i = j; i < N; ++i) {
+#pragma unroll 2
+    for (int i = j; i < N; ++i) {              // per-step dot products are independent chains; only the final add is serial
       const double *g = G + (i - j) * 27 + c;
       const double *vi = v + i * NR;
+      double t = 0.0;
 #pragma unroll
-      for (int rr = 0; rr < NR; ++rr) s += g[(NR == 9 ? rr : rows[rr]) * 3] * vi[rr];
+      for (int rr = 0; rr < NR; ++rr) t += g[(NR == 9 ? rr : rows[rr]) * 3] * vi[rr];
+      s += t;
     }
     out[e] = s;
   }
@@ -448,6 +451,11 @@ __device__ __forceinline__ double conv_forward_row(const double *G, const double
   return s;
 }
 
+#ifdef F16_EXP_STAMPB   // diagnostic build: cycles per phase of the build kernel, aircraft b -> u_seq column b
+#define BSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t1_ = __builtin_amdgcn_s_memtime(); tB[i] += t1_ - tb0; tb0 = t1_; }
+#else
+#define BSTAMP(i)
+#endif
 template <bool SETUP_ONLY>
 __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -469,6 +477,9 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
   double *scr = Minv, *X = Minv + 760;                  // DARE scratch (748 doubles), then X (82)
   double *QG = Minv, *QbG = Minv + N * 27;
 
+#ifdef F16_EXP_STAMPB
+  unsigned long long tB[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tb0 = __builtin_amdgcn_s_memtime();
+#endif
   for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
     // a prepared plan (mode 2) already holds everything that depends on the model only: A, Q, Qbar, G_k, P, A'A;
     // what is left per call is the state-dependent part, pred_i = A^(i+1) x and q
@@ -493,8 +504,10 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
       xref[l] = (l >= 5 && l < 8 && a.dem) ? a.dem[(l - 5) * a.ld + b] : v;   // env.py:380-383 (x_ref[5:8] = demands)
     }
     __syncthreads();
+    BSTAMP(0)
     if (!update_only) {
     dare_sda_wave(A, Bm, Q, X, scr);
+    BSTAMP(1)
     // (the gain K = -dlqr of utils.py:96 is not needed itself: it only enters through Q_bar)
     // Q_bar (utils.py:100) solves X = Phi' X Phi + Q + K'RK with Phi = A + B K: for the LQR gain K that equation IS the
     // DARE, so its solution is the DARE solution X itself.  (Measured on the reference's trim models: SDA's X agrees
@@ -504,33 +517,55 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
       for (int e = l; e < 81; e += F16_WAVE) { exm[e] = A[e]; exm[81 + e] = Q[e]; exm[162 + e] = Qb[e]; }
     }
     // ---------------- prediction blocks G_k = A^k B, pred_i = A^(i+1) x (utils.py:171-197 without forming CC/MM)
-    copy(G, Bm, 27);
-    for (int k = 1; k < N; ++k) mm<false, false>(G + k * 27, A, G + (k - 1) * 27, 9, 9, 3);
-    }
-    for (int i = 0; i < N; ++i) {
-      const double *prev = i == 0 ? x9 : pred + (i - 1) * 9;
-      if (l < 9) {
-        double s = 0.0;
-        for (int p = 0; p < 9; ++p) s += A[l * 9 + p] * prev[p];
-        pred[i * 9 + l] = s;
+    {   // lane e = (r,c) < 27 carries G_k[r][c]; G_(k+1)[r][c] = sum_p A[r][p] G_k[p][c] takes the nine operands from the
+        // lanes (p,c) by ds_bpermute: no LDS round trip + barrier per step of this N-long dependent chain
+      const int e = l < 27 ? l : 0, r = e / 3, c = e - 3 * r;
+      double ar[9], gv = Bm[e];
+#pragma unroll
+      for (int p = 0; p < 9; ++p) ar[p] = A[r * 9 + p];
+      __syncthreads();                         // (Bm aliases pred: read before anything writes there)
+      if (l < 27) G[l] = gv;
+      for (int k = 1; k < N; ++k) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int p = 0; p < 9; ++p) sacc += ar[p] * __shfl(gv, p * 3 + c, 64);
+        gv = sacc;
+        if (l < 27) G[k * 27 + l] = gv;
       }
       __syncthreads();
     }
-    // QG_k = Q G_k, QbG_k = Qbar G_k
-    for (int k = 0; k < (update_only ? 0 : N); ++k) {
-      for (int e = l; e < 27; e += F16_WAVE) {
-        const int r = e / 3, c = e - 3 * r;
-        double s1 = 0.0, s2 = 0.0;
-        for (int p = 0; p < 9; ++p) {
-          const double g = G[k * 27 + p * 3 + c];
-          s1 += Q[r * 9 + p] * g;
-          s2 += Qb[r * 9 + p] * g;
-        }
-        QG[k * 27 + e] = s1;
-        QbG[k * 27 + e] = s2;
+    BSTAMP(2)
+    }
+    {   // pred_i = A pred_(i-1): lane r < 9 carries component r, the operands come by v_readlane
+      const int r = l < 9 ? l : 0;
+      double ar[9], pv = x9[r];
+#pragma unroll
+      for (int p = 0; p < 9; ++p) ar[p] = A[r * 9 + p];
+      for (int i = 0; i < N; ++i) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int p = 0; p < 9; ++p) sacc += ar[p] * readlane_f64(pv, p);
+        pv = sacc;
+        if (l < 9) pred[i * 9 + l] = pv;
       }
+      __syncthreads();
+    }
+    BSTAMP(3)
+    // QG_k = Q G_k, QbG_k = Qbar G_k
+    for (int t = l; t < (update_only ? 0 : N * 27); t += F16_WAVE) {
+      const int k = t / 27, e = t - 27 * k, r = e / 3, c = e - 3 * r;
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int p = 0; p < 9; ++p) {
+        const double g = G[k * 27 + p * 3 + c];
+        s1 += Q[r * 9 + p] * g;
+        s2 += Qb[r * 9 + p] * g;
+      }
+      QG[t] = s1;
+      QbG[t] = s2;
     }
     __syncthreads();
+    BSTAMP(4)
     // ---------------- P = 2 (CC' QQ CC + RR) and A'A = CCs'CCs + I + D'D, packed lower, to the workspace.
     // Block (j,l), j >= l, d = j-l:  T(j,l) = TQ(j,l) + G'_{N-1-j} Qbar G_{N-1-l},
     //   TQ(j,l) = TQ(j+1,l+1) + G'_{N-2-j} Q G_{N-2-l} (0 beyond N-2),  TS likewise with S'S and all i <= N-1.
@@ -561,6 +596,7 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
         }
       }
     }
+    BSTAMP(5)
     // ---------------- q = -2 CC' QQ (x_ref - MM x)   (utils.py:112)
     for (int e = l; e < 9 * N; e += F16_WAVE) {
       const int i = e / 9, r = e - 9 * i;
@@ -606,6 +642,10 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
       if (!update_only) { for (int e = l; e < N * 27; e += F16_WAVE) ex[n + e] = G[e]; }
       for (int e = l; e < 9 * N; e += F16_WAVE) ex[n + N * 27 + e] = pred[e];
     }
+    BSTAMP(6)
+#ifdef F16_EXP_STAMPB
+    if (SETUP_ONLY && a.useq && l == 0) for (int i = 0; i < 7; ++i) { a.useq[i * a.ld + b] = (double)tB[i]; tB[i] = 0; }
+#endif
     if (SETUP_ONLY) { __syncthreads(); continue; }
     // ---------------- ADMM (OSQP Algorithm 1, reduced dense form; settings a.s)
     double rho = a.s.rho;
@@ -866,6 +906,9 @@ static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream, int mode) {
     return rc;
   hipLaunchKernelGGL(k_mpc<true>, dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
   if (int rc = hip_check(hipGetLastError(), "f16_mpc_batch setup launch")) return rc;
+#ifdef F16_EXP_STAMPB
+  return 0;
+#endif
   if (mode == 1) return F16_OK;
   return mpc_fast_solve_launch(ctx, a, stream);
 }
