@@ -311,6 +311,25 @@ class F16Batch:
         except Exception:
             pass
 
+    def setup_OSQP(self, p_dem, q_dem, r_dem, hzn, b=0):
+        """The QP of aircraft b in the reference's own form (utils.py:21-167 `setup_OSQP`): dense host arrays
+        (P [n,n], q [n], A [15 hzn, n], l, u) with n = 3 hzn and the reference's row order (9 hzn state rows, 3 hzn
+        command rows, 3 hzn rate rows; unbounded rows carry +-inf), built on the device from the frozen reduced
+        model and the current state -- for callers that hand the QP to a solver of their own, and for the tests."""
+        if self.ssr is None:
+            self.build_ssr()
+        Ad, Bd, Cd = self.ssr
+        dem = torch.empty((3, self.B), dtype=torch.float64, device=self.device)
+        for k, v in enumerate((p_dem, q_dem, r_dem)):
+            dem[k] = torch.as_tensor(v, dtype=torch.float64, device=self.device)
+        n, rows = 3 * int(hzn), 15 * int(hzn)
+        P, q, A = np.zeros((n, n)), np.zeros(n), np.zeros((rows, n))
+        l, u = np.zeros(rows), np.zeros(rows)
+        hp = lambda a: ctypes.c_void_p(a.ctypes.data)
+        self._check(self.lib.f16_mpc_qp_debug(self.ctx.handle, _vp(Ad), _vp(Bd), _vp(Cd), _vp(self._x), _vp(dem), int(b), self.B,
+                                              int(hzn), self.dt, hp(P), hp(q), hp(A), hp(l), hp(u)))
+        return P, q, A, l, u
+
     def _calc_MPC_action(self, p_dem, q_dem, r_dem, hzn, settings=None, return_info=False, relinearise=False,
                          use_plan=False):
         """First MPC move [B,3] (dh,da,dr commands) for demands p,q,r (scalars or [B]) over horizon hzn, from the

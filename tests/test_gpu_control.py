@@ -97,6 +97,9 @@ def test_qp_build_vs_reference_setup_OSQP(xcg, N):
     Ad, Bd, Cd = (soa(np.tile(g5[f"ssr_{k}_xcg{xcg}"], (B, 1, 1))) for k in ("Ad", "Bd", "Cd"))
     dem = torch.zeros((3, B), dtype=torch.float64, device="cuda:0")
     P, q, A, l, u = qp_debug(env, Ad, Bd, Cd, dem, 1, N)
+    env.ssr = (Ad, Bd, Cd)                                   # the class-level mirror of utils.py:21 gives the same QP
+    for got, ref in zip(env.setup_OSQP(0.0, 0.0, 0.0, N, b=1), (P, q, A, l, u)):
+        assert np.array_equal(got, ref)
     tag = f"xcg{xcg}_N{N}"
     assert np.abs(P - g8[f"P_{tag}"]).max() / np.abs(g8[f"P_{tag}"]).max() < 1e-9
     assert np.abs(q - g8[f"q_{tag}"]).max() / np.abs(g8[f"q_{tag}"]).max() < 1e-7
