@@ -325,25 +325,33 @@ __device__ __forceinline__ double reduce3(double v0, double v1, double v2, bool 
   k += dpp_f64<DPP_XOR1>(k);
   return k;
 }
-// quad k of the row (lanes 4k..4k+3) ends up with the total of v[k]
-__device__ __forceinline__ double reduce4(d4_t v, bool h, bool g) {
-  const double s0 = h ? v[0] : v[2], s1 = h ? v[1] : v[3];
-  double k0 = h ? v[2] : v[0], k1 = h ? v[3] : v[1];
-  k0 += dpp_f64<DPP_MIRROR>(s0);
-  k1 += dpp_f64<DPP_MIRROR>(s1);
-  const double s = g ? k0 : k1;
-  double k = g ? k1 : k0;
-  k += dpp_f64<DPP_HMIRROR>(s);
+// reduce4: quad k of the row (lanes 4k..4k+3) ends up with the total of v[k] -- mirror step keeps two of the four values
+// and hands two over, half-mirror step keeps one, then two butterfly steps.  Written naively that is twelve selects per
+// call; instead the caller keeps its four values in slot order (slot_of below): slot 0 = the value this lane's quad ends
+// up owning, slot 1 = the one its half-mirror partner owns, slots 2, 3 = what the mirror partner keeps in its slots 0, 1
+// -- a lane-dependent permutation the caller applies ONCE to the operator it multiplies with (stage 2: the accumulator
+// registers of the KKT inverse).
+__device__ __forceinline__ int slot_of(int slot, bool h, bool g) {
+  const int hh = h ? 1 : 0, gg = g ? 1 : 0;
+  return slot == 0 ? 2 * hh + gg : (slot == 1 ? 2 * hh + (1 - gg) : (slot == 2 ? 2 * (1 - hh) + (1 - gg) : 2 * (1 - hh) + gg));
+}
+__device__ __forceinline__ double reduce4_slots(d4_t p) {
+  const double k0 = p[0] + dpp_f64<DPP_MIRROR>(p[2]);
+  const double k1 = p[1] + dpp_f64<DPP_MIRROR>(p[3]);
+  double k = k0 + dpp_f64<DPP_HMIRROR>(k1);
   k += dpp_f64<DPP_XOR2>(k);
   k += dpp_f64<DPP_XOR1>(k);
   return k;
 }
-// totals land in: lanes 0,1 v0 | 2,3 v1 | 4-7 v2 | 8,9 v3 | 10,11 v4 | 12-15 v5
-__device__ __forceinline__ double reduce6(double v0, double v1, double v2, double v3, double v4, double v5, bool h, bool g,
-                                          bool e) {
-  const double k0 = (h ? v3 : v0) + dpp_f64<DPP_MIRROR>(h ? v0 : v3);
-  const double k1 = (h ? v4 : v1) + dpp_f64<DPP_MIRROR>(h ? v1 : v4);
-  const double k2 = (h ? v5 : v2) + dpp_f64<DPP_MIRROR>(h ? v2 : v5);
+// totals land in: lanes 0,1 v0 | 2,3 v1 | 4-7 v2 | 8,9 v3 | 10,11 v4 | 12-15 v5.  The six inputs come in slot order:
+// p0..p2 = the three values this lane's half of the row keeps (h ? v3,v4,v5 : v0,v1,v2), p3..p5 = the three it hands to
+// its mirror partner -- the caller's operator (the rows of the Toeplitz blocks) is stored in that order per lane, which
+// removes the twelve selects of the first step.
+__device__ __forceinline__ double reduce6_slots(double p0, double p1, double p2, double p3, double p4, double p5, bool g,
+                                                bool e) {
+  const double k0 = p0 + dpp_f64<DPP_MIRROR>(p3);
+  const double k1 = p1 + dpp_f64<DPP_MIRROR>(p4);
+  const double k2 = p2 + dpp_f64<DPP_MIRROR>(p5);
   const double t0 = g ? k0 : k2, t1 = g ? k1 : 0.0;
   double n0 = g ? k2 : k0, n1 = g ? 0.0 : k1;
   n0 += dpp_f64<DPP_HMIRROR>(t0);
@@ -363,10 +371,13 @@ __device__ __forceinline__ double reduce6(double v0, double v1, double v2, doubl
 // Out-of-range blocks read zeros (the vectors are zero-padded in LDS), so there is no per-lane masking.
 // (operand loads and arithmetic are separate calls: the caller issues every LDS read of a phase first -- left alone the
 //  compiler emits read, wait, use in source order and a phase pays three or four LDS round trips instead of one)
+// (slot order of the kept state rows, see reduce6_slots: lanes of the upper half of a row hold rows 3,4,5,0,1,2.  The
+//  state-row vectors in LDS carry NINE doubles per horizon step -- rows 0..5, then 0..2 again -- so that either order
+//  is six contiguous doubles: wp points at 9 * step + (h ? 3 : 0).)
+constexpr int WROW = 9;
 __device__ __forceinline__ void stage1_load(const double *wp, double (&wv)[12]) {
-  const double2 *p = reinterpret_cast<const double2 *>(wp);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) { const double2 t = p[k]; wv[2 * k] = t.x; wv[2 * k + 1] = t.y; }
+  for (int k = 0; k < 6; ++k) { wv[k] = wp[k]; wv[6 + k] = wp[WROW + k]; }
 }
 __device__ __forceinline__ void stage1_fma(const double (&Gd)[2][6][3], const double (&wv)[12], double (&o)[3]) {
 #pragma unroll
@@ -392,7 +403,7 @@ __device__ __forceinline__ void stage3_fma(const double (&Gd)[2][6][3], const do
 }
 
 #define MPC_PHASE() __builtin_amdgcn_sched_barrier(0x7)      /* LDS / memory ops stay put, ALU may float */
-constexpr int WSP = 6 * 64;            // zero-padded state-row vectors (stage 1 reads up to block 31 + 31 + 1)
+constexpr int WSP = WROW * 64;         // zero-padded state-row vectors (stage 1 reads up to block 31 + 31 + 1)
 constexpr int XOFF = 3 * 32;           // zeros in front of x~ (stage 3 reads down to block -31)
 constexpr int XTP = XOFF + FN + 8;
 
@@ -423,8 +434,10 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
   const bool xown = inb && (lc == 0 || lc == 4 || lc == 8);
   const int xe = 3 * blk + (lc >> 2);
   const int xec = xe < FN ? xe : FN - 1;                        // in-range index for lanes that own no variable
-  double *const wdst = kind == 1 ? wsP + 6 * blk + sub : (kind == 2 ? wc + k3 : wr + k3);
-  double *const ydst = kind == 1 ? ysP + 6 * blk + sub : (kind == 2 ? yc + k3 : yr + k3);
+  double *const wdst = kind == 1 ? wsP + WROW * blk + sub : (kind == 2 ? wc + k3 : wr + k3);
+  double *const ydst = kind == 1 ? ysP + WROW * blk + sub : (kind == 2 ? yc + k3 : yr + k3);
+  const int dup = (kind == 1 && sub < 3) ? 6 : 0;              // state rows 0..2 are stored twice (stage1_load)
+  const double *const wsrc = wsP + WROW * (blk + 2 * q) + (h ? 3 : 0), *const ysrc = ysP + WROW * (blk + 2 * q) + (h ? 3 : 0);
   // zero everything once: the pads are never written again
   for (int i = tid; i < WSP; i += FT) { wsP[i] = 0.0; ysP[i] = 0.0; }
   for (int i = tid; i < XTP; i += FT) xtP[i] = 0.0;
@@ -464,7 +477,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
     double *const exm = const_cast<double *>(ex) + mpc_ext_model(N);      // A | Q | Qbar | rho of a prepared plan
     double *const tl = a.tiles ? a.tiles + (size_t)b * MPC_TILE_DOUBLES + (size_t)(w * NT * 4) * 64 + l : nullptr;
     double rho = a.mode == 2 ? exm[243] : a.s.rho;
-    if (kind) *wdst = (a.mode == 2 ? rho : 0.0) * z - y;       // w = rho z - y of the start point (zero unless warm)
+    if (kind) { const double w0 = (a.mode == 2 ? rho : 0.0) * z - y; wdst[0] = w0; wdst[dup] = w0; }   // w = rho z - y of the start point (zero unless warm)
     if (!(rho > 0.0)) {   // automatic: balance the two terms of P + rho A'A (our QP is not Ruiz-scaled as OSQP's would be)
       double tr[2] = {xown ? Pg[tri(xe, xe)] : 0.0, xown ? Ag[tri(xe, xe)] : 0.0};
       const bool sums[2] = {true, true};
@@ -519,6 +532,19 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         t0 = tP2;
 #endif
       }
+      // ---- stage 2 reads the inverse in slot order (reduce4_slots): one lane-dependent register permutation per
+      // factorisation instead of twelve selects per iteration
+      {
+        const int i0 = slot_of(0, h, g), i1 = slot_of(1, h, g), i2 = slot_of(2, h, g), i3 = slot_of(3, h, g);
+#pragma unroll
+        for (int J = 0; J < NTT; ++J) {
+          const d4_t t = acc[J];
+          acc[J][0] = sel4(t[0], t[1], t[2], t[3], i0);
+          acc[J][1] = sel4(t[0], t[1], t[2], t[3], i1);
+          acc[J][2] = sel4(t[0], t[1], t[2], t[3], i2);
+          acc[J][3] = sel4(t[0], t[1], t[2], t[3], i3);
+        }
+      }
       // ---- this lane's two Toeplitz blocks (utils.py:171-197: CC[i,j] = A^(i-j) B, rows S kept); loaded after the call
       double Gd[2][6][3];
       {
@@ -527,9 +553,11 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         for (int bb = 0; bb < 2; ++bb) {
           const int d = 2 * q + bb;
 #pragma unroll
-          for (int rr = 0; rr < 6; ++rr)
+          for (int rr = 0; rr < 6; ++rr) {
+            const int srow = h ? SR[(rr + 3) % 6] : SR[rr];         // slot order of the kept rows (reduce6_slots)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) Gd[bb][rr][c] = d < N ? Gg[d * 27 + SR[rr] * 3 + c] : 0.0;
+            for (int c = 0; c < 3; ++c) Gd[bb][rr][c] = d < N ? Gg[d * 27 + srow * 3 + c] : 0.0;
+          }
         }
       }
       const double rinv = 1.0 / rho;
@@ -541,7 +569,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
       // ---- A: rhs = sigma x - q + A'(rho z - y)
       {
         double wv[12], o1[3];
-        stage1_load(wsP + 6 * (blk + 2 * q), wv);
+        stage1_load(wsrc, wv);
         const double wce = wc[xec], wre = wr[xec], wrn = wr[xec + 3];
         MPC_PHASE();
         stage1_fma(Gd, wv, o1);
@@ -551,7 +579,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
       MSTAMP(0)
       __syncthreads();
       MSTAMP(1)
-      // ---- B: x~ = Minv rhs from the accumulators (element (16w + 4qq + lq, 16J + lc) in acc[J][qq])
+      // ---- B: x~ = Minv rhs from the accumulators (element (16w + 4 slot_of(qq) + lq, 16J + lc) in acc[J][qq])
       if (w < NTT) {
         d4_t part = {0.0, 0.0, 0.0, 0.0};
         double rj[NTT];
@@ -563,7 +591,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq) part[qq] = fma(acc[J][qq], rj[J], part[qq]);
         }
-        const double v = reduce4(part, h, g);
+        const double v = reduce4_slots(part);
         const int row = 16 * w + (lc & 12) + lq;
         if ((lc & 3) == 0 && row < n) xtP[XOFF + row] = -v;
       }
@@ -577,7 +605,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         const double xte = xtP[XOFF + xec], xk = xtP[XOFF + k3], xkm = xtP[XOFF + k3 - 3];
         MPC_PHASE();
         stage3_fma(Gd, xv, o3);
-        const double zs = reduce6(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], h, g, e);
+        const double zs = reduce6_slots(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], g, e);
         if (xown) xs = alpha * xte + (1 - alpha) * xs;
         if (kind) {
           const double zt = kind == 1 ? zs : (kind == 2 ? xk : xk - xkm);
@@ -591,14 +619,14 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
       const bool check = (it % a.s.check_every == 0) || it >= a.s.max_iter;
       if (check) {
         // ---- residuals (OSQP termination test): A x, P x, A' y
-        if (kind) *ydst = y;
+        if (kind) { ydst[0] = y; ydst[dup] = y; }
         __syncthreads();                                        // all reads of x~ are done: the buffer now carries x
         if (xown) xtP[XOFF + xe] = xs;
         __syncthreads();
         double o3[6], o1[3], px3[3] = {0.0, 0.0, 0.0};
         { double xv[6]; stage3_load(xtP + XOFF + 3 * (blk - 2 * q - 1), xv); stage3_fma(Gd, xv, o3); }
-        const double axs = reduce6(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], h, g, e);
-        { double wv[12]; stage1_load(ysP + 6 * (blk + 2 * q), wv); stage1_fma(Gd, wv, o1); }
+        const double axs = reduce6_slots(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], g, e);
+        { double wv[12]; stage1_load(ysrc, wv); stage1_fma(Gd, wv, o1); }
         const double atys = reduce3(o1[0], o1[1], o1[2], h, g);
         if (inb) {                                              // P x: row blk's 16 lanes split the columns six apiece
 #pragma unroll
@@ -636,9 +664,9 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
           block_reduce<2>(u, kinds, red);
           const double ndy = u[0], supp = u[1];
           if (ndy > a.s.eps_prim_inf && supp < -a.s.eps_prim_inf * ndy) {
-            if (kind) *ydst = dy;
+            if (kind) { ydst[0] = dy; ydst[dup] = dy; }
             __syncthreads();
-            { double wv[12]; stage1_load(ysP + 6 * (blk + 2 * q), wv); stage1_fma(Gd, wv, o1); }
+            { double wv[12]; stage1_load(ysrc, wv); stage1_fma(Gd, wv, o1); }
             const double t = reduce3(o1[0], o1[1], o1[2], h, g);
             double wv[1] = {xown ? fabs(t + yc[xe] + (yr[xe] - yr[xe + 3])) : 0.0};
             const bool km[1] = {false};
@@ -656,7 +684,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         }
       }
       // w = rho z - y for the next iteration
-      if (kind) *wdst = rho * z - y;
+      if (kind) { const double wn = rho * z - y; wdst[0] = wn; wdst[dup] = wn; }
       MSTAMP(4)
       __syncthreads();
       MSTAMP(5)
