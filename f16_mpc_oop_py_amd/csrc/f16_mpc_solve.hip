@@ -484,7 +484,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
       block_reduce<2>(tr, sums, red);
       rho = fmin(fmax(RHO_AUTO_SCALE * sqrt(tr[0] / tr[1]), 1e-6), 1e6);
     }
-    int it = 0;
+    int it = 0, to_check = a.s.check_every > 0 ? a.s.check_every : 1;
     double rp = INFINITY, rd = INFINITY;
     bool converged = false, infeasible = false, ok = true;
     bool done = a.s.max_iter < 0;                              // (max_iter == 0: factor only, used for timing)
@@ -616,7 +616,8 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
           z = zn;
         }
       }
-      const bool check = (it % a.s.check_every == 0) || it >= a.s.max_iter;
+      const bool check = --to_check == 0 || it >= a.s.max_iter;      // it % check_every == 0, without the division
+      if (to_check == 0) to_check = a.s.check_every;
       if (check) {
         // ---- residuals (OSQP termination test): A x, P x, A' y
         if (kind) { ydst[0] = y; ydst[dup] = y; }
