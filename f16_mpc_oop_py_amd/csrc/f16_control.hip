@@ -457,25 +457,26 @@ __device__ __forceinline__ double conv_forward_row(const double *G, const double
 #define BSTAMP(i)
 #endif
 template <bool SETUP_ONLY>
-__global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
+__global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int N = a.N, n = 3 * N, np = n * (n + 1) / 2, ms = 6 * N, m = 12 * N;
   const int l = lane_id();
   Bump al{smem};
-  // R0 is time-shared: DARE scratch -> Q G_k / Qbar G_k blocks -> packed KKT inverse
-  const int r0 = SETUP_ONLY ? max(54 * N, 1100) : max(max(np, 54 * N), 1100);
+  // R0 is time-shared: DARE scratch -> (build) pred | Q-weighted error | q -> (generic solver) packed KKT inverse.
+  // Build-only launches keep the footprint at 17.8 KB for N = 30 (eight wavefronts per CU): the Q G_k / Qbar G_k blocks
+  // of the P recursion are formed just in time (jit, 54 doubles) instead of being stored for all k.
+  const int r0 = SETUP_ONLY ? 1100 : max(np, 1100);
   double *Minv = al.take(r0);
   double *G = al.take(N * 27);
   double *A = al.take(81), *Q = al.take(81), *Qb = al.take(81);
-  double *qv = al.take(n);
-  double *wbuf = al.take(SETUP_ONLY ? 9 * N : m);
-  double *pred = al.take(9 * N);      // MM x: A^(i+1) x
-  double *Bm = pred;                  // B is dead once G_0 is copied out, before pred is first written
+  double *jit = al.take(54);
+  double *Bm = jit;                   // B is dead once G_0 is copied out, long before the P recursion uses jit
   double *x9 = al.take(9), *xref = al.take(9);
+  double *qv, *wbuf, *pred;           // q | QQ (x_ref - MM x) | MM x: A^(i+1) x
   double *xs = nullptr, *xt = nullptr, *rhs = nullptr, *tv = nullptr;      // generic solver only
-  if (!SETUP_ONLY) { xs = al.take(n); xt = al.take(n); rhs = al.take(n); tv = al.take(n); }
+  if (SETUP_ONLY) { pred = Minv; wbuf = Minv + 9 * N; qv = Minv + 18 * N; }      // 21 N <= 840 < 1100
+  else { qv = al.take(n); wbuf = al.take(m); pred = al.take(9 * N); xs = al.take(n); xt = al.take(n); rhs = al.take(n); tv = al.take(n); }
   double *scr = Minv, *X = Minv + 760;                  // DARE scratch (748 doubles), then X (82)
-  double *QG = Minv, *QbG = Minv + N * 27;
 
 #ifdef F16_EXP_STAMPB
   unsigned long long tB[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tb0 = __builtin_amdgcn_s_memtime();
@@ -551,52 +552,6 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
       __syncthreads();
     }
     BSTAMP(3)
-    // QG_k = Q G_k, QbG_k = Qbar G_k
-    for (int t = l; t < (update_only ? 0 : N * 27); t += F16_WAVE) {
-      const int k = t / 27, e = t - 27 * k, r = e / 3, c = e - 3 * r;
-      double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-      for (int p = 0; p < 9; ++p) {
-        const double g = G[k * 27 + p * 3 + c];
-        s1 += Q[r * 9 + p] * g;
-        s2 += Qb[r * 9 + p] * g;
-      }
-      QG[t] = s1;
-      QbG[t] = s2;
-    }
-    __syncthreads();
-    BSTAMP(4)
-    // ---------------- P = 2 (CC' QQ CC + RR) and A'A = CCs'CCs + I + D'D, packed lower, to the workspace.
-    // Block (j,l), j >= l, d = j-l:  T(j,l) = TQ(j,l) + G'_{N-1-j} Qbar G_{N-1-l},
-    //   TQ(j,l) = TQ(j+1,l+1) + G'_{N-2-j} Q G_{N-2-l} (0 beyond N-2),  TS likewise with S'S and all i <= N-1.
-    double *Pg = a.Ppk + (size_t)b * np, *Ag = a.Apk + (size_t)b * np;
-    for (int ch = l; ch < (update_only ? 0 : N * 9); ch += F16_WAVE) {       // one chain per (diagonal d, element (ra,cb))
-      const int d = ch / 9, ee = ch - 9 * d, ra = ee / 3, cb = ee - 3 * ra;
-      double tq = 0.0, ts = 0.0;
-      for (int j = N - 1; j >= d; --j) {
-        const int lcol = j - d;
-        if (j <= N - 2) {
-          double s = 0.0;
-          for (int p = 0; p < 9; ++p) s += QG[(N - 2 - j) * 27 + p * 3 + ra] * G[(N - 2 - lcol) * 27 + p * 3 + cb];
-          tq += s;
-        }
-        double sb = 0.0, ss = 0.0;
-        for (int p = 0; p < 9; ++p) sb += QbG[(N - 1 - j) * 27 + p * 3 + ra] * G[(N - 1 - lcol) * 27 + p * 3 + cb];
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr) ss += G[(N - 1 - j) * 27 + SROW[rr] * 3 + ra] * G[(N - 1 - lcol) * 27 + SROW[rr] * 3 + cb];
-        ts += ss;
-        const int gi = 3 * j + ra, gj = 3 * lcol + cb;
-        if (gi >= gj) {
-          double pv = 2.0 * (tq + sb + ((gi == gj) ? 1.0 : 0.0));      // RR = I (env.py:405-407)
-          double av = ts;
-          if (gi == gj) av += 1.0 + ((j < N - 1) ? 2.0 : 1.0);         // I'I + D'D diagonal
-          if (d == 1 && ra == cb) av += -1.0;                          // D'D sub-diagonal block -I
-          Pg[tri(gi, gj)] = pv;
-          Ag[tri(gi, gj)] = av;
-        }
-      }
-    }
-    BSTAMP(5)
     // ---------------- q = -2 CC' QQ (x_ref - MM x)   (utils.py:112)
     for (int e = l; e < 9 * N; e += F16_WAVE) {
       const int i = e / 9, r = e - 9 * i;
@@ -611,6 +566,71 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
     for (int e = l; e < n; e += F16_WAVE) qv[e] = -2.0 * qv[e];
     __threadfence_block();
     __syncthreads();
+    BSTAMP(4)
+    // ---------------- P = 2 (CC' QQ CC + RR) and A'A = CCs'CCs + I + D'D, packed lower, to the workspace.
+    // Block (j,l), j >= l, d = j-l:  T(j,l) = TQ(j,l) + G'_{N-1-j} Qbar G_{N-1-l},
+    //   TQ(j,l) = TQ(j+1,l+1) + G'_{N-2-j} Q G_{N-2-l} (0 beyond N-2),  TS likewise with S'S and all i <= N-1.
+    // One chain per (diagonal d, element (ra,cb)), up to MAXCH per lane; all chains walk j together, so the two weighted
+    // blocks a step needs (Q G_{N-2-j}, Qbar G_{N-1-j}) are the same for every lane and are formed once per step (jit).
+    // This loop is LDS-bandwidth-bound (42 operand reads for 24 FMAs per chain element).  Tried and dropped: one lane per
+    // block diagonal (216 FMAs for 27 + 72 reads per step, running sums in registers, no jit broadcast conflicts) --
+    // fewer LDS bytes but only N active lanes and as many address computations for the packed stores: 20 % slower.
+    double *Pg = a.Ppk + (size_t)b * np, *Ag = a.Apk + (size_t)b * np;
+    if (!update_only) {
+      constexpr int MAXCH = (9 * MAXN + F16_WAVE - 1) / F16_WAVE;
+      constexpr int SR[6] = {2, 3, 4, 5, 6, 8};                            // = SROW at compile time: the S'S operands
+      double tq[MAXCH], ts[MAXCH];                                         // below are six of the nine just read
+#pragma unroll
+      for (int t = 0; t < MAXCH; ++t) { tq[t] = 0.0; ts[t] = 0.0; }
+      const int wh = l >= 27 ? 1 : 0, je = l - 27 * wh, jr = je / 3, jc = je - 3 * jr;      // jit roles of lanes 0..53
+      const double *Qw = wh ? Qb : Q;
+      __syncthreads();
+      for (int j = N - 1; j >= 0; --j) {
+        const int kq = wh ? N - 1 - j : N - 2 - j;
+        if (l < 54 && kq >= 0) {
+          double sj = 0.0;
+#pragma unroll
+          for (int p = 0; p < 9; ++p) sj += Qw[jr * 9 + p] * G[kq * 27 + p * 3 + jc];
+          jit[l] = sj;
+        }
+        __syncthreads();
+        const double *QGk = jit, *QbGk = jit + 27;
+#pragma unroll
+        for (int t = 0; t < MAXCH; ++t) {
+          const int ch = l + F16_WAVE * t, d = ch / 9, ee = ch - 9 * d, ra = ee / 3, cb = ee - 3 * ra;
+          __builtin_amdgcn_sched_barrier(0);      // one chain at a time: bounds the live operands (two waves per SIMD)
+          if (ch < 9 * N && j >= d) {
+            const int lcol = j - d;
+            if (j <= N - 2) {
+              double s = 0.0;
+#pragma unroll
+              for (int p = 0; p < 9; ++p) s += QGk[p * 3 + ra] * G[(N - 2 - lcol) * 27 + p * 3 + cb];
+              tq[t] += s;
+            }
+            double gc[9];
+#pragma unroll
+            for (int p = 0; p < 9; ++p) gc[p] = G[(N - 1 - lcol) * 27 + p * 3 + cb];
+            double sb = 0.0, ss = 0.0;
+#pragma unroll
+            for (int p = 0; p < 9; ++p) sb += QbGk[p * 3 + ra] * gc[p];
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr) ss += G[(N - 1 - j) * 27 + SR[rr] * 3 + ra] * gc[SR[rr]];
+            ts[t] += ss;
+            const int gi = 3 * j + ra, gj = 3 * lcol + cb;
+            if (gi >= gj) {
+              double pv = 2.0 * (tq[t] + sb + ((gi == gj) ? 1.0 : 0.0));      // RR = I (env.py:405-407)
+              double av = ts[t];
+              if (gi == gj) av += 1.0 + ((j < N - 1) ? 2.0 : 1.0);         // I'I + D'D diagonal
+              if (d == 1 && ra == cb) av += -1.0;                          // D'D sub-diagonal block -I
+              Pg[tri(gi, gj)] = pv;
+              Ag[tri(gi, gj)] = av;
+            }
+          }
+        }
+        __syncthreads();                                                    // jit is rewritten by the next step
+      }
+    }
+    BSTAMP(5)
     // ---------------- bounds of the kept rows (utils.py:129-152): [6N state | 3N command | 3N rate]
     double lo[MAXT], hi[MAXT], z[MAXT], y[MAXT], dy[MAXT];
 #pragma unroll
@@ -794,12 +814,12 @@ __global__ __launch_bounds__(64) void k_mpc(MpcArgs a) {
   }
 }
 
-static size_t mpc_lds_doubles(int N, bool setup_only) {
+static size_t mpc_lds_doubles(int N, bool setup_only) {      // mirrors the Bump allocations at the top of k_mpc
   const int n = 3 * N, np = n * (n + 1) / 2, m = 12 * N;
   auto ev = [](int v) { return (size_t)((v + 1) & ~1); };
-  int r0 = (!setup_only && np > 54 * N) ? np : 54 * N;
-  if (r0 < 1100) r0 = 1100;
-  return ev(r0) + ev(N * 27) + ev(81) * 3 + ev(n) + ev(setup_only ? 9 * N : m) + ev(9 * N) + ev(9) * 2 + (setup_only ? 0 : 4 * ev(n));
+  const int r0 = (!setup_only && np > 1100) ? np : 1100;
+  const size_t common = ev(r0) + ev(N * 27) + ev(81) * 3 + ev(54) + ev(9) * 2;
+  return setup_only ? common : common + ev(n) + ev(m) + ev(9 * N) + 4 * ev(n);
 }
 
 }  // namespace f16

@@ -13,9 +13,9 @@ env.build_ssr()
 for _ in range(3):      # the first call pays first-touch / code-load costs
     u, info = env._calc_MPC_action(0, 0, 0, 30, return_info=True)
     torch.cuda.synchronize()
-s = info["u_seq"][:, :7].cpu().numpy() * 24      # [B, 7]
-names = ["load+Q", "DARE", "G_k", "pred", "QG", "P,A'A", "q+bounds+ext"]
+s = info["u_seq"][:, :7].cpu().numpy()      # [B, 7] shader-clock cycles
+names = ["load+Q", "DARE", "G_k", "pred", "q", "P,A'A", "bounds+ext"]
 for q, lab in ((None, "mean"), (50, "median"), (5, "p5"), (95, "p95")):
     v = s.mean(0) if q is None else np.percentile(s, q, axis=0)
-    print("%-6s cycles (s_memtime x 24): " % lab + " | ".join("%s %d" % (n, x) for n, x in zip(names, v)) + " | total %d" % v.sum())
+    print("%-6s cycles: " % lab + " | ".join("%s %d" % (n, x) for n, x in zip(names, v)) + " | total %d" % v.sum())
 print("aircraft 0:", s[0].astype(int), " aircraft B-1:", s[-1].astype(int))
