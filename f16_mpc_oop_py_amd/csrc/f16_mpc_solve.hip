@@ -16,7 +16,6 @@
 //     barriers, 410 KB).
 #include <hip/hip_runtime.h>
 #include <math.h>
-#include <stdlib.h>
 
 #include "f16_mpc.hpp"
 #include "f16_smallmat.hpp"
@@ -722,446 +721,6 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
   }
 }
 
-// ===============================================================================================================
-// k_mpc_fast2: the same solver on 256 lanes per aircraft, TWO workgroups per CU.
-// The two wavefronts that share a SIMD in k_mpc_fast belong to one aircraft and meet at the same three barriers: they
-// wait for LDS together and then compete for the VALU together.  Here each physical lane carries two LOGICAL lanes of
-// the 512-lane layout (slot s = logical lane tid + 256 s: same position in its DPP row, horizon step blk + 16 s,
-// tile row w + 4 s), so the per-lane Toeplitz blocks -- identical in every DPP row -- are held once for both, the
-// per-aircraft register footprint halves and a second, independent aircraft runs on the same SIMDs and fills the
-// stalls.  Arithmetic per logical lane, reduction trees and workgroup reductions are those of k_mpc_fast (results are
-// bit-identical; plans and warm-start records are interchangeable).
-constexpr int FT2 = 256;
-
-// workgroup reductions over the 8 LOGICAL waves in k_mpc_fast's order (red: [8][NV])
-template <int NV>
-__device__ __forceinline__ void block_reduce2(double (&v0)[NV], double (&v1)[NV], const bool (&is_sum)[NV], double *red) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    v0[i] = is_sum[i] ? wave_sum(v0[i]) : wave_max(v0[i]);
-    v1[i] = is_sum[i] ? wave_sum(v1[i]) : wave_max(v1[i]);
-  }
-  __syncthreads();
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) { red[wv * NV + i] = v0[i]; red[(wv + 4) * NV + i] = v1[i]; }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    double r = red[i];
-    for (int w = 1; w < 8; ++w) r = is_sum[i] ? r + red[w * NV + i] : fmax(r, red[w * NV + i]);
-    v0[i] = r;
-  }
-}
-
-// tile row `wrow` of P + r A'A + sigma I from the packed lower triangles (identity on the padding rows)
-template <int NTT>
-__device__ __forceinline__ void load_tile_row(d4_t (&acc)[NT], const double *Pg, const double *Ag, double r, double sigma, int n,
-                                              int wrow, int lc, int lq) {
-#pragma unroll
-  for (int J = 0; J < NTT; ++J) {
-    double pv[4], av[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = 16 * wrow + 4 * q + lq, j = 16 * J + lc;
-      const bool in = i < n && j < n;
-      const int e = in ? (i >= j ? tri(i, j) : tri(j, i)) : 0;
-      pv[q] = Pg[e]; av[q] = Ag[e];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = 16 * wrow + 4 * q + lq, j = 16 * J + lc;
-      acc[J][q] = (i < n && j < n) ? pv[q] + r * av[q] + (i == j ? sigma : 0.0) : (i == j ? 1.0 : 0.0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// mfma_inverse for four wavefronts: wave w sweeps tile row w and (NTT > 4, w < NTT - 4) tile row w + 4
-template <int NTT>
-__device__ __forceinline__ bool mfma_inverse2(d4_t *acc0_out, d4_t *acc1_out, double *Cs, const double *Pg, const double *Ag,
-                                              double r, double sigma, int n) {
-  constexpr bool TWO = NTT > 4;
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-  int lc = l & 15, lq = l >> 4;
-  asm volatile("" : "+v"(lc), "+v"(lq));
-  bool ok = true;
-  d4_t a0[NT], a1[NT];
-  load_tile_row<NTT>(a0, Pg, Ag, r, sigma, n, w, lc, lq);
-  const bool has1 = TWO && w + 4 < NTT;
-  if (has1) load_tile_row<NTT>(a1, Pg, Ag, r, sigma, n, w + 4, lc, lq);
-  double *c0 = Cs, *c1 = Cs + PAN_SIZE;
-  __syncthreads();
-  if (w == 0) {
-#pragma unroll
-    for (int J = 0; J < NTT; ++J) c0[(16 * J + lc) * 4 + lq] = a0[J][0];
-    publish_dinv(c0, 0, l);
-  }
-  for (int Kt = 0; Kt < NTT; ++Kt) {
-    __syncthreads();
-    if (w < NTT) inverse_step<NTT, 0>(a0, c0, c1, Kt, w, lc, lq, ok);
-    if (has1) inverse_step<NTT, 0>(a1, c0, c1, Kt, w + 4, lc, lq, ok);
-    __syncthreads();
-    if (w < NTT) inverse_step<NTT, 1>(a0, c1, c0, Kt, w, lc, lq, ok);
-    if (has1) inverse_step<NTT, 1>(a1, c1, c0, Kt, w + 4, lc, lq, ok);
-    __syncthreads();
-    if (w < NTT) inverse_step<NTT, 2>(a0, c0, c1, Kt, w, lc, lq, ok);
-    if (has1) inverse_step<NTT, 2>(a1, c0, c1, Kt, w + 4, lc, lq, ok);
-    __syncthreads();
-    if (w < NTT) inverse_step<NTT, 3>(a0, c1, c0, Kt, w, lc, lq, ok);
-    if (has1) inverse_step<NTT, 3>(a1, c1, c0, Kt, w + 4, lc, lq, ok);
-  }
-#pragma unroll
-  for (int J = 0; J < NTT; ++J) { acc0_out[J] = a0[J]; acc1_out[J] = a1[J]; }
-  return __syncthreads_and(ok) != 0;
-}
-
-template <int NTT>
-__global__ __launch_bounds__(FT2, 2) void k_mpc_fast2(MpcArgs a) {
-  __shared__ __attribute__((aligned(16))) double wsP[WSP], ysP[WSP], xtP[XTP], Cs[2 * FN * 4 + 40];
-  __shared__ double rhs[FN], wc[FN], wr[FN + 4], yc[FN], yr[FN + 4], red[8 * 8];
-  __shared__ double accL[2 * NT * 4 * 64];                    // slot-ordered inverse, tile rows 4 and 5: [wave][J][slot][lane]
-  constexpr bool TWO = NTT > 4;
-  const int N = a.N, n = 3 * N;
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lc = l & 15, lq = l >> 4, blk0 = tid >> 4, q = lc;
-  const bool h = lc & 8, g = lc & 4, e = lc & 2;
-  const bool has1 = TWO && w + 4 < NTT;                       // this wave also owns tile row w + 4
-  // ---- lane roles: by position in the DPP row (same for both slots), active where the slot's horizon step exists
-  int kindlc = 0, sub = 0;
-  if (lc == 0 || lc == 2 || lc == 4) { kindlc = 1; sub = lc >> 1; }
-  else if (lc == 8 || lc == 10 || lc == 12) { kindlc = 1; sub = 3 + ((lc - 8) >> 1); }
-  else if (lc == 1 || lc == 3 || lc == 5) { kindlc = 2; sub = (lc - 1) >> 1; }
-  else if (lc == 9 || lc == 11 || lc == 13) { kindlc = 3; sub = (lc - 9) >> 1; }
-  const bool xlane = lc == 0 || lc == 4 || lc == 8;
-  const int dup = (kindlc == 1 && sub < 3) ? 6 : 0;
-  // slot 1 addresses = slot 0 + a constant (16 horizon steps further on)
-  const int doff = kindlc == 1 ? 16 * WROW : 48;
-  double *const wdst0 = kindlc == 1 ? wsP + WROW * blk0 + sub : (kindlc == 2 ? wc + 3 * blk0 + sub : wr + 3 * blk0 + sub);
-  double *const ydst0 = kindlc == 1 ? ysP + WROW * blk0 + sub : (kindlc == 2 ? yc + 3 * blk0 + sub : yr + 3 * blk0 + sub);
-  const double *const wsrc0 = wsP + WROW * (blk0 + 2 * q) + (h ? 3 : 0), *const ysrc0 = ysP + WROW * (blk0 + 2 * q) + (h ? 3 : 0);
-  const double *const xsrc0 = xtP + XOFF + 3 * (blk0 - 2 * q - 1);
-  const int k30 = 3 * blk0 + sub, xe0 = 3 * blk0 + (lc >> 2);
-  int kind[2], k3[2], xe[2], xec[2];
-  bool inb[2], xown[2];
-  double *wdst[2], *ydst[2];
-  const double *wsrc[2], *ysrc[2], *xsrc[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int blk = blk0 + 16 * s;
-    inb[s] = blk < N;
-    kind[s] = inb[s] ? kindlc : 0;
-    k3[s] = k30 + 48 * s;
-    xown[s] = inb[s] && xlane;
-    xe[s] = xe0 + 48 * s;
-    xec[s] = xe[s] < FN ? xe[s] : FN - 1;
-    wdst[s] = wdst0 + doff * s;
-    ydst[s] = ydst0 + doff * s;
-    wsrc[s] = wsrc0 + 16 * WROW * s;
-    ysrc[s] = ysrc0 + 16 * WROW * s;
-    xsrc[s] = xsrc0 + 48 * s;
-  }
-  for (int i = tid; i < WSP; i += FT2) { wsP[i] = 0.0; ysP[i] = 0.0; }
-  for (int i = tid; i < XTP; i += FT2) xtP[i] = 0.0;
-  for (int i = tid; i < FN + 4; i += FT2) { wr[i] = 0.0; yr[i] = 0.0; }
-  for (int i = tid; i < FN; i += FT2) { rhs[i] = 0.0; wc[i] = 0.0; yc[i] = 0.0; }
-  __syncthreads();
-
-  const double sigma = a.s.sigma, alpha = a.s.alpha;
-  const long b = blockIdx.x;                                   // one aircraft per workgroup (grid = B)
-  const double *ex = a.ext + (size_t)b * mpc_ext_doubles(N);
-  const double *Pg = a.Ppk + (size_t)b * (n * (n + 1) / 2), *Ag = a.Apk + (size_t)b * (n * (n + 1) / 2);
-  const double *Gg = ex + n, *pred = ex + n + 27 * N;
-  double qe[2], lo[2], hi[2], z[2], y[2], dy[2], xs[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int blk = blk0 + 16 * s;
-    qe[s] = xown[s] ? ex[xe[s]] : 0.0;
-    lo[s] = 0.0; hi[s] = 0.0; z[s] = 0.0; y[s] = 0.0; dy[s] = 0.0; xs[s] = 0.0;
-    if (kind[s] == 1) {
-      const double pm = pred[blk * 9 + SROW[sub]];
-      lo[s] = SLB[sub] - pm; hi[s] = SUB[sub] - pm;
-    } else if (kind[s] == 2) {
-      lo[s] = ULB[sub]; hi[s] = UUB[sub];
-    } else if (kind[s] == 3) {
-      if (blk == 0) {
-        const double act = a.x ? a.x[(13 + sub) * a.ld + b] : 0.0;
-        lo[s] = act + RLB[sub] * a.dt; hi[s] = act + RUB[sub] * a.dt;
-      } else { lo[s] = RLB[sub]; hi[s] = RUB[sub]; }           // reference quirk: not scaled by dt (utils.py:151-152)
-    }
-    if (a.warm && a.warm_load) {
-      const double *wms = a.warm + (size_t)b * MPC_WARM_DOUBLES + tid + FT2 * s;
-      const double x0 = wms[0], z0 = wms[FT], y0 = wms[2 * FT];
-      if (isfinite(x0) && isfinite(z0) && isfinite(y0)) { xs[s] = x0; z[s] = z0; y[s] = y0; }
-    }
-  }
-  double *const exm = const_cast<double *>(ex) + mpc_ext_model(N);
-  double *const tl0 = a.tiles ? a.tiles + (size_t)b * MPC_TILE_DOUBLES + (size_t)(w * NT * 4) * 64 + l : nullptr;
-  double *const tl1 = a.tiles ? a.tiles + (size_t)b * MPC_TILE_DOUBLES + (size_t)((w + 4) * NT * 4) * 64 + l : nullptr;
-  double rho = a.mode == 2 ? exm[243] : a.s.rho;
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-    if (kind[s]) { const double w0 = (a.mode == 2 ? rho : 0.0) * z[s] - y[s]; wdst[s][0] = w0; wdst[s][dup] = w0; }
-  if (!(rho > 0.0)) {
-    double t0[2] = {xown[0] ? Pg[tri(xe[0], xe[0])] : 0.0, xown[0] ? Ag[tri(xe[0], xe[0])] : 0.0};
-    double t1[2] = {xown[1] ? Pg[tri(xe[1], xe[1])] : 0.0, xown[1] ? Ag[tri(xe[1], xe[1])] : 0.0};
-    const bool sums[2] = {true, true};
-    block_reduce2<2>(t0, t1, sums, red);
-    rho = fmin(fmax(RHO_AUTO_SCALE * sqrt(t0[0] / t0[1]), 1e-6), 1e6);
-  }
-  int it = 0, to_check = a.s.check_every > 0 ? a.s.check_every : 1;
-  double rp = INFINITY, rd = INFINITY;
-  bool converged = false, infeasible = false, ok = true;
-  bool done = a.s.max_iter < 0;
-  bool from_plan = a.mode == 2;
-  if (from_plan && !(exm[244] > 0.5)) ok = false;
-  while (!done) {
-    d4_t acc0[NT];                                             // MINUS the KKT inverse, tile row w (slot order)
-    {
-      d4_t acc1[NT];                                           // tile row w + 4 (waves 0, 1): parked in LDS for the loop
-      if (from_plan) {
-        from_plan = false;
-#pragma unroll
-        for (int J = 0; J < NTT; ++J)
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            acc0[J][qq] = w < NTT ? tl0[(J * 4 + qq) * 64] : 0.0;
-            acc1[J][qq] = has1 ? tl1[(J * 4 + qq) * 64] : 0.0;
-          }
-      } else {
-        d4_t t0[NT], t1[NT];
-        ok = mfma_inverse2<NTT>(t0, t1, Cs, Pg, Ag, rho, sigma, n) && ok;
-#pragma unroll
-        for (int J = 0; J < NTT; ++J) { acc0[J] = t0[J]; acc1[J] = t1[J]; }
-        if (a.mode == 1) {
-#pragma unroll
-          for (int J = 0; J < NTT; ++J)
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-              if (w < NTT) tl0[(J * 4 + qq) * 64] = acc0[J][qq];
-              if (has1) tl1[(J * 4 + qq) * 64] = acc1[J][qq];
-            }
-          if (tid == 0) { exm[243] = rho; exm[244] = ok ? 1.0 : 0.0; }
-          done = true;
-        }
-      }
-      // stage 2 reads the inverse in slot order (reduce4_slots)
-      const int i0 = slot_of(0, h, g), i1 = slot_of(1, h, g), i2 = slot_of(2, h, g), i3 = slot_of(3, h, g);
-#pragma unroll
-      for (int J = 0; J < NTT; ++J) {
-        const d4_t t = acc0[J], u = acc1[J];
-        acc0[J][0] = sel4(t[0], t[1], t[2], t[3], i0); acc0[J][1] = sel4(t[0], t[1], t[2], t[3], i1);
-        acc0[J][2] = sel4(t[0], t[1], t[2], t[3], i2); acc0[J][3] = sel4(t[0], t[1], t[2], t[3], i3);
-        if (has1) {
-          double *dst = accL + ((size_t)w * NT * 4 + J * 4) * 64 + l;
-          dst[0] = sel4(u[0], u[1], u[2], u[3], i0); dst[64] = sel4(u[0], u[1], u[2], u[3], i1);
-          dst[128] = sel4(u[0], u[1], u[2], u[3], i2); dst[192] = sel4(u[0], u[1], u[2], u[3], i3);
-        }
-      }
-    }
-    double Gd[2][6][3];
-    {
-      constexpr int SR[6] = {2, 3, 4, 5, 6, 8};
-#pragma unroll
-      for (int bb = 0; bb < 2; ++bb) {
-        const int d = 2 * q + bb;
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr) {
-          const int srow = h ? SR[(rr + 3) % 6] : SR[rr];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) Gd[bb][rr][c] = d < N ? Gg[d * 27 + srow * 3 + c] : 0.0;
-        }
-      }
-    }
-    const double rinv = 1.0 / rho;
-    bool refactor = false;
-    if (!ok || a.s.max_iter <= 0) done = true;
-    __syncthreads();
-    while (!done && !refactor) {
-      ++it;
-      // ---- A: rhs = sigma x - q + A'(rho z - y)
-      // (one slot after the other: the second workgroup on the CU hides the extra LDS round trip, and the operand
-      //  window of only one slot is live at a time)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        double wv[12], o1[3];
-        stage1_load(wsrc[s], wv);
-        const double wce = wc[xec[s]], wre = wr[xec[s]], wrn = wr[xec[s] + 3];
-        MPC_PHASE();
-        stage1_fma(Gd, wv, o1);
-        const double t = reduce3(o1[0], o1[1], o1[2], h, g);
-        if (xown[s]) rhs[xe[s]] = sigma * xs[s] - qe[s] + (t + wce + (wre - wrn));
-        MPC_PHASE();
-      }
-      __syncthreads();
-      // ---- B: x~ = Minv rhs from the accumulators
-      if (w < NTT) {
-        double rj[NTT];
-#pragma unroll
-        for (int J = 0; J < NTT; ++J) rj[J] = rhs[16 * J + lc];
-        MPC_PHASE();
-        {
-          d4_t part = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int J = 0; J < NTT; ++J)
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) part[qq] = fma(acc0[J][qq], rj[J], part[qq]);
-          const double v = reduce4_slots(part);
-          const int row = 16 * w + (lc & 12) + lq;
-          if ((lc & 3) == 0 && row < n) xtP[XOFF + row] = -v;
-        }
-        if (has1) {
-          d4_t part = {0.0, 0.0, 0.0, 0.0};
-          const double *src = accL + (size_t)w * NT * 4 * 64 + l;
-#pragma unroll
-          for (int J = 0; J < NTT; ++J)
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) part[qq] = fma(src[(J * 4 + qq) * 64], rj[J], part[qq]);
-          const double v = reduce4_slots(part);
-          const int row = 16 * (w + 4) + (lc & 12) + lq;
-          if ((lc & 3) == 0 && row < n) xtP[XOFF + row] = -v;
-        }
-      }
-      __syncthreads();
-      // ---- C: z~ = A x~, relaxation, projection, dual update
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        double xv[6], o3[6];
-        stage3_load(xsrc[s], xv);
-        const double xte = xtP[XOFF + xec[s]], xk = xtP[XOFF + k3[s]], xkm = xtP[XOFF + k3[s] - 3];
-        MPC_PHASE();
-        stage3_fma(Gd, xv, o3);
-        const double zs = reduce6_slots(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], g, e);
-        if (xown[s]) xs[s] = alpha * xte + (1 - alpha) * xs[s];
-        if (kind[s]) {
-          const double zt = kind[s] == 1 ? zs : (kind[s] == 2 ? xk : xk - xkm);
-          const double zr = alpha * zt + (1 - alpha) * z[s];
-          const double zn = fmin(fmax(fma(y[s], rinv, zr), lo[s]), hi[s]);
-          dy[s] = rho * (zr - zn);
-          y[s] = y[s] + dy[s];
-          z[s] = zn;
-        }
-        MPC_PHASE();
-      }
-      const bool check = --to_check == 0 || it >= a.s.max_iter;
-      if (to_check == 0) to_check = a.s.check_every;
-      if (check) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          if (kind[s]) { ydst[s][0] = y[s]; ydst[s][dup] = y[s]; }
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          if (xown[s]) xtP[XOFF + xe[s]] = xs[s];
-        __syncthreads();
-        double v0[7], v1[7];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          double (&v)[7] = s ? v1 : v0;
-          const int blk = blk0 + 16 * s;
-          double o3[6], o1[3], px3[3] = {0.0, 0.0, 0.0};
-          { double xv[6]; stage3_load(xsrc[s], xv); stage3_fma(Gd, xv, o3); }
-          const double axs = reduce6_slots(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], g, e);
-          { double wv[12]; stage1_load(ysrc[s], wv); stage1_fma(Gd, wv, o1); }
-          const double atys = reduce3(o1[0], o1[1], o1[2], h, g);
-          if (inb[s]) {
-#pragma unroll
-            for (int cc = 0; cc < 6; ++cc) {
-              const int col = 6 * q + cc;
-              if (col < n) {
-                const double xvv = xtP[XOFF + col];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                  const int row = 3 * blk + c;
-                  px3[c] = fma(Pg[row >= col ? tri(row, col) : tri(col, row)], xvv, px3[c]);
-                }
-              }
-            }
-          }
-          const double px = reduce3(px3[0], px3[1], px3[2], h, g);
-#pragma unroll
-          for (int i = 0; i < 7; ++i) v[i] = 0.0;
-          if (kind[s]) {
-            const double ax = kind[s] == 1 ? axs : (kind[s] == 2 ? xtP[XOFF + k3[s]] : xtP[XOFF + k3[s]] - xtP[XOFF + k3[s] - 3]);
-            v[0] = fabs(ax - z[s]); v[1] = fabs(ax); v[2] = fabs(z[s]);
-          }
-          if (xown[s]) {
-            const double aty = atys + yc[xe[s]] + (yr[xe[s]] - yr[xe[s] + 3]);
-            v[3] = fabs(px + qe[s] + aty); v[4] = fabs(px); v[5] = fabs(aty); v[6] = fabs(qe[s]);
-          }
-        }
-        const bool allmax[7] = {false, false, false, false, false, false, false};
-        block_reduce2<7>(v0, v1, allmax, red);
-        rp = v0[0]; rd = v0[3];
-        const double np_ = fmax(v0[1], v0[2]), nd_ = fmax(fmax(v0[4], v0[5]), v0[6]);
-        if (rp <= a.s.eps_abs + a.s.eps_rel * np_ && rd <= a.s.eps_abs + a.s.eps_rel * nd_) { done = true; converged = true; }
-        else {
-          double u0[2] = {kind[0] ? fabs(dy[0]) : 0.0, kind[0] ? hi[0] * fmax(dy[0], 0.0) + lo[0] * fmin(dy[0], 0.0) : 0.0};
-          double u1[2] = {kind[1] ? fabs(dy[1]) : 0.0, kind[1] ? hi[1] * fmax(dy[1], 0.0) + lo[1] * fmin(dy[1], 0.0) : 0.0};
-          const bool kinds[2] = {false, true};
-          block_reduce2<2>(u0, u1, kinds, red);
-          const double ndy = u0[0], supp = u0[1];
-          if (ndy > a.s.eps_prim_inf && supp < -a.s.eps_prim_inf * ndy) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-              if (kind[s]) { ydst[s][0] = dy[s]; ydst[s][dup] = dy[s]; }
-            __syncthreads();
-            double c0v[1], c1v[1];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              double o1[3];
-              { double wv[12]; stage1_load(ysrc[s], wv); stage1_fma(Gd, wv, o1); }
-              const double t = reduce3(o1[0], o1[1], o1[2], h, g);
-              (s ? c1v : c0v)[0] = xown[s] ? fabs(t + yc[xe[s]] + (yr[xe[s]] - yr[xe[s] + 3])) : 0.0;
-            }
-            const bool km[1] = {false};
-            block_reduce2<1>(c0v, c1v, km, red);
-            if (c0v[0] < a.s.eps_prim_inf * ndy) { done = true; infeasible = true; }
-          }
-          if (!done) {
-            if (it >= a.s.max_iter) done = true;
-            else if (a.s.adaptive_rho && it % a.s.rho_every == 0) {
-              double nw = rho * sqrt((rp / fmax(np_, 1e-10)) / fmax(rd / fmax(nd_, 1e-10), 1e-10));
-              nw = fmin(fmax(nw, 1e-6), 1e6);
-              if (nw > 5 * rho || nw < rho / 5) { rho = nw; refactor = true; }
-            }
-          }
-        }
-      }
-      // w = rho z - y for the next iteration
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-        if (kind[s]) { const double wn = rho * z[s] - y[s]; wdst[s][0] = wn; wdst[s][dup] = wn; }
-      __syncthreads();
-    }
-  }
-
-  if (a.mode == 1) return;
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    if (a.warm) {
-      double *wms = a.warm + (size_t)b * MPC_WARM_DOUBLES + tid + FT2 * s;
-      const bool good = converged && !infeasible;
-      wms[0] = good ? xs[s] : NAN; wms[FT] = good ? z[s] : NAN; wms[2 * FT] = good ? y[s] : NAN;
-    }
-    if (xown[s]) {
-      if (xe[s] < 3) a.ucmd[xe[s] * a.ld + b] = infeasible ? NAN : xs[s];
-      if (a.useq) a.useq[xe[s] * a.ld + b] = infeasible ? NAN : xs[s];
-    }
-  }
-  if (tid == 0) {
-    if (a.info) {
-      a.info[0 * a.ld + b] = (double)it;
-      a.info[1 * a.ld + b] = rp;
-      a.info[2 * a.ld + b] = rd;
-      a.info[3 * a.ld + b] = rho;
-    }
-    if (a.status && infeasible) a.status[b] |= F16_ST_QP_INFEASIBLE;
-    else if (a.status && a.s.max_iter > 0 && (!converged || !ok)) a.status[b] |= F16_ST_QP_MAXITER;
-  }
-}
-
 int mpc_fast_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
   (void)ctx;
   if (a.N < 1 || a.N > FAST_MAXN) return set_error(F16_EINVAL, "fast MPC solver needs 1 <= N <= 32");
@@ -1169,11 +728,6 @@ int mpc_fast_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
   if (a.B > 0x7fffffffL) return set_error(F16_EINVAL, "batch too large for one launch");
   const unsigned grid = (unsigned)a.B;
   const int nt = (3 * a.N + 15) / 16;       // 16x16 tiles per side of the KKT matrix, instantiated for 2 / 4 / 6
-  static const int lanes = [] { const char *e = getenv("F16_MPC_LANES"); return e ? atoi(e) : 512; }();
-  if (lanes == 256 && nt > 4) {
-    hipLaunchKernelGGL(k_mpc_fast2<6>, dim3(grid), dim3(FT2), 0, (hipStream_t)stream, a);
-    return hip_check(hipGetLastError(), "f16_mpc_batch solve launch");
-  }
   if (nt <= 2) hipLaunchKernelGGL(k_mpc_fast<2>, dim3(grid), dim3(FT), 0, (hipStream_t)stream, a);
   else if (nt <= 4) hipLaunchKernelGGL(k_mpc_fast<4>, dim3(grid), dim3(FT), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(k_mpc_fast<6>, dim3(grid), dim3(FT), 0, (hipStream_t)stream, a);
