@@ -125,6 +125,8 @@ def main():
     if not args.no_mpc:
         out["mpc"] = bench_mpc(args, dev, rank, world, fdist, barrier)
         out["config5_closed_loop"] = bench_closed_loop(args, dev, rank, world, fdist, barrier)
+        if rank == 0:
+            out["trim"] = bench_trim(dev)
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(x0, u0, T)
         if "mpc" in out:
@@ -245,6 +247,25 @@ def bench_mpc(args, dev, rank, world, fdist, barrier):
                                              "max": float(it01.max()), "mean": float(it01.mean())},
                               "status_or": int(fdist.or_status(info01["status"]))},
             "linearise_zoh_lqr_per_s": world * B / dl}
+
+
+def bench_trim(dev, B=4096):
+    """straight-and-level trim of B flight conditions in one launch (the reference's Nelder-Mead,
+    env.py:198-292, one wavefront lane per condition); the reference takes 0.56 s for one condition."""
+    import torch
+    from f16_mpc_oop_py_amd import F16Batch
+    rng = np.random.default_rng(7)
+    h = rng.uniform(5e3, 3e4, B)
+    v = rng.uniform(450.0, 800.0, B)
+    F16Batch.trim(h[:64], v[:64], device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x, info = F16Batch.trim(h, v, device=dev)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    cost = info["cost"].cpu().numpy()
+    return {"conditions": B, "ms": dt * 1e3, "trims_per_s": B / dt, "cost_max": float(cost.max()),
+            "nfev_mean": float(info["nfev"].double().mean()), "reference_s_per_trim": 0.56}
 
 
 def bench_closed_loop(args, dev, rank, world, fdist, barrier, B=8192, T=20):
