@@ -417,6 +417,7 @@ template <int NTT>
 __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
   __shared__ __attribute__((aligned(16))) double wsP[WSP], ysP[WSP], xtP[XTP], Cs[2 * FN * 4 + 40];
   __shared__ double rhs[FN], wc[FN], wr[FN + 4], yc[FN], yr[FN + 4], red[8 * 8];
+  extern __shared__ double pxL[];       // [18][FT]: this lane's 18 entries of P for the dual residual (termination test)
 
   const int N = a.N, n = 3 * N;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lc = l & 15, lq = l >> 4, blk = tid >> 4, q = lc;
@@ -456,6 +457,18 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
     const unsigned long long tP0 = __builtin_amdgcn_s_memtime();
 #endif
     const double qe = xown ? ex[xe] : 0.0;
+    // the termination test needs P x: row blk's 16 lanes split the columns six apiece, so a lane touches the SAME 18
+    // entries of P at every test -- fetched once here, with the other prologue loads, into per-lane LDS slots (a test
+    // used to pay a global round trip: 5.4 iterations' worth of time per test, now 2)
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) {
+      const int col = 6 * q + cc;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int row = 3 * blk + c;
+        pxL[(cc * 3 + c) * FT + tid] = (inb && col < n) ? Pg[row >= col ? tri(row, col) : tri(col, row)] : 0.0;
+      }
+    }
     // ---- bounds of this lane's constraint row (utils.py:129-152; rows with two infinite bounds are not kept)
     double lo = 0.0, hi = 0.0, z = 0.0, y = 0.0, dy = 0.0, xs = 0.0;
     if (kind == 1) {
@@ -629,19 +642,11 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         const double axs = reduce6_slots(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], g, e);
         { double wv[12]; stage1_load(ysrc, wv); stage1_fma(Gd, wv, o1); }
         const double atys = reduce3(o1[0], o1[1], o1[2], h, g);
-        if (inb) {                                              // P x: row blk's 16 lanes split the columns six apiece
 #pragma unroll
-          for (int cc = 0; cc < 6; ++cc) {
-            const int col = 6 * q + cc;
-            if (col < n) {
-              const double xv = xtP[XOFF + col];
+        for (int cc = 0; cc < 6; ++cc) {                          // P x from the cached entries (zeros outside the matrix)
+          const double xv = xtP[XOFF + 6 * q + cc];
 #pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                const int row = 3 * blk + c;
-                px3[c] = fma(Pg[row >= col ? tri(row, col) : tri(col, row)], xv, px3[c]);
-              }
-            }
-          }
+          for (int c = 0; c < 3; ++c) px3[c] = fma(pxL[(cc * 3 + c) * FT + tid], xv, px3[c]);
         }
         const double px = reduce3(px3[0], px3[1], px3[2], h, g);
         double v[7] = {0, 0, 0, 0, 0, 0, 0};                    // r1, |Ax|, |z|, r2, |Px|, |A'y|, |q|
@@ -728,9 +733,17 @@ int mpc_fast_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
   if (a.B > 0x7fffffffL) return set_error(F16_EINVAL, "batch too large for one launch");
   const unsigned grid = (unsigned)a.B;
   const int nt = (3 * a.N + 15) / 16;       // 16x16 tiles per side of the KKT matrix, instantiated for 2 / 4 / 6
-  if (nt <= 2) hipLaunchKernelGGL(k_mpc_fast<2>, dim3(grid), dim3(FT), 0, (hipStream_t)stream, a);
-  else if (nt <= 4) hipLaunchKernelGGL(k_mpc_fast<4>, dim3(grid), dim3(FT), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(k_mpc_fast<6>, dim3(grid), dim3(FT), 0, (hipStream_t)stream, a);
+  constexpr size_t dyn = 18 * FT * sizeof(double);      // per-lane P entries for the termination test (73.7 KB)
+  static const int attr_rc = [] {                        // static + dynamic LDS exceed 64 KB: opt in, once per process
+    int rc = hipFuncSetAttribute((const void *)k_mpc_fast<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (!rc) rc = hipFuncSetAttribute((const void *)k_mpc_fast<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (!rc) rc = hipFuncSetAttribute((const void *)k_mpc_fast<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    return rc;
+  }();
+  if (attr_rc) return hip_check((hipError_t)attr_rc, "hipFuncSetAttribute(k_mpc_fast)");
+  if (nt <= 2) hipLaunchKernelGGL(k_mpc_fast<2>, dim3(grid), dim3(FT), dyn, (hipStream_t)stream, a);
+  else if (nt <= 4) hipLaunchKernelGGL(k_mpc_fast<4>, dim3(grid), dim3(FT), dyn, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_mpc_fast<6>, dim3(grid), dim3(FT), dyn, (hipStream_t)stream, a);
   return hip_check(hipGetLastError(), "f16_mpc_batch solve launch");
 }
 

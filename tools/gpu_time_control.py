@@ -28,3 +28,7 @@ for N in (10, 30):
     print(N, "mpc 25 it ms", t(lambda: env._calc_MPC_action(0, 0, 0, N, settings=dict(max_iter=25))))
     print(N, "mpc 100 it no-check ms", t(lambda: env._calc_MPC_action(0, 0, 0, N, settings=dict(max_iter=100, check_every=1000))))
     print(N, "mpc full ms", t(lambda: env._calc_MPC_action(0, 0, 0, N)))
+# cost of one termination test: 100 iterations that never converge, tested every 5 (20 tests + the final one) against never
+tn = t(lambda: env._calc_MPC_action(0, 0, 0, 30, settings=dict(max_iter=100, check_every=1000, eps_abs=1e-30, eps_rel=1e-30, adaptive_rho=0)))
+t5 = t(lambda: env._calc_MPC_action(0, 0, 0, 30, settings=dict(max_iter=100, check_every=5, eps_abs=1e-30, eps_rel=1e-30, adaptive_rho=0)))
+print("30 mpc termination test: %.1f us per 4096 (= %.1f iterations)" % ((t5 - tn) / 19 * 1e3, (t5 - tn) / 19 / ((tn - 1.3) / 100)))
