@@ -25,12 +25,35 @@ namespace f16 {
 constexpr int FT = 512;                    // lanes per aircraft
 constexpr int FN = 3 * FAST_MAXN;          // 96
 
-// workgroup-wide reductions of NV values at once (red: [8][NV] doubles of LDS)
+// wave-wide sum / max (of non-negative values) on the DPP network: four butterfly steps inside each 16-lane row, two row
+// broadcasts, the total read from lane 63 -- no LDS traffic (__shfl_xor is ds_bpermute: ~100 cycles per step and a
+// share of the one LDS pipe; the termination test reduces nine values)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_masked_f64(double v) {      // lanes outside ROWMASK receive 0
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <bool SUM>
+__device__ __forceinline__ double wave_reduce_dpp(double v) {
+  auto op = [](double a, double b) { return SUM ? a + b : fmax(a, b); };
+  v = op(v, dpp_masked_f64<0xB1, 0xF>(v));       // quad_perm [1,0,3,2]
+  v = op(v, dpp_masked_f64<0x4E, 0xF>(v));       // quad_perm [2,3,0,1]
+  v = op(v, dpp_masked_f64<0x141, 0xF>(v));      // row_half_mirror
+  v = op(v, dpp_masked_f64<0x140, 0xF>(v));      // row_mirror: every lane of a row holds the row total
+  v = op(v, dpp_masked_f64<0x142, 0xA>(v));      // row_bcast:15 -> rows 1, 3
+  v = op(v, dpp_masked_f64<0x143, 0xC>(v));      // row_bcast:31 -> rows 2, 3
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+// workgroup-wide reductions of NV values at once (red: [8][NV] doubles of LDS); max only of non-negative values
 template <int NV>
 __device__ __forceinline__ void block_reduce(double (&v)[NV], const bool (&is_sum)[NV], double *red) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) v[i] = is_sum[i] ? wave_sum(v[i]) : wave_max(v[i]);
+  for (int i = 0; i < NV; ++i) v[i] = is_sum[i] ? wave_reduce_dpp<true>(v[i]) : wave_reduce_dpp<false>(v[i]);
   __syncthreads();
   if (lane == 0) {
 #pragma unroll
@@ -416,7 +439,7 @@ constexpr int XTP = XOFF + FN + 8;
 template <int NTT>
 __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
   __shared__ __attribute__((aligned(16))) double wsP[WSP], ysP[WSP], xtP[XTP], Cs[2 * FN * 4 + 40];
-  __shared__ double rhs[FN], wc[FN], wr[FN + 4], yc[FN], yr[FN + 4], red[8 * 8];
+  __shared__ double rhs[FN], wc[FN], wr[FN + 4], yc[FN], yr[FN + 4], red[8 * 9], xcP[XTP];
   extern __shared__ double pxL[];       // [18][FT]: this lane's 18 entries of P for the dual residual (termination test)
 
   const int N = a.N, n = 3 * N;
@@ -441,7 +464,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
   const double *const wsrc = wsP + WROW * (blk + 2 * q) + (h ? 3 : 0), *const ysrc = ysP + WROW * (blk + 2 * q) + (h ? 3 : 0);
   // zero everything once: the pads are never written again
   for (int i = tid; i < WSP; i += FT) { wsP[i] = 0.0; ysP[i] = 0.0; }
-  for (int i = tid; i < XTP; i += FT) xtP[i] = 0.0;
+  for (int i = tid; i < XTP; i += FT) { xtP[i] = 0.0; xcP[i] = 0.0; }
   for (int i = tid; i < FN + 4; i += FT) { wr[i] = 0.0; yr[i] = 0.0; }
   for (int i = tid; i < FN; i += FT) { rhs[i] = 0.0; wc[i] = 0.0; yc[i] = 0.0; }
   __syncthreads();
@@ -632,43 +655,42 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
       const bool check = --to_check == 0 || it >= a.s.max_iter;      // it % check_every == 0, without the division
       if (to_check == 0) to_check = a.s.check_every;
       if (check) {
-        // ---- residuals (OSQP termination test): A x, P x, A' y
+        // ---- residuals (OSQP termination test): A x, P x, A' y.  x goes to its own zero-padded buffer (x~ may still be
+        // read by slower waves), y to the state-row layout; one barrier, then everything of the test in one reduction
+        // (the two quantities of the primal-infeasibility certificate ride along: they only depend on dy)
         if (kind) { ydst[0] = y; ydst[dup] = y; }
-        __syncthreads();                                        // all reads of x~ are done: the buffer now carries x
-        if (xown) xtP[XOFF + xe] = xs;
+        if (xown) xcP[XOFF + xe] = xs;
         __syncthreads();
         double o3[6], o1[3], px3[3] = {0.0, 0.0, 0.0};
-        { double xv[6]; stage3_load(xtP + XOFF + 3 * (blk - 2 * q - 1), xv); stage3_fma(Gd, xv, o3); }
+        { double xv[6]; stage3_load(xcP + XOFF + 3 * (blk - 2 * q - 1), xv); stage3_fma(Gd, xv, o3); }
         const double axs = reduce6_slots(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], g, e);
         { double wv[12]; stage1_load(ysrc, wv); stage1_fma(Gd, wv, o1); }
         const double atys = reduce3(o1[0], o1[1], o1[2], h, g);
 #pragma unroll
         for (int cc = 0; cc < 6; ++cc) {                          // P x from the cached entries (zeros outside the matrix)
-          const double xv = xtP[XOFF + 6 * q + cc];
+          const double xv = xcP[XOFF + 6 * q + cc];
 #pragma unroll
           for (int c = 0; c < 3; ++c) px3[c] = fma(pxL[(cc * 3 + c) * FT + tid], xv, px3[c]);
         }
         const double px = reduce3(px3[0], px3[1], px3[2], h, g);
-        double v[7] = {0, 0, 0, 0, 0, 0, 0};                    // r1, |Ax|, |z|, r2, |Px|, |A'y|, |q|
+        double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};              // r1, |Ax|, |z|, r2, |Px|, |A'y|, |q|, |dy|, support(dy)
         if (kind) {
-          const double ax = kind == 1 ? axs : (kind == 2 ? xtP[XOFF + k3] : xtP[XOFF + k3] - xtP[XOFF + k3 - 3]);
+          const double ax = kind == 1 ? axs : (kind == 2 ? xcP[XOFF + k3] : xcP[XOFF + k3] - xcP[XOFF + k3 - 3]);
           v[0] = fabs(ax - z); v[1] = fabs(ax); v[2] = fabs(z);
+          v[7] = fabs(dy); v[8] = hi * fmax(dy, 0.0) + lo * fmin(dy, 0.0);
         }
         if (xown) {
           const double aty = atys + yc[xe] + (yr[xe] - yr[xe + 3]);
           v[3] = fabs(px + qe + aty); v[4] = fabs(px); v[5] = fabs(aty); v[6] = fabs(qe);
         }
-        const bool allmax[7] = {false, false, false, false, false, false, false};
-        block_reduce<7>(v, allmax, red);
+        const bool issum[9] = {false, false, false, false, false, false, false, false, true};
+        block_reduce<9>(v, issum, red);
         rp = v[0]; rd = v[3];
         const double np_ = fmax(v[1], v[2]), nd_ = fmax(fmax(v[4], v[5]), v[6]);
         if (rp <= a.s.eps_abs + a.s.eps_rel * np_ && rd <= a.s.eps_abs + a.s.eps_rel * nd_) { done = true; converged = true; }
         else {
           // OSQP primal-infeasibility certificate on dy
-          double u[2] = {kind ? fabs(dy) : 0.0, kind ? hi * fmax(dy, 0.0) + lo * fmin(dy, 0.0) : 0.0};
-          const bool kinds[2] = {false, true};
-          block_reduce<2>(u, kinds, red);
-          const double ndy = u[0], supp = u[1];
+          const double ndy = v[7], supp = v[8];
           if (ndy > a.s.eps_prim_inf && supp < -a.s.eps_prim_inf * ndy) {
             if (kind) { ydst[0] = dy; ydst[dup] = dy; }
             __syncthreads();
