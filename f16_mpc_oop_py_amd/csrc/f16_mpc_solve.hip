@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include <mutex>
+
 #include "f16_mpc.hpp"
 #include "f16_smallmat.hpp"
 
@@ -756,13 +758,20 @@ int mpc_fast_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
   const unsigned grid = (unsigned)a.B;
   const int nt = (3 * a.N + 15) / 16;       // 16x16 tiles per side of the KKT matrix, instantiated for 2 / 4 / 6
   constexpr size_t dyn = 18 * FT * sizeof(double);      // per-lane P entries for the termination test (73.7 KB)
-  static const int attr_rc = [] {                        // static + dynamic LDS exceed 64 KB: opt in, once per process
-    int rc = hipFuncSetAttribute((const void *)k_mpc_fast<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    if (!rc) rc = hipFuncSetAttribute((const void *)k_mpc_fast<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    if (!rc) rc = hipFuncSetAttribute((const void *)k_mpc_fast<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    return rc;
-  }();
-  if (attr_rc) return hip_check((hipError_t)attr_rc, "hipFuncSetAttribute(k_mpc_fast)");
+  {   // static + dynamic LDS exceed 64 KB: opt in, once per device (not per launch: a plan's solve may run under capture)
+    static std::mutex mu;
+    static bool ready[64] = {};
+    int dev = 0;
+    if (int rc = hip_check(hipGetDevice(&dev), "hipGetDevice")) return rc;
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev >= 0 && dev < 64 && !ready[dev]) {
+      hipError_t e = hipFuncSetAttribute((const void *)k_mpc_fast<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_mpc_fast<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_mpc_fast<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      if (int rc = hip_check(e, "hipFuncSetAttribute(k_mpc_fast)")) return rc;
+      ready[dev] = true;
+    }
+  }
   if (nt <= 2) hipLaunchKernelGGL(k_mpc_fast<2>, dim3(grid), dim3(FT), dyn, (hipStream_t)stream, a);
   else if (nt <= 4) hipLaunchKernelGGL(k_mpc_fast<4>, dim3(grid), dim3(FT), dyn, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(k_mpc_fast<6>, dim3(grid), dim3(FT), dyn, (hipStream_t)stream, a);
