@@ -27,29 +27,6 @@ namespace f16 {
 constexpr int FT = 512;                    // lanes per aircraft
 constexpr int FN = 3 * FAST_MAXN;          // 96
 
-// wave-wide sum / max (of non-negative values) on the DPP network: four butterfly steps inside each 16-lane row, two row
-// broadcasts, the total read from lane 63 -- no LDS traffic (__shfl_xor is ds_bpermute: ~100 cycles per step and a
-// share of the one LDS pipe; the termination test reduces nine values)
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ double dpp_masked_f64(double v) {      // lanes outside ROWMASK receive 0
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xF, false);
-  return __hiloint2double(hi, lo);
-}
-template <bool SUM>
-__device__ __forceinline__ double wave_reduce_dpp(double v) {
-  auto op = [](double a, double b) { return SUM ? a + b : fmax(a, b); };
-  v = op(v, dpp_masked_f64<0xB1, 0xF>(v));       // quad_perm [1,0,3,2]
-  v = op(v, dpp_masked_f64<0x4E, 0xF>(v));       // quad_perm [2,3,0,1]
-  v = op(v, dpp_masked_f64<0x141, 0xF>(v));      // row_half_mirror
-  v = op(v, dpp_masked_f64<0x140, 0xF>(v));      // row_mirror: every lane of a row holds the row total
-  v = op(v, dpp_masked_f64<0x142, 0xA>(v));      // row_bcast:15 -> rows 1, 3
-  v = op(v, dpp_masked_f64<0x143, 0xC>(v));      // row_bcast:31 -> rows 2, 3
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-  return __hiloint2double(hi, lo);
-}
-
 // workgroup-wide reductions of NV values at once (red: [8][NV] doubles of LDS); max only of non-negative values
 template <int NV>
 __device__ __forceinline__ void block_reduce(double (&v)[NV], const bool (&is_sum)[NV], double *red) {

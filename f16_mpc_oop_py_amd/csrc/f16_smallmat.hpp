@@ -30,17 +30,30 @@ __device__ __forceinline__ void copy(double *dst, const double *src, int n) {
   __syncthreads();
 }
 
-// wave-wide max of a non-negative quantity
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
+// wave-wide sum / max (of NON-NEGATIVE values) on the DPP network: four butterfly steps inside each 16-lane row, two row
+// broadcasts, the total read from lane 63 -- no LDS traffic (__shfl_xor is ds_bpermute: ~100 cycles per step and a
+// share of the one LDS pipe; the Riccati doubling reduces three values per step, the ADMM termination test nine)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_masked_f64(double v) {      // lanes outside ROWMASK receive 0
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xF, false);
+  return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+template <bool SUM>
+__device__ __forceinline__ double wave_reduce_dpp(double v) {
+  auto op = [](double a, double b) { return SUM ? a + b : fmax(a, b); };
+  v = op(v, dpp_masked_f64<0xB1, 0xF>(v));       // quad_perm [1,0,3,2]
+  v = op(v, dpp_masked_f64<0x4E, 0xF>(v));       // quad_perm [2,3,0,1]
+  v = op(v, dpp_masked_f64<0x141, 0xF>(v));      // row_half_mirror
+  v = op(v, dpp_masked_f64<0x140, 0xF>(v));      // row_mirror: every lane of a row holds the row total
+  v = op(v, dpp_masked_f64<0x142, 0xA>(v));      // row_bcast:15 -> rows 1, 3
+  v = op(v, dpp_masked_f64<0x143, 0xC>(v));      // row_bcast:31 -> rows 2, 3
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce_dpp<false>(v); }      // v >= 0
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce_dpp<true>(v); }
 
 // In-place inverse of the n x n matrix M (n <= 12) by Gauss-Jordan with partial pivoting.
 // W: scratch [n][2n], f: scratch [n].  Result overwrites M.  Returns false on a zero pivot.
