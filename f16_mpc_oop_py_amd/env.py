@@ -345,7 +345,10 @@ class F16Batch:
         else:
             dem = torch.empty((3, self.B), dtype=torch.float64, device=self.device)
             for k, v in enumerate((p_dem, q_dem, r_dem)):
-                dem[k] = torch.as_tensor(v, dtype=torch.float64, device=self.device)
+                if isinstance(v, (int, float)):
+                    dem[k].fill_(float(v))            # scalar demand: a fill kernel, no host-to-device copy
+                else:
+                    dem[k] = torch.as_tensor(v, dtype=torch.float64, device=self.device)
         ucmd = torch.empty((3, self.B), dtype=torch.float64, device=self.device)
         info = torch.empty((4, self.B), dtype=torch.float64, device=self.device)
         useq = torch.empty((3 * hzn, self.B), dtype=torch.float64, device=self.device) if return_info else None
