@@ -224,7 +224,7 @@ __device__ F16_INV_ATTR bool mfma_inverse(d4_t *acc_out, double *Cs, const doubl
   bool ok = true;
   d4_t acc[NT];
   // tiles straight from the packed lower triangles in the workspace (L2-resident: the build kernel just wrote them).
-  // One tile at a time (scheduling fence): hoisting all 2 x 24 loads to the top costs more registers than there are.
+  // Two tiles per round trip (scheduling fence): hoisting all 2 x 24 loads to the top costs more registers than there are.
 #pragma unroll
   for (int J = 0; J < NTT; ++J) {
     double pv[4], av[4];
@@ -240,7 +240,7 @@ __device__ F16_INV_ATTR bool mfma_inverse(d4_t *acc_out, double *Cs, const doubl
       const int i = 16 * w + 4 * q + lq, j = 16 * J + lc;
       acc[J][q] = (i < n && j < n) ? pv[q] + r * av[q] + (i == j ? sigma : 0.0) : (i == j ? 1.0 : 0.0);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if (J & 1) __builtin_amdgcn_sched_barrier(0);      // two tiles (2 x 16 loads) in flight per round trip
   }
   double *c0 = Cs, *c1 = Cs + PAN_SIZE;
   __syncthreads();                        // previous users of Cs are done
