@@ -493,9 +493,15 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
       __syncthreads();
     } else {
     // ---------------- model + weights (utils.py:82-105)
-    load_soa(A, a.Ad, 81, a.ld, b);
-    load_soa(Bm, a.Bd, 27, a.ld, b);
-    load_soa(Qb, a.Cd, 81, a.ld, b);                  // Cd staged in Qb
+    {   // one global round trip for the three operands (189 strided loads in flight) instead of three
+      const double a0 = a.Ad[(size_t)l * a.ld + b], a1 = l + 64 < 81 ? a.Ad[(size_t)(l + 64) * a.ld + b] : 0.0;
+      const double c0 = a.Cd[(size_t)l * a.ld + b], c1 = l + 64 < 81 ? a.Cd[(size_t)(l + 64) * a.ld + b] : 0.0;
+      const double b0 = l < 27 ? a.Bd[(size_t)l * a.ld + b] : 0.0;
+      A[l] = a0; Qb[l] = c0;                           // Cd staged in Qb
+      if (l + 64 < 81) { A[l + 64] = a1; Qb[l + 64] = c1; }
+      if (l < 27) Bm[l] = b0;
+      __syncthreads();
+    }
     mm<true, false>(Q, Qb, Qb, 9, 9, 9);              // Q = C'C (env.py:389)
     }
     if (l < 9) {
