@@ -462,14 +462,59 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
     // the termination test needs P x: row blk's 16 lanes split the columns six apiece, so a lane touches the SAME 18
     // entries of P at every test -- fetched once here, with the other prologue loads, into per-lane LDS slots (a test
     // used to pay a global round trip: 5.4 iterations' worth of time per test, now 2)
+    double pv[18];
 #pragma unroll
     for (int cc = 0; cc < 6; ++cc) {
       const int col = 6 * q + cc;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const int row = 3 * blk + c;
-        pxL[(cc * 3 + c) * FT + tid] = (inb && col < n) ? Pg[row >= col ? tri(row, col) : tri(col, row)] : 0.0;
+        pv[cc * 3 + c] = (inb && col < n) ? Pg[row >= col ? tri(row, col) : tri(col, row)] : 0.0;
       }
+    }
+    auto store_pv = [&]() {
+#pragma unroll
+      for (int k = 0; k < 18; ++k) pxL[k * FT + tid] = pv[k];
+    };
+    if (a.mode != 2) store_pv();      // (a plan first puts its tile and Toeplitz loads in flight as well, next)
+    d4_t acc[NT];                                              // MINUS (P + sigma I + rho A'A)^-1, tile row w (slot order)
+    double Gd[2][6][3];                                        // this lane's two Toeplitz blocks
+    // stage 2 reads the inverse in slot order (reduce4_slots): one lane-dependent register permutation per
+    // factorisation instead of twelve selects per iteration
+    auto permute_acc = [&]() {
+      const int i0 = slot_of(0, h, g), i1 = slot_of(1, h, g), i2 = slot_of(2, h, g), i3 = slot_of(3, h, g);
+#pragma unroll
+      for (int J = 0; J < NTT; ++J) {
+        const d4_t t = acc[J];
+        acc[J][0] = sel4(t[0], t[1], t[2], t[3], i0);
+        acc[J][1] = sel4(t[0], t[1], t[2], t[3], i1);
+        acc[J][2] = sel4(t[0], t[1], t[2], t[3], i2);
+        acc[J][3] = sel4(t[0], t[1], t[2], t[3], i3);
+      }
+    };
+    // the lane's two Toeplitz blocks (utils.py:171-197: CC[i,j] = A^(i-j) B, rows S kept, slot order of reduce6_slots)
+    auto load_Gd = [&]() {
+      constexpr int SR[6] = {2, 3, 4, 5, 6, 8};
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int d = 2 * q + bb;
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) {
+          const int srow = h ? SR[(rr + 3) % 6] : SR[rr];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) Gd[bb][rr][c] = d < N ? Gg[d * 27 + srow * 3 + c] : 0.0;
+        }
+      }
+    };
+    double *const tl = a.tiles ? a.tiles + (size_t)b * MPC_TILE_DOUBLES + (size_t)(w * NT * 4) * 64 + l : nullptr;
+    if (a.mode == 2) {
+      // a plan's solve starts from HBM-cold data: tiles (24 loads per lane, 512-byte runs), Toeplitz blocks (36) and the
+      // P entries (18) go out in ONE batch, ahead of everything that waits for a load, instead of three serial round trips
+#pragma unroll
+      for (int J = 0; J < NTT; ++J)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) acc[J][qq] = w < NTT ? tl[(J * 4 + qq) * 64] : 0.0;
+      load_Gd();
     }
     // ---- bounds of this lane's constraint row (utils.py:129-152; rows with two infinite bounds are not kept)
     double lo = 0.0, hi = 0.0, z = 0.0, y = 0.0, dy = 0.0, xs = 0.0;
@@ -490,7 +535,6 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
       if (isfinite(x0) && isfinite(z0) && isfinite(y0)) { xs = x0; z = z0; y = y0; }
     }
     double *const exm = const_cast<double *>(ex) + mpc_ext_model(N);      // A | Q | Qbar | rho of a prepared plan
-    double *const tl = a.tiles ? a.tiles + (size_t)b * MPC_TILE_DOUBLES + (size_t)(w * NT * 4) * 64 + l : nullptr;
     double rho = a.mode == 2 ? exm[243] : a.s.rho;
     if (kind) { const double w0 = (a.mode == 2 ? rho : 0.0) * z - y; wdst[0] = w0; wdst[dup] = w0; }   // w = rho z - y of the start point (zero unless warm)
     if (!(rho > 0.0)) {   // automatic: balance the two terms of P + rho A'A (our QP is not Ruiz-scaled as OSQP's would be)
@@ -511,21 +555,22 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
 #else
 #define MSTAMP(i)
 #endif
+    bool plan_loaded = false;
+    if (from_plan) {                                           // (loads issued at the top of the prologue)
+      from_plan = false; plan_loaded = true;
+      store_pv();
+      permute_acc();
+    }
     // outer loop: one trip per KKT factorisation (rho changes at most every rho_every iterations).  The inverse is a
     // real call; it sits OUTSIDE the iteration loop so that nothing big is live across it.
     while (!done) {
-      d4_t acc[NT];                                            // MINUS (P + sigma I + rho A'A)^-1, tile row w
       {
 #ifdef F16_EXP_STAMPM
         __builtin_amdgcn_s_waitcnt(0);
         tP1 = __builtin_amdgcn_s_memtime();
 #endif
-        if (from_plan) {                                        // tiles [w][J][q][lane]: 512-byte runs per load
-          from_plan = false;
-#pragma unroll
-          for (int J = 0; J < NTT; ++J)
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) acc[J][qq] = w < NTT ? tl[(J * 4 + qq) * 64] : 0.0;
+        if (plan_loaded) {
+          plan_loaded = false;
         } else {
           d4_t tmp[NT];                                        // the call hands the tiles over in memory: copy them into
           ok = mfma_inverse<NTT>(tmp, Cs, Pg, Ag, rho, sigma, n) && ok;   // an array whose address never escapes
@@ -541,39 +586,13 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
             if (tid == 0) { exm[243] = rho; exm[244] = ok ? 1.0 : 0.0; }
             done = true;
           }
+          permute_acc();
+          load_Gd();                                           // after the call: nothing big is live across it
         }
 #ifdef F16_EXP_STAMPM
         tP2 = __builtin_amdgcn_s_memtime();
         t0 = tP2;
 #endif
-      }
-      // ---- stage 2 reads the inverse in slot order (reduce4_slots): one lane-dependent register permutation per
-      // factorisation instead of twelve selects per iteration
-      {
-        const int i0 = slot_of(0, h, g), i1 = slot_of(1, h, g), i2 = slot_of(2, h, g), i3 = slot_of(3, h, g);
-#pragma unroll
-        for (int J = 0; J < NTT; ++J) {
-          const d4_t t = acc[J];
-          acc[J][0] = sel4(t[0], t[1], t[2], t[3], i0);
-          acc[J][1] = sel4(t[0], t[1], t[2], t[3], i1);
-          acc[J][2] = sel4(t[0], t[1], t[2], t[3], i2);
-          acc[J][3] = sel4(t[0], t[1], t[2], t[3], i3);
-        }
-      }
-      // ---- this lane's two Toeplitz blocks (utils.py:171-197: CC[i,j] = A^(i-j) B, rows S kept); loaded after the call
-      double Gd[2][6][3];
-      {
-        constexpr int SR[6] = {2, 3, 4, 5, 6, 8};
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-          const int d = 2 * q + bb;
-#pragma unroll
-          for (int rr = 0; rr < 6; ++rr) {
-            const int srow = h ? SR[(rr + 3) % 6] : SR[rr];         // slot order of the kept rows (reduce6_slots)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) Gd[bb][rr][c] = d < N ? Gg[d * 27 + srow * 3 + c] : 0.0;
-          }
-        }
       }
       const double rinv = 1.0 / rho;
       bool refactor = false;
