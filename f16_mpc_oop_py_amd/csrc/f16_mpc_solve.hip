@@ -476,7 +476,8 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
 #pragma unroll
       for (int k = 0; k < 18; ++k) pxL[k * FT + tid] = pv[k];
     };
-    if (a.mode != 2) store_pv();      // (a plan first puts its tile and Toeplitz loads in flight as well, next)
+    // (stored further down: every other load of the prologue is issued first, so that they share one round trip)
+    const double trP = (a.mode != 2 && xown) ? Pg[tri(xe, xe)] : 0.0, trA = (a.mode != 2 && xown) ? Ag[tri(xe, xe)] : 0.0;
     d4_t acc[NT];                                              // MINUS (P + sigma I + rho A'A)^-1, tile row w (slot order)
     double Gd[2][6][3];                                        // this lane's two Toeplitz blocks
     // stage 2 reads the inverse in slot order (reduce4_slots): one lane-dependent register permutation per
@@ -537,8 +538,9 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
     double *const exm = const_cast<double *>(ex) + mpc_ext_model(N);      // A | Q | Qbar | rho of a prepared plan
     double rho = a.mode == 2 ? exm[243] : a.s.rho;
     if (kind) { const double w0 = (a.mode == 2 ? rho : 0.0) * z - y; wdst[0] = w0; wdst[dup] = w0; }   // w = rho z - y of the start point (zero unless warm)
+    if (a.mode != 2) store_pv();
     if (!(rho > 0.0)) {   // automatic: balance the two terms of P + rho A'A (our QP is not Ruiz-scaled as OSQP's would be)
-      double tr[2] = {xown ? Pg[tri(xe, xe)] : 0.0, xown ? Ag[tri(xe, xe)] : 0.0};
+      double tr[2] = {trP, trA};
       const bool sums[2] = {true, true};
       block_reduce<2>(tr, sums, red);
       rho = fmin(fmax(RHO_AUTO_SCALE * sqrt(tr[0] / tr[1]), 1e-6), 1e6);
