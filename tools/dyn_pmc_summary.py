@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Summarise the dynamics SQ-counter pass of tools/profile_round.sh into profiles/<tag>_pmc_dyn.csv.
+
+  python tools/dyn_pmc_summary.py gpurun_out/prof_dyn r01
+
+One row per (kernel, counter): mean per dispatch, plus derived VALU issue utilisation =
+SQ_ACTIVE_INST_VALU / (4 x SQ_BUSY_CYCLES-equivalent SIMD cycles) printed to stdout."""
+import csv, glob, os, sys
+from collections import defaultdict
+
+d, tag = sys.argv[1], sys.argv[2]
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+acc = defaultdict(lambda: [0.0, 0])
+for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"]
+        if "k_rollout" not in name:
+            continue
+        short = name.split("(")[0].replace("void f16::", "")
+        a = acc[(short, r["Counter_Name"])]
+        a[0] += float(r["Counter_Value"]); a[1] += 1
+out = os.path.join(REPO, "profiles", f"{tag}_pmc_dyn.csv")
+with open(out, "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "counter", "dispatch_rows", "mean_per_dispatch"])
+    for (k, c), (s, n) in sorted(acc.items()):
+        w.writerow([k, c, n, "%.1f" % (s / n)])
+kern = sorted({k for k, _ in acc})
+for k in kern:
+    g = lambda c: acc[(k, c)][0] / max(acc[(k, c)][1], 1)
+    print("%-28s VALU wave-instr %.3e | active VALU cycles / wave cycles %.3f | wait / wave cycles %.3f | LDS instr %.3e, conflict/active %.3f"
+          % (k, g("SQ_INSTS_VALU"), g("SQ_ACTIVE_INST_VALU") / max(g("SQ_WAVE_CYCLES"), 1), g("SQ_WAIT_ANY") / max(g("SQ_WAVE_CYCLES"), 1),
+             g("SQ_INSTS_LDS"), g("SQ_LDS_BANK_CONFLICT") / max(g("SQ_ACTIVE_INST_LDS"), 1)))
+print("wrote", out)

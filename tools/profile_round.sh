@@ -19,3 +19,7 @@ rocprofv3 --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_AC
 echo "mpc passes done"
 python3 bench.py > $O/bench.json 2> $O/bench.err
 echo "plain bench done"
+# SQ counters of the dynamics kernels (issue utilisation behind the "VALU-bound when the chip is full" reading)
+rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT \
+  -d $O/prof_dyn -o d -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mpc > /dev/null 2> $O/prof_dyn.err
+echo "dynamics SQ pass done"
