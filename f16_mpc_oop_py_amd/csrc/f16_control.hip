@@ -967,6 +967,8 @@ struct f16_mpc_plan {
   double *buf;
   double *warm;        // x, z, y of the previous solve (allocated when warm start is switched on)
   bool warm_on, have_prev;
+  int32_t *sched;      // [2][B]: iteration counts of the last solve | dispatch order of the next (longest first)
+  bool have_order;
   MpcArgs a;
 };
 
@@ -986,7 +988,7 @@ extern "C" int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const doub
   if (hzn < 1 || hzn > FAST_MAXN) return set_error(F16_EINVAL, "prepared plans need 1 <= hzn <= 32");
   f16_mpc_plan *p = new f16_mpc_plan();
   p->ctx = ctx; p->B = B; p->ld = ld; p->N = hzn; p->dt = dt;
-  p->warm = nullptr; p->warm_on = false; p->have_prev = false;
+  p->warm = nullptr; p->warm_on = false; p->have_prev = false; p->sched = nullptr; p->have_order = false;
   if (s) p->s = *s; else f16_qp_default_settings(&p->s);
   if (p->s.check_every < 1 || p->s.rho_every < 1 || !(p->s.rho >= 0) || !(p->s.sigma > 0) || p->s.max_iter < 1) {
     delete p;
@@ -995,6 +997,7 @@ extern "C" int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const doub
   const size_t np = (size_t)(3 * hzn) * (3 * hzn + 1) / 2;
   const size_t per = 2 * np + mpc_ext_doubles(hzn) + MPC_TILE_DOUBLES;
   if (int rc = hip_check(hipMalloc(&p->buf, per * (size_t)B * sizeof(double)), "hipMalloc MPC plan")) { delete p; return rc; }
+  if (int rc = hip_check(hipMalloc(&p->sched, 2 * (size_t)B * sizeof(int32_t)), "hipMalloc MPC plan")) { (void)hipFree(p->buf); delete p; return rc; }
   MpcArgs &a = p->a;
   a = MpcArgs{};
   a.Ad = Ad; a.Bd = Bd; a.Cd = Cd; a.B = B; a.ld = ld; a.N = hzn; a.dt = dt; a.s = p->s;
@@ -1004,7 +1007,7 @@ extern "C" int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const doub
   int rc = plan_launch_build(p, a, stream);
   if (!rc) rc = mpc_fast_solve_launch(ctx, a, stream);
   a.Ad = a.Bd = a.Cd = nullptr;                        // not retained
-  if (rc) { (void)hipFree(p->buf); delete p; return rc; }
+  if (rc) { (void)hipFree(p->buf); (void)hipFree(p->sched); delete p; return rc; }
   *plan = p;
   return F16_OK;
 }
@@ -1017,8 +1020,12 @@ extern "C" int f16_mpc_plan_solve(f16_mpc_plan *p, const double *x, const double
   a.mode = 2;
   a.warm = p->warm_on ? p->warm : nullptr;
   a.warm_load = p->warm_on && p->have_prev;
+  a.iters_out = p->sched;
+  a.order = p->have_order ? p->sched + p->B : nullptr;
   if (int rc = plan_launch_build(p, a, stream)) return rc;
   if (int rc = mpc_fast_solve_launch(p->ctx, a, stream)) return rc;
+  if (int rc = mpc_plan_order_launch(p->sched, p->sched + p->B, p->B, p->s.check_every, stream)) return rc;
+  p->have_order = true;
   p->have_prev = p->warm_on;
   return F16_OK;
 }
@@ -1037,6 +1044,7 @@ extern "C" void f16_mpc_plan_destroy(f16_mpc_plan *p) {
   if (!p) return;
   (void)hipDeviceSynchronize();
   (void)hipFree(p->buf);
+  if (p->sched) (void)hipFree(p->sched);
   if (p->warm) (void)hipFree(p->warm);
   delete p;
 }

@@ -31,6 +31,8 @@ struct MpcArgs {
   int mode;                   // 0 one-shot; 1 prepare (build + factor, keep everything, no iterations); 2 solve from a plan
   double *warm;               // plans with warm start: [B][MPC_WARM_DOUBLES] x, z, y of the previous solve (per lane)
   int warm_load;              // start from them (else from zero, as the reference's fresh OSQP object does)
+  const int32_t *order;       // plans: workgroup -> aircraft map (longest solve of the previous call first), or null
+  int32_t *iters_out;         // plans: iteration count of this solve per aircraft (input of the next call's order)
   long B, ld;
   int N;
   double dt;
@@ -47,5 +49,6 @@ constexpr int MPC_TILE_DOUBLES = 6 * 6 * 4 * 64;   // six tile rows x six tiles 
 // f16_mpc_solve.hip
 constexpr int FAST_MAXN = 32;
 int mpc_fast_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream);
+int mpc_plan_order_launch(const int32_t *iters, int32_t *order, long B, int check_every, void *stream);
 
 }  // namespace f16
