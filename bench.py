@@ -208,6 +208,17 @@ def bench_mpc(args, dev, rank, world, fdist, barrier):
     dt = fdist.max_over_ranks(time.perf_counter() - t0, dev) / n
     it = info["iters"].cpu().numpy()
     assert fdist.or_status(info["status"]) == 0
+    # the same without the dispatch-order heuristic (workgroups in the caller's order instead of longest-first by the
+    # previous call's iteration counts): what a first call on an unseen batch costs
+    os.environ["F16_MPC_DISPATCH_ORDER"] = "0"
+    env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn)
+    barrier()
+    dco = fdist.max_over_ranks(time.perf_counter() - t0, dev) / n
+    del os.environ["F16_MPC_DISPATCH_ORDER"]
     # linearise + ZOH + LQR chain (BASELINE config 3)
     env._calc_LQR_gain()
     barrier()
@@ -242,6 +253,8 @@ def bench_mpc(args, dev, rank, world, fdist, barrier):
                          "note": "dense-form FLOP accounting of SURVEY 8(d) over the measured time; the kernels use the "
                                  "Toeplitz recursion, so issued FLOPs are lower"},
             "admm_iters_mean": float(np.mean(it)), "mfma": mfma,
+            "dispatch": {"order": "longest-first by the previous call's iteration counts (any order gives the same results)",
+                         "value_in_caller_order": world * B / dco, "ms_per_batch_in_caller_order": dco * 1e3},
             "rho_start_0p1": {"value": world * B / d01, "unit": "solves/s", "ms_per_batch": d01 * 1e3,
                               "admm_iters": {"min": float(it01.min()), "median": float(np.median(it01)),
                                              "max": float(it01.max()), "mean": float(it01.mean())},

@@ -64,6 +64,7 @@ extern "C" void f16_destroy(f16_ctx *c) {
   if (c->d_lofi) (void)hipFree(c->d_lofi);
   if (c->d_one) (void)hipFree(c->d_one);
   if (c->d_work) (void)hipFree(c->d_work);
+  if (c->d_sched) (void)hipFree(c->d_sched);
   if (c->h_one) (void)hipHostFree(c->h_one);
   delete c;
 }

@@ -12,6 +12,7 @@
 // so CC*U and CC'*v are causal (adjoint) convolutions with the N blocks G_k = A^k B, and CC'QQ CC is built by a
 // diagonal recursion over the same blocks (DESIGN.md "QP build").
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <math.h>
 
 #include <mutex>
@@ -936,7 +937,29 @@ static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream, int mode) {
   return 0;
 #endif
   if (mode == 1) return F16_OK;
-  return mpc_fast_solve_launch(ctx, a, stream);
+  // Dispatch order (see k_plan_order): the reference's closed loops call calc_MPC_action once per step on states that
+  // move little, so the iteration counts of the previous call of the same batch size predict this one's; any order is
+  // valid, a stale one only loses the gain.  F16_MPC_DISPATCH_ORDER=0 keeps the caller's order (measurements).
+  const char *ev = getenv("F16_MPC_DISPATCH_ORDER");
+  const bool use_order = !(ev && ev[0] == '0');
+  if (use_order) {
+    static std::mutex mu2;
+    std::lock_guard<std::mutex> lk(mu2);
+    if (ctx->sched_B != a.B) {
+      if (ctx->d_sched) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->d_sched); ctx->d_sched = nullptr; }
+      ctx->sched_B = 0; ctx->sched_valid = 0;
+      if (int rc = hip_check(hipMalloc(&ctx->d_sched, 2 * (size_t)a.B * sizeof(int32_t)), "hipMalloc dispatch order")) return rc;
+      ctx->sched_B = a.B;
+    }
+    a.iters_out = ctx->d_sched;
+    a.order = ctx->sched_valid ? ctx->d_sched + a.B : nullptr;
+  }
+  if (int rc = mpc_fast_solve_launch(ctx, a, stream)) return rc;
+  if (use_order) {
+    if (int rc = mpc_plan_order_launch(ctx->d_sched, ctx->d_sched + a.B, a.B, a.s.check_every, stream)) return rc;
+    ctx->sched_valid = 1;
+  }
+  return F16_OK;
 }
 
 extern "C" int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,

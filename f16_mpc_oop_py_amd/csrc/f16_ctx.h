@@ -12,6 +12,10 @@ struct f16_ctx {
   double *h_one;    // pinned mirror
   void *d_work;     // QP workspace (packed P and A'A per aircraft), grown on demand
   size_t work_bytes;
+  // one-shot MPC calls: iteration counts of the last call | dispatch order derived from them ([2][sched_B] int32)
+  int32_t *d_sched;
+  long sched_B;
+  int sched_valid;
 };
 
 namespace f16 {
