@@ -373,3 +373,19 @@ def test_plan_warm_start_closed_loop():
     assert runs[True][1][0] == runs[False][1][0]                # the first solve has nothing to start from
     assert runs[True][1][1:].mean() < 0.8 * runs[False][1][1:].mean()
     assert np.abs(runs[True][0] - runs[False][0]).max() < 1e-2 * max(1.0, np.abs(runs[False][0]).max()) * 1e-2 + 5e-3
+
+
+def test_dispatch_order_does_not_change_results(monkeypatch):
+    """The workgroup -> aircraft map of k_mpc_fast (longest solve of the previous call first) is scheduling only: the
+    second call of a batch (ordered) returns bit for bit what the first call (caller's order) and an unordered call return."""
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(512, seed=11)
+    env = make_env(x0, u0, xcg=0.35)
+    env.build_ssr()
+    u1, i1 = env._calc_MPC_action(0.0, 0.0, 0.0, 30, return_info=True)        # no history yet for this batch size
+    u2, i2 = env._calc_MPC_action(0.0, 0.0, 0.0, 30, return_info=True)        # dispatched longest-first
+    monkeypatch.setenv("F16_MPC_DISPATCH_ORDER", "0")
+    u3, i3 = env._calc_MPC_action(0.0, 0.0, 0.0, 30, return_info=True)
+    assert len(set(i1["iters"].cpu().numpy().tolist())) > 1                     # a mix of iteration counts to order
+    for u, i in ((u2, i2), (u3, i3)):
+        assert torch.equal(u, u1) and torch.equal(i["iters"], i1["iters"]) and torch.equal(i["u_seq"], i1["u_seq"])
