@@ -122,7 +122,8 @@ int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double
  * + demands dem[3][ld] (p,q,r; written to x_ref[5:8] exactly as the reference does) -> first move
  * u_cmd[3][ld].  Dense condensed QP of horizon hzn (utils.py:21-167) solved by OSQP-style ADMM with the
  * settings in f16_qp_settings (rho = 0 selects the automatic start value 2 sqrt(tr P / tr A'A)).  u_seq (may be NULL) gets the full [3*hzn][ld] sequence,
- * info (may be NULL) gets [4][ld] = iterations, r_prim, r_dual, rho.  * Scheduling only: workgroups are dispatched longest-first by the iteration counts of the previous call of the same
+ * info (may be NULL) gets [4][ld] = iterations, r_prim, r_dual, rho.
+ * Scheduling only: workgroups are dispatched longest-first by the iteration counts of the previous call of the same
  * batch size on this context (results do not depend on it; F16_MPC_DISPATCH_ORDER=0 keeps the caller's order). */
 typedef struct f16_qp_settings {
   double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf;
