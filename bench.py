@@ -7,17 +7,24 @@ i.e. 4,096,000 aircraft-steps per launch.  value = aircraft-steps/s over all ran
 before the timed region.  Multi-GPU: aircraft are independent, so ranks own disjoint batch shards (weak scaling,
 no data-path collective); the max-over-ranks time is taken with one scalar all-reduce.
 
-Extra keys on the same JSON line: "roofline" (dominant kernel k_rollout, HBM-bound by SURVEY 8(d) accounting,
-timed with HIP events on the launch stream), "cpu_baseline" (the C oracle on the host cores, bounded sample),
-"mpc" (batched calc_MPC_action throughput, N=30, xcg 0.35 -- BASELINE config 4).
+Launching.  `python bench.py --gpus N` starts N ranks ITSELF when it was not started by a launcher (RANK unset): the
+parent process -- which never imports torch or touches the GPU -- spawns N fresh children, one per GPU
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment), relays rank 0's JSON line
+and exits with the children's status.  Under `python -m torch.distributed.run ... bench.py --gpus N` the environment is
+already set and each process is a rank.  `n_gpus` in the JSON is the world size the process group actually has.
+
+Extra keys on the same JSON line: "roofline" (dominant kernel, HBM-bound by SURVEY 8(d) accounting, timed with HIP
+events on the launch stream), "cpu_baseline" (the C oracle on the host cores, bounded sample), "mpc" (batched
+calc_MPC_action throughput, N=30, xcg 0.35 -- BASELINE config 4), "config5_closed_loop" (BASELINE config 5 per GPU:
+8192 aircraft, T=100 closed-loop steps, then the timed all-gather of the [T,18,8192] shards).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
@@ -26,7 +33,7 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_STORED_STEP = 144           # 18 doubles written per stored trajectory sample
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -36,16 +43,99 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-mpc", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the large-batch roofline leg")
+    ap.add_argument("--no-config5", action="store_true", help="skip the closed-loop leg")
     ap.add_argument("--large-batch", type=int, default=262144)
     ap.add_argument("--mpc-hzn", type=int, default=30)
-    args = ap.parse_args()
+    ap.add_argument("--config5-batch", type=int, default=8192, help="aircraft per GPU in the closed-loop leg")
+    ap.add_argument("--config5-steps", type=int, default=100)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch path only: rendezvous, shard bookkeeping and the collectives on CPU tensors (no GPU needed)")
+    return ap.parse_args(argv)
 
+
+# ------------------------------------------------------------------------------------------------ launcher
+def spawn_ranks(n, argv):
+    """Parent of a multi-rank run.  Must not import torch / touch the GPU: children are fresh processes (never an exec of
+    a process that has initialised HIP).  Rank 0's stdout is relayed, the other ranks' stdout goes to stderr."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        failed = [p for p in procs if p.poll() not in (None, 0)]
+        if failed:                              # a rank died: the others would wait in a collective until its timeout
+            rc = failed[0].returncode
+            time.sleep(2.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                    # exactly the children started above
+            break
+        time.sleep(0.05)
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    reader.join(10)
+    sys.stdout.write(b"".join(chunks).decode())
+    sys.stdout.flush()
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if args.dry_run:
+        return dry_run(args)
+    run(args)
+
+
+def dry_run(args):
+    """The multi-rank plumbing of run() without the kernels: process group from the environment, contiguous shards,
+    the one data-path collective (all-gather of trajectory shards, both layouts) and the scalar reductions."""
+    import torch
+    import torch.distributed as dist
+    from f16_mpc_oop_py_amd import dist as fdist
+    rank, world, local = fdist.init_from_env()
+    T, Bl = 4, 6
+    lo, hi = fdist.shard_bounds(world * Bl, world, rank)
+    full = torch.arange(T * 18 * world * Bl, dtype=torch.float64).reshape(T, 18, world * Bl)
+    mine = full[:, :, lo:hi].contiguous()
+    flat = fdist.all_gather_trajectories(mine, chunk_bytes=18 * Bl * world * 8 * 3)     # three samples per chunk: ragged tail
+    ranks = fdist.all_gather_trajectories(mine, layout="ranks")
+    ok = bool(torch.equal(flat, full)) and bool(torch.equal(ranks.reshape(T, 18, -1), full))
+    t = fdist.max_over_ranks(1.0 + rank)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": fdist.world_size(), "requested_gpus": args.gpus,
+                          "allgather_ok": ok, "max_over_ranks": t,
+                          "backend": dist.get_backend() if world > 1 else None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
+
+
+# ------------------------------------------------------------------------------------------------ the bench
+def run(args):
+    import numpy as np
     import torch
     import torch.distributed as dist
     from f16_mpc_oop_py_amd import F16Batch
     from f16_mpc_oop_py_amd.workload import config2_states
-
     from f16_mpc_oop_py_amd import dist as fdist
+    from f16_mpc_oop_py_amd.env import _vp
+
     rank, world, local = fdist.init_from_env()
     local = local % max(torch.cuda.device_count(), 1)      # (only differs in a rehearsal with more ranks than GPUs)
     torch.cuda.set_device(local)
@@ -61,9 +151,6 @@ def main():
     x0, u0 = x0_all[rank * B:(rank + 1) * B], u0_all[rank * B:(rank + 1) * B]
     env = F16Batch(x0, u0, device=dev)
     traj = torch.empty((T, 18, B), dtype=torch.float64, device=dev)
-
-    import ctypes
-    from f16_mpc_oop_py_amd.env import _vp
 
     def one_pass():
         env._x.copy_(env._x_init)
@@ -93,30 +180,35 @@ def main():
     steps_total = world * B * T * args.steps
     value = steps_total / elapsed
     achieved = B * T * BYTES_PER_STORED_STEP / (kern_ms * 1e-3) / 1e9
+    kname = "k_rollout_q" if B <= 8192 else ("k_rollout_4w" if B <= 16384 else "k_rollout")
     out = {
         "metric": "F16 env steps/sec (hifi Nguyen model, explicit Euler dt=1ms, batch 4096 per GPU)",
-        "value": value, "unit": "aircraft-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "aircraft-steps/s", "n_gpus": fdist.world_size(), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"BASELINE config 2: open-loop {T}-step rollout, B={B}/GPU, hifi, xcg=0.25, "
                                f"trajectory [T,18,B] stored every step", "batch_per_gpu": B, "euler_steps": T,
-                   "parallelism": f"batch-sharded x{world}, no collective in the timed region"},
-        "roofline": {"bound": "hbm", "kernel": "k_rollout_q" if B <= 4096 else ("k_rollout_4w" if B <= 16384 else "k_rollout"), "achieved": achieved, "peak": HBM_PEAK_GBS,
+                   "parallelism": f"batch-sharded x{world}, no collective in the timed region",
+                   "requested_gpus": args.gpus},
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel_ms": kern_ms, "bytes_per_launch": B * T * BYTES_PER_STORED_STEP,
                      "note": "B=4096: 256 workgroups of 16 aircraft (four lanes per aircraft, four role wavefronts), one per CU; bound by the per-step dependency chain (lookup round trips + fp64 issue), not HBM (DESIGN.md 4)"},
+        "scaling_note": "1/2/4/8-GPU values exist only where the driver ran this command on an 8-GPU node; the builder's "
+                        "box has one GPU (multi-rank paths rehearsed there with F16_DIST_BACKEND=gloo)",
     }
-
-    out["roofline"]["traffic"] = recorded_traffic(B, T)
+    tr, src = recorded_traffic(B, T)
+    out["roofline"]["traffic"] = tr
+    out["roofline"]["traffic_source"] = src
     if world > 1:
         # the one data-path collective -- all-gather of the trajectory shards -- timed on its own
         barrier()
         t0 = time.perf_counter()
-        full = fdist.all_gather_trajectories(traj)
+        full = fdist.all_gather_trajectories(traj, layout="ranks")
         barrier()
         tg = fdist.max_over_ranks(time.perf_counter() - t0, dev)
         out["allgather"] = {"ms": tg * 1e3, "bytes_received_per_gpu": int(full.numel() * 8),
-                            "GB/s_per_gpu": full.numel() * 8 / tg / 1e9,
+                            "GB/s_per_gpu": full.numel() * 8 / tg / 1e9, "layout": "[T,18,W,B/W] view of the receive buffer",
                             "steps_per_s_including_collation": world * B * T / (elapsed / args.steps + tg)}
         del full
     del traj
@@ -124,39 +216,43 @@ def main():
         out["roofline_large_batch"] = bench_large(args, dev, rank)
     if not args.no_mpc:
         out["mpc"] = bench_mpc(args, dev, rank, world, fdist, barrier)
-        out["config5_closed_loop"] = bench_closed_loop(args, dev, rank, world, fdist, barrier)
         if rank == 0:
             out["trim"] = bench_trim(dev)
+    if not args.no_config5:
+        out["config5_closed_loop"] = bench_closed_loop(args, dev, rank, world, fdist, barrier)
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(x0, u0, T)
         if "mpc" in out:
             out["mpc"]["cpu_baseline"] = cpu_baseline_mpc(args.mpc_hzn)
-        out["config1_dropin_loop"] = config1_dropin_loop()
+        out["config1_reference_style_loop"] = config1_reference_style_loop()
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         barrier()
         dist.destroy_process_group()
 
 
 def recorded_traffic(B, T):
-    """HBM bytes per k_rollout launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE/WRITE_SIZE,
-    corrected as MI355X_MICROARCH.md prescribes); recorded under profiles/ by tools/pmc_summary.py.  None if the
-    recorded run was a different workload."""
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of this same command
+    (FETCH_SIZE/WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), RECORDED under profiles/ by
+    tools/pmc_summary.py -- not measured in this run (counters need rocprofv3).  (None, None) if the recorded run was a
+    different workload."""
     path = os.path.join(REPO, "profiles", "traffic_k_rollout.json")
     try:
         rec = json.load(open(path))
         if rec.get("batch") == B and rec.get("euler_steps") == T:
-            return rec["hbm_bytes_per_launch"]
+            return rec["hbm_bytes_per_launch"], "recorded: profiles/traffic_k_rollout.json (rocprofv3 --pmc pass of this command)"
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def bench_large(args, dev, rank):
     """SURVEY.md 8(d) caveat: at B=4096 there are 64 wavefronts for 1024 SIMDs, so the HBM fraction of the same kernel
     family is also reported where the chip is full: B=262,144 aircraft per GPU, 200 Euler steps, every state stored
     (7.5 GB trajectory).  Same accounting (144 B per stored aircraft-step), HIP events on the launch stream."""
+    import numpy as np
     import torch
     from f16_mpc_oop_py_amd import F16Batch
     from f16_mpc_oop_py_amd.workload import config2_states
@@ -182,15 +278,26 @@ def bench_large(args, dev, rank):
     assert int(env.status.max()) == 0 and bool(torch.isfinite(traj[-1]).all())
     ms = float(np.mean(ts))
     gbs = B * T * BYTES_PER_STORED_STEP / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "k_rollout<512>" if B >= 131072 else "k_rollout<256>", "batch_per_gpu": B, "euler_steps": T, "kernel_ms": ms,
-            "steps_per_s": B * T / (ms * 1e-3), "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": B * T * BYTES_PER_STORED_STEP,
-            "note": "two waves per SIMD on all 256 CUs; fp64/VALU issue-bound (~1,700 instructions per aircraft-step)"}
+    res = {"bound": "hbm", "kernel": "k_rollout<512>" if B >= 131072 else "k_rollout<256>", "batch_per_gpu": B, "euler_steps": T, "kernel_ms": ms,
+           "steps_per_s": B * T / (ms * 1e-3), "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": B * T * BYTES_PER_STORED_STEP, "traffic": None,
+           "note": "two waves per SIMD on all 256 CUs; fp64/VALU issue-bound"}
+    try:
+        rec = json.load(open(os.path.join(REPO, "profiles", "traffic_k_rollout_large.json")))
+        if rec.get("batch") == B and rec.get("euler_steps") == T:
+            res["traffic"] = rec["hbm_bytes_per_launch"]
+            res["traffic_source"] = "recorded: profiles/traffic_k_rollout_large.json"
+    except Exception:
+        pass
+    return res
 
 
 def bench_mpc(args, dev, rank, world, fdist, barrier):
     """BASELINE config 4: B=4096/GPU, xcg=0.35, N=30, one calc_MPC_action per aircraft, (A,B) from each aircraft's
-    own linearisation.  Same barrier + max-over-ranks timing rule as the dynamics leg."""
+    own linearisation.  Same barrier + max-over-ranks timing rule as the dynamics leg.  The headline `value` is measured
+    with the solver settings the reference's call implies (osqp defaults, env.py:420-422: Ruiz equilibration, rho = 0.1,
+    adaptive rho); the builder's own start-value rule (no scaling, rho0 = 2 sqrt(tr P / tr A'A)) is reported beside it."""
+    import numpy as np
     import torch
     from f16_mpc_oop_py_amd import F16Batch
     from f16_mpc_oop_py_amd.workload import config4_states
@@ -198,27 +305,46 @@ def bench_mpc(args, dev, rank, world, fdist, barrier):
     x0, u0 = config4_states(B * world)
     env = F16Batch(x0[rank * B:(rank + 1) * B], u0[rank * B:(rank + 1) * B], xcg=0.35, device=dev)
     env.build_ssr()
-    env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn)
     n = max(2, args.steps // 4)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        u, info = env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn, return_info=True)
-    barrier()
-    dt = fdist.max_over_ranks(time.perf_counter() - t0, dev) / n
-    it = info["iters"].cpu().numpy()
-    assert fdist.or_status(info["status"]) == 0
+
+    def timed(settings, reps):
+        env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn, settings=settings)
+        env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn, settings=settings)      # (second call: dispatch order known)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            _, info = env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn, settings=settings, return_info=True)
+        barrier()
+        dt = fdist.max_over_ranks(time.perf_counter() - t0, dev) / reps
+        it = info["iters"].cpu().numpy()
+        return dt, it, int(fdist.or_status(info["status"]))
+
+    def leg(settings, reps):
+        dt, it, st = timed(settings, reps)
+        flop = 5.2e6 + 1.15e5 * float(np.mean(it))          # SURVEY.md 8(d) dense-form accounting
+        return {"value": world * B / dt, "unit": "solves/s", "ms_per_batch": dt * 1e3, "status_or": st,
+                "admm_iters": {"min": float(it.min()), "median": float(np.median(it)), "max": float(it.max()),
+                               "mean": float(it.mean())},
+                "roofline": {"bound": "fp64 vector/MFMA (78.6 TF/s)", "achieved": flop * B / dt / 1e12, "peak": 78.6,
+                             "unit": "TFLOP/s", "frac": flop * B / dt / 78.6e12,
+                             "note": "dense-form FLOP accounting of SURVEY 8(d) over the measured time; the kernels use "
+                                     "the Toeplitz recursion, so issued FLOPs are lower"}}
+
+    modes = env.solver_modes()
+    res = {"metric": "MPC solves/sec (calc_MPC_action, N=%d, batch %d per GPU, xcg=0.35)" % (args.mpc_hzn, B)}
+    legs = {name: leg(s, n) for name, s in modes.items()}
+    head = "osqp_defaults" if "osqp_defaults" in legs else next(iter(legs))
+    res.update(legs[head])
+    res["settings"] = head
+    res["other_settings"] = {k: v for k, v in legs.items() if k != head}
+    assert res["status_or"] == 0
     # the same without the dispatch-order heuristic (workgroups in the caller's order instead of longest-first by the
     # previous call's iteration counts): what a first call on an unseen batch costs
     os.environ["F16_MPC_DISPATCH_ORDER"] = "0"
-    env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn)
-    barrier()
-    dco = fdist.max_over_ranks(time.perf_counter() - t0, dev) / n
+    dco, _, _ = timed(modes[head], n)
     del os.environ["F16_MPC_DISPATCH_ORDER"]
+    res["dispatch"] = {"order": "longest-first by the previous call's iteration counts (any order gives the same results)",
+                       "value_in_caller_order": world * B / dco, "ms_per_batch_in_caller_order": dco * 1e3}
     # linearise + ZOH + LQR chain (BASELINE config 3)
     env._calc_LQR_gain()
     barrier()
@@ -227,44 +353,21 @@ def bench_mpc(args, dev, rank, world, fdist, barrier):
         env._calc_LQR_gain()
     barrier()
     dl = fdist.max_over_ranks(time.perf_counter() - t0, dev) / n
-    # the same solves with OSQP's fixed start value rho = 0.1 (the literal config-4 setting of SURVEY.md 8d; the default
-    # above starts from 2 sqrt(tr P / tr A'A) because the QP is not Ruiz-scaled -- DESIGN.md 4)
-    env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn, settings=dict(rho=0.1))
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(2):
-        _, info01 = env._calc_MPC_action(0.0, 0.0, 0.0, args.mpc_hzn, settings=dict(rho=0.1), return_info=True)
-    barrier()
-    d01 = fdist.max_over_ranks(time.perf_counter() - t0, dev) / 2
-    it01 = info01["iters"].cpu().numpy()
-    flop_per_solve = 5.2e6 + 1.15e5 * float(np.mean(it))          # SURVEY.md 8(d) dense-form accounting
-    mfma = None
-    try:        # fp64 matrix-core counters of this same workload, recorded from the rocprofv3 --pmc pass (profiles/)
+    res["linearise_zoh_lqr_per_s"] = world * B / dl
+    try:        # fp64 matrix-core counters of this same workload, RECORDED from a rocprofv3 --pmc pass (profiles/)
         rec = json.load(open(os.path.join(REPO, "profiles", "mfma_mpc.json")))
         if rec.get("batch") == B and rec.get("hzn") == args.mpc_hzn:
-            mfma = {k: rec[k] for k in ("k_mpc_fast", "k_mpc<true> (build)", "source")}
+            res["mfma"] = {k: rec[k] for k in rec if k not in ("batch", "hzn")}
+            res["mfma"]["source"] = "recorded: profiles/mfma_mpc.json (" + str(rec.get("source", "rocprofv3 --pmc")) + ")"
     except Exception:
         pass
-    return {"metric": "MPC solves/sec (calc_MPC_action, N=%d, batch %d per GPU, xcg=0.35)" % (args.mpc_hzn, B),
-            "value": world * B / dt, "unit": "solves/s", "ms_per_batch": dt * 1e3,
-            "admm_iters": {"min": float(it.min()), "median": float(np.median(it)), "max": float(it.max())},
-            "roofline": {"bound": "fp64 vector/MFMA (78.6 TF/s)", "achieved": flop_per_solve * B / dt / 1e12,
-                         "peak": 78.6, "unit": "TFLOP/s", "frac": flop_per_solve * B / dt / 78.6e12,
-                         "note": "dense-form FLOP accounting of SURVEY 8(d) over the measured time; the kernels use the "
-                                 "Toeplitz recursion, so issued FLOPs are lower"},
-            "admm_iters_mean": float(np.mean(it)), "mfma": mfma,
-            "dispatch": {"order": "longest-first by the previous call's iteration counts (any order gives the same results)",
-                         "value_in_caller_order": world * B / dco, "ms_per_batch_in_caller_order": dco * 1e3},
-            "rho_start_0p1": {"value": world * B / d01, "unit": "solves/s", "ms_per_batch": d01 * 1e3,
-                              "admm_iters": {"min": float(it01.min()), "median": float(np.median(it01)),
-                                             "max": float(it01.max()), "mean": float(it01.mean())},
-                              "status_or": int(fdist.or_status(info01["status"]))},
-            "linearise_zoh_lqr_per_s": world * B / dl}
+    return res
 
 
 def bench_trim(dev, B=4096):
-    """straight-and-level trim of B flight conditions in one launch (the reference's Nelder-Mead,
-    env.py:198-292, one wavefront lane per condition); the reference takes 0.56 s for one condition."""
+    """straight-and-level trim of B flight conditions in one call (the reference's Nelder-Mead,
+    env.py:198-292); the reference takes 0.56 s for one condition."""
+    import numpy as np
     import torch
     from f16_mpc_oop_py_amd import F16Batch
     rng = np.random.default_rng(7)
@@ -277,32 +380,35 @@ def bench_trim(dev, B=4096):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     cost = info["cost"].cpu().numpy()
-    return {"conditions": B, "ms": dt * 1e3, "trims_per_s": B / dt, "cost_max": float(cost.max()),
-            "nfev_mean": float(info["nfev"].double().mean()), "nfev_max": int(info["nfev"].max()),
-            "reference_s_per_trim": 0.56,
-            "note": "one lane per condition: the launch lasts as long as its slowest member (conditions that are not "
-                    "trimmable run Nelder-Mead to the reference's maxiter = 50,000 iterations)"}
+    nfev = info["nfev"].cpu().numpy()
+    st = info["status"].cpu().numpy()
+    return {"conditions": B, "ms": dt * 1e3, "trims_per_s": B / dt, "cost_median": float(np.median(cost)),
+            "cost_max": float(cost.max()), "nfev_mean": float(nfev.mean()), "nfev_max": int(nfev.max()),
+            "not_converged": int(((st & 64) != 0).sum()), "reference_s_per_trim": 0.56}
 
 
-def bench_closed_loop(args, dev, rank, world, fdist, barrier, B=8192, T=20):
-    """BASELINE config 5 shape per GPU: B = 8192 aircraft, closed loop (calc_MPC_action N = 30, then one Euler step),
-    T steps, trajectory kept on the device ([T,18,B]; the one all-gather is timed in the open-loop leg).  The model is
-    frozen at construction as in the reference (env.py:49-60), so the model-only part of the QP is a prepared plan;
-    the one-shot figure (everything rebuilt per call, as the reference does) is measured beside it."""
+def bench_closed_loop(args, dev, rank, world, fdist, barrier):
+    """BASELINE config 5 per GPU: B = 8192 aircraft, closed loop (calc_MPC_action N = 30, then one Euler step), T = 100
+    steps with the trajectory [T,18,B] kept on the device, then the ONE data-path collective: the all-gather of the
+    shards, timed on its own.  The model is frozen at construction as in the reference (env.py:49-60), so
+    the model-only part of the QP is a prepared plan; shorter legs measure the variants beside it."""
     import torch
     from f16_mpc_oop_py_amd import F16Batch
     from f16_mpc_oop_py_amd.workload import config4_states
+    B, T = args.config5_batch, args.config5_steps
     x0, u0 = config4_states(B * world)
     sl = slice(rank * B, (rank + 1) * B)
     res = {}
-    for name, use_plan, steps in (("prepared_plan", True, T), ("one_shot", False, max(4, T // 4)),
-                                  ("prepared_plan_warm_start", True, T), ("prepared_plan_warm_start_check5", True, T)):
+    short = max(4, T // 5)
+    for name, use_plan, steps in (("prepared_plan", True, T), ("one_shot", False, max(4, short // 2)),
+                                  ("prepared_plan_warm_start", True, short), ("prepared_plan_warm_start_check5", True, short)):
         env = F16Batch(x0[sl], u0[sl], xcg=0.35, device=dev)
         env.build_ssr()
         if use_plan:
             env.prepare_MPC(args.mpc_hzn, settings=dict(check_every=5) if name.endswith("check5") else None,
                             warm_start="warm_start" in name)
         fdist.closed_loop_mpc_rollout(env, steps=2, hzn=args.mpc_hzn, gather=False, use_plan=use_plan)
+        env.reset()
         barrier()
         t0 = time.perf_counter()
         traj = fdist.closed_loop_mpc_rollout(env, steps=steps, hzn=args.mpc_hzn, gather=False, use_plan=use_plan)
@@ -310,8 +416,20 @@ def bench_closed_loop(args, dev, rank, world, fdist, barrier, B=8192, T=20):
         dt = fdist.max_over_ranks(time.perf_counter() - t0, dev)
         assert bool(torch.isfinite(traj).all()) and fdist.or_status(env.status) & ~(64 | 128) == 0
         res[name] = {"aircraft_steps_per_s": world * B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps}
+        if name == "prepared_plan":
+            barrier()
+            t0 = time.perf_counter()
+            full = fdist.all_gather_trajectories(traj, layout="ranks")
+            barrier()
+            tg = fdist.max_over_ranks(time.perf_counter() - t0, dev)
+            res["allgather"] = {"ms": tg * 1e3, "bytes_received_per_gpu": int(full.numel() * 8) if world > 1 else 0,
+                                "shape": list(full.shape), "world": fdist.world_size()}
+            res["aircraft_steps_per_s"] = world * B * steps / dt
+            res["aircraft_steps_per_s_including_collation"] = world * B * steps / (dt + tg)
+            del full
         del env, traj
     res["batch_per_gpu"] = B
+    res["steps"] = T
     res["hzn"] = args.mpc_hzn
     res["note"] = ("prepared_plan / one_shot start every solve cold, as the reference does (a new OSQP object per call); "
                    "warm_start is the opt-in extension (OSQP's in-object default); check5 = the same with the termination test "
@@ -340,57 +458,81 @@ def cpu_baseline(x0, u0, T):
                       f"(single-thread figure: first {n1} aircraft); oracle/libf16_oracle.so (C restatement)"}
 
 
-def cpu_baseline_mpc(hzn, n=12):
-    """the MPC CPU baseline is the same-algorithm numpy restatement (oracle/, kind 'port') on the same
-    config-4 flight conditions -- OSQP itself cannot be timed anywhere in this pipeline (not installable offline).
-    Bounded sample: n aircraft, single thread; whole chain per solve = linearise + ZOH + setup_OSQP + ADMM."""
+def cpu_baseline_mpc(hzn):
+    """the MPC CPU baseline is the C restatement of the same chain (oracle/f16_mpc_oracle.c, kind
+    'port': linearise + ZOH + DARE + setup_OSQP + OSQP-style ADMM with the reference's implied settings) on the same
+    config-4 flight conditions, single thread and all cores -- OSQP itself cannot be timed anywhere in this pipeline
+    (not installable offline)."""
+    import numpy as np
     from oracle import mpc_oracle as mo
     from f16_mpc_oop_py_amd.workload import config4_states
     ora = mo.COracle()
-    x0, _ = config4_states(n)
+    cores = min(len(os.sched_getaffinity(0)), 64)
+    n1, nall = 48, 48 * cores
+    x0, _ = config4_states(max(nall, n1))
     t0 = time.perf_counter()
-    its = []
-    for b in range(n):
-        Ac, Bc, Cc, Dc = ora.linearise_na(x0[b], xcg=0.35)
-        Ad, Bd, Cd, _ = mo.c2d(Ac, Bc, Cc, Dc, 0.001)
-        P, q, A, l, u = mo.mpc_qp(x0[b], Ad, Bd, Cd, hzn, 0.001)
-        its.append(mo.admm_osqp_style(P, q, A, l, u)["iters"])
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "solves/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
-            "sample": f"{n} config-4 aircraft, N={hzn}: C linearise + scipy ZOH/DARE + numpy setup_OSQP + numpy ADMM "
-                      f"(same rules as the kernel; mean {float(np.mean(its)):.0f} iterations); one Python thread, numpy/BLAS may use the cores listed"}
+    r1 = ora.mpc_batch(x0[:n1], hzn, xcg=0.35, nthreads=1)
+    t1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ra = ora.mpc_batch(x0[:nall], hzn, xcg=0.35, nthreads=cores)
+    ta = time.perf_counter() - t0
+    return {"value": nall / ta, "unit": "solves/s", "cores": cores, "kind": "port", "single_thread_value": n1 / t1,
+            "admm_iters_mean": float(np.mean(ra["iters"])),
+            "sample": f"first {nall} config-4 aircraft, N={hzn}, on {cores} threads (single-thread figure: first {n1}): "
+                      f"C linearise + ZOH + DARE + dense setup_OSQP + Cholesky ADMM, settings = the GPU headline's"}
 
 
-def config1_dropin_loop(steps=2000):
-    """BASELINE config 1 shape (1 aircraft, lofi, open-loop Euler through the reference-style caller): a Python loop
-    over the drop-in `Nlplant` / `atmos` symbols of libf16hip.so (host pointers, one aircraft per call on the GPU) next
-    to the same loop over the C restatement on the CPU.  us per step, lower is better; not the product's use case."""
+def config1_reference_style_loop(steps=10000):
+    """BASELINE config 1 (1 aircraft, lofi, open-loop Euler through the reference-style caller): the
+    reference's `step` (env.py:105-130) written out against a ctypes handle exposing `Nlplant` / `atmos`
+    (env.py:65-103: four actuator models, upd_lef through atmos(), Nlplant, Euler) for 10,000 steps -- once with the handle
+    = the C restatement on the CPU (what the reference's own .so does), once with the handle = libf16hip.so's drop-in
+    symbols (one aircraft per call on the GPU).  us per step, lower is better; not the product's use case."""
     import ctypes
+    import numpy as np
     from f16_mpc_oop_py_amd import lib
     from f16_mpc_oop_py_amd import parameters as P
     from oracle import mpc_oracle as mo
     L = lib.load()
     L.f16_dropin_config(0.25, 0)
-    x = np.array(P.x0, dtype=np.float64) if hasattr(P, "x0") else None
-    if x is None:
-        from f16_mpc_oop_py_amd.workload import config2_states
-        x = config2_states(1)[0][0].copy()
-    xdot = np.zeros(18)
-    vp = ctypes.c_void_p
+    ora = mo.COracle()                              # (runs f16o_init)
+    ora.lib.f16o_set_xcg(0.25)
+    # plain CDLL handles, as the reference makes them (parameters.py:108-114): no argtypes, c_double / c_void_p objects
+    h_cpu = ctypes.CDLL(os.path.join(REPO, "oracle", "libf16_oracle.so"))
+    h_gpu = ctypes.CDLL(lib.SO_PATH)
+    vp, cd, ci = ctypes.c_void_p, ctypes.c_double, ctypes.c_int
+    x_lb, x_ub = np.array(P.x_lb, dtype=float), np.array(P.x_ub, dtype=float)
 
-    def loop(fn):
-        xx = x.copy()
+    def loop(handle, nsteps):
+        x = np.array(P.x0, dtype=np.float64)
+        u = np.array(P.u0, dtype=np.float64)
+        xdot = np.zeros(18)
+        coeff = np.zeros(3)
         t0 = time.perf_counter()
-        for _ in range(steps):
-            fn(vp(xx.ctypes.data), vp(xdot.ctypes.data), 0)
-            xx[:12] += xdot[:12] * 0.001
-        return (time.perf_counter() - t0) / steps * 1e6
+        for _ in range(nsteps):
+            if ((x < x_lb) | (x > x_ub)).any():                                     # env.py:117-124
+                break
+            # env.py:90-98 (utils.py:289-330)
+            T_dot = np.clip(np.clip(u[0], 1000, 19000) - x[12], -10000, 10000)
+            dh_dot = np.clip(20.2 * (np.clip(u[1], -25, 25) - x[13]), -60, 60)
+            da_dot = np.clip(20.2 * (np.clip(u[2], -21.5, 21.5) - x[14]), -80, 80)
+            dr_dot = np.clip(20.2 * (np.clip(u[3], -30, 30) - x[15]), -120, 120)
+            handle.atmos(cd(x[2]), cd(x[6]), vp(coeff.ctypes.data))                  # utils.py:291
+            alpha_deg = x[7] * 180 / np.pi
+            LF_err = alpha_deg - (x[17] + 2 * alpha_deg)
+            lef_cmd = np.clip((x[17] + 2 * alpha_deg) * 1.38 + 1.45 - coeff[1] / coeff[2] * 9.05, 0, 25)
+            lf2_dot = np.clip((1 / 0.136) * (lef_cmd - x[16]), -25, 25)
+            handle.Nlplant(vp(x.ctypes.data), vp(xdot.ctypes.data), ci(0))          # env.py:100, fi_flag = 0
+            xdot[12:18] = (T_dot, dh_dot, da_dot, dr_dot, lf2_dot, LF_err * 7.25)   # env.py:102
+            x += xdot * 0.001                                                        # env.py:126
+        return (time.perf_counter() - t0) / nsteps * 1e6, x
 
-    gpu_us = loop(L.Nlplant)
-    ora = mo.COracle()
-    cpu_us = loop(ora.lib.Nlplant) if hasattr(ora, "lib") and hasattr(ora.lib, "Nlplant") else None
-    return {"steps": steps, "fidelity": "lofi", "us_per_step_dropin_gpu_symbol": gpu_us,
-            "us_per_step_cpu_restatement_symbol": cpu_us, "unit": "us/step"}
+    cpu_us, xc = loop(h_cpu, steps)
+    gpu_us, xg = loop(h_gpu, steps)
+    return {"steps": steps, "fidelity": "lofi", "us_per_step_cpu_restatement_handle": cpu_us,
+            "us_per_step_dropin_gpu_handle": gpu_us, "unit": "us/step",
+            "final_state_max_rel_diff": float(np.max(np.abs(xc - xg) / np.maximum(1.0, np.abs(xc)))),
+            "reference_us_per_step_measured_in_build_container": "169-188 (BASELINE.md, hifi)"}
 
 
 if __name__ == "__main__":

@@ -54,6 +54,16 @@ extern "C" int f16_create(f16_ctx **out, int device) {
     f16_destroy(c);
     return rc;
   }
+  {   // stream-ordered pool for per-call workspaces: keep freed blocks cached instead of returning them to the driver
+    hipMemPoolProps props = {};
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = device;
+    if ((rc = hip_check(hipMemPoolCreate(&c->pool, &props), "hipMemPoolCreate"))) { c->pool = nullptr; f16_destroy(c); return rc; }
+    uint64_t keep = UINT64_MAX;
+    (void)hipMemPoolSetAttribute(c->pool, hipMemPoolAttrReleaseThreshold, &keep);
+  }
   *out = c;
   return F16_OK;
 }
@@ -63,8 +73,9 @@ extern "C" void f16_destroy(f16_ctx *c) {
   if (c->d_tab) (void)hipFree(c->d_tab);
   if (c->d_lofi) (void)hipFree(c->d_lofi);
   if (c->d_one) (void)hipFree(c->d_one);
-  if (c->d_work) (void)hipFree(c->d_work);
-  if (c->d_sched) (void)hipFree(c->d_sched);
+  (void)hipDeviceSynchronize();       // in-flight calls may still own pool blocks / schedule buffers
+  for (int i = 0; i < c->n_sched; ++i) if (c->sched[i].buf) (void)hipFree(c->sched[i].buf);
+  if (c->pool) (void)hipMemPoolDestroy(c->pool);
   if (c->h_one) (void)hipHostFree(c->h_one);
   delete c;
 }

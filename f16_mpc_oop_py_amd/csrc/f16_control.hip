@@ -902,64 +902,94 @@ extern "C" void f16_qp_default_settings(f16_qp_settings *s) {
   s->check_every = 25; s->rho_every = 100; s->adaptive_rho = 1;
 }
 
-// mode 0: generic one-wave kernel (build + ADMM); 1: build only (workspace P, A'A, q|G|pred); 2: build, then the
-// register-resident 512-thread solver (N <= 32).
-static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream, int mode) {
+// k_mpc's dynamic LDS exceeds 64 KB for the generic solver at large N: opt in ONCE per device, to the MAXN size (never
+// per launch: a concurrent call with a smaller horizon must not shrink the limit under a larger launch, and attribute
+// calls are not legal under stream capture).
+static int mpc_lds_opt_in() {
+  static std::mutex mu;
+  static bool ready[64] = {};
+  int dev = 0;
+  if (int rc = hip_check(hipGetDevice(&dev), "hipGetDevice")) return rc;
+  std::lock_guard<std::mutex> lk(mu);
+  if (dev < 0 || dev >= 64 || ready[dev]) return F16_OK;
+  hipError_t e = hipFuncSetAttribute((const void *)k_mpc<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(mpc_lds_doubles(MAXN, false) * sizeof(double)));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void *)k_mpc<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(mpc_lds_doubles(MAXN, true) * sizeof(double)));
+  if (int rc = hip_check(e, "hipFuncSetAttribute(k_mpc)")) return rc;
+  ready[dev] = true;
+  return F16_OK;
+}
+
+// Per-call QP workspace, stream-ordered (see f16_ctx.h): [B][np] P | [B][np] A'A | [B][ext] extras.
+static int mpc_work_alloc(f16_ctx *ctx, MpcArgs &a, bool with_ext, void *stream, void **block) {
+  const size_t np = (size_t)(3 * a.N) * (3 * a.N + 1) / 2;
+  const size_t need = (2 * np + (with_ext ? mpc_ext_doubles(a.N) : 0)) * (size_t)a.B * sizeof(double);
+  *block = nullptr;
+  if (int rc = hip_check(hipMallocFromPoolAsync(block, need, ctx->pool, (hipStream_t)stream), "hipMallocFromPoolAsync QP workspace")) return rc;
+  a.Ppk = (double *)*block;
+  a.Apk = a.Ppk + np * (size_t)a.B;
+  a.ext = with_ext ? a.Apk + np * (size_t)a.B : nullptr;
+  return F16_OK;
+}
+static int mpc_work_free(void *block, void *stream) {
+  return block ? hip_check(hipFreeAsync(block, (hipStream_t)stream), "hipFreeAsync QP workspace") : F16_OK;
+}
+
+// Dispatch-order history of one-shot calls, per (stream, batch size); nullptr = none available (run in caller's order).
+static f16_ctx::sched_entry *mpc_sched_entry(f16_ctx *ctx, void *stream, long B) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  for (int i = 0; i < ctx->n_sched; ++i)
+    if (ctx->sched[i].stream == stream && ctx->sched[i].B == B) return &ctx->sched[i];
+  if (ctx->n_sched >= F16_MAX_SCHED) return nullptr;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
+  int32_t *buf = nullptr;
+  if (hipMalloc(&buf, 2 * (size_t)B * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  f16_ctx::sched_entry &e = ctx->sched[ctx->n_sched++];
+  e.stream = stream; e.B = B; e.buf = buf; e.valid = 0;
+  return &e;
+}
+
+// mode 0: generic one-wave kernel (build + ADMM); 1: build only (workspace P, A'A, q|G|pred; *keep receives the block,
+// the caller frees it); 2: build, then the register-resident 512-thread solver (N <= 32).
+static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream, int mode, void **keep = nullptr) {
   const int N = a.N;
   if (N < 1 || N > MAXN) return set_error(F16_EINVAL, "horizon must be 1..40 for the LDS-resident QP solver");
-  const size_t np = (size_t)(3 * N) * (3 * N + 1) / 2;
-  const size_t need = (2 * np + mpc_ext_doubles(N)) * (size_t)a.B * sizeof(double);
-  {
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lk(mu);
-    if (ctx->work_bytes < need) {
-      if (ctx->d_work) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->d_work); ctx->d_work = nullptr; ctx->work_bytes = 0; }
-      if (int rc = hip_check(hipMalloc(&ctx->d_work, need), "hipMalloc QP workspace")) return rc;
-      ctx->work_bytes = need;
-    }
-  }
-  a.Ppk = (double *)ctx->d_work;
-  a.Apk = a.Ppk + np * (size_t)a.B;
-  a.ext = mode ? a.Apk + np * (size_t)a.B : nullptr;
   const size_t lds = mpc_lds_doubles(N, mode != 0) * sizeof(double);
   if (lds > 160 * 1024) return set_error(F16_EINVAL, "horizon too large for LDS");
+  if (int rc = mpc_lds_opt_in()) return rc;
+  void *block = nullptr;
+  if (int rc = mpc_work_alloc(ctx, a, mode != 0, stream, &block)) return rc;
+  int rc = F16_OK;
   if (mode == 0) {
-    if (int rc = hip_check(hipFuncSetAttribute((const void *)k_mpc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"))
-      return rc;
     hipLaunchKernelGGL(k_mpc<false>, dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
-    return hip_check(hipGetLastError(), "f16_mpc_batch launch");
-  }
-  if (int rc = hip_check(hipFuncSetAttribute((const void *)k_mpc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"))
-    return rc;
-  hipLaunchKernelGGL(k_mpc<true>, dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
-  if (int rc = hip_check(hipGetLastError(), "f16_mpc_batch setup launch")) return rc;
+    rc = hip_check(hipGetLastError(), "f16_mpc_batch launch");
+  } else {
+    hipLaunchKernelGGL(k_mpc<true>, dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
+    rc = hip_check(hipGetLastError(), "f16_mpc_batch setup launch");
 #ifdef F16_EXP_STAMPB
-  return 0;
+    mode = 1;
 #endif
-  if (mode == 1) return F16_OK;
-  // Dispatch order (see k_plan_order): the reference's closed loops call calc_MPC_action once per step on states that
-  // move little, so the iteration counts of the previous call of the same batch size predict this one's; any order is
-  // valid, a stale one only loses the gain.  F16_MPC_DISPATCH_ORDER=0 keeps the caller's order (measurements).
-  const char *ev = getenv("F16_MPC_DISPATCH_ORDER");
-  const bool use_order = !(ev && ev[0] == '0');
-  if (use_order) {
-    static std::mutex mu2;
-    std::lock_guard<std::mutex> lk(mu2);
-    if (ctx->sched_B != a.B) {
-      if (ctx->d_sched) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->d_sched); ctx->d_sched = nullptr; }
-      ctx->sched_B = 0; ctx->sched_valid = 0;
-      if (int rc = hip_check(hipMalloc(&ctx->d_sched, 2 * (size_t)a.B * sizeof(int32_t)), "hipMalloc dispatch order")) return rc;
-      ctx->sched_B = a.B;
+    if (!rc && mode == 2) {
+      // Dispatch order (see k_plan_order): the reference's closed loops call calc_MPC_action once per step on states that
+      // move little, so the iteration counts of the previous call of the same batch size ON THE SAME STREAM predict this
+      // one's; any order is valid, a stale one only loses the gain.  F16_MPC_DISPATCH_ORDER=0 keeps the caller's order.
+      const char *ev = getenv("F16_MPC_DISPATCH_ORDER");
+      f16_ctx::sched_entry *se = (ev && ev[0] == '0') ? nullptr : mpc_sched_entry(ctx, stream, a.B);
+      if (se) { a.iters_out = se->buf; a.order = se->valid ? se->buf + a.B : nullptr; }
+      rc = mpc_fast_solve_launch(ctx, a, stream);
+      if (!rc && se) {
+        rc = mpc_plan_order_launch(se->buf, se->buf + a.B, a.B, a.s.check_every, stream);
+        if (!rc) se->valid = 1;
+      }
     }
-    a.iters_out = ctx->d_sched;
-    a.order = ctx->sched_valid ? ctx->d_sched + a.B : nullptr;
   }
-  if (int rc = mpc_fast_solve_launch(ctx, a, stream)) return rc;
-  if (use_order) {
-    if (int rc = mpc_plan_order_launch(ctx->d_sched, ctx->d_sched + a.B, a.B, a.s.check_every, stream)) return rc;
-    ctx->sched_valid = 1;
-  }
-  return F16_OK;
+  if (keep && !rc) { *keep = block; return F16_OK; }
+  const int rf = mpc_work_free(block, stream);
+  return rc ? rc : rf;
 }
 
 extern "C" int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
@@ -997,9 +1027,8 @@ struct f16_mpc_plan {
 
 static int plan_launch_build(f16_mpc_plan *p, MpcArgs &a, void *stream) {
   const size_t lds = mpc_lds_doubles(p->N, true) * sizeof(double);
-  if (a.mode == 1) {      // once, when the plan is created (the solve path may run under stream capture)
-    if (int rc = hip_check(hipFuncSetAttribute((const void *)k_mpc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"))
-      return rc;
+  if (a.mode == 1) {      // once per device (the solve path may run under stream capture)
+    if (int rc = mpc_lds_opt_in()) return rc;
   }
   hipLaunchKernelGGL(k_mpc<true>, dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
   return hip_check(hipGetLastError(), "f16_mpc_plan build launch");
@@ -1087,7 +1116,8 @@ extern "C" int f16_mpc_qp_debug(f16_ctx *ctx, const double *Ad, const double *Bd
   MpcArgs a{};
   a.Ad = Ad; a.Bd = Bd; a.Cd = Cd; a.x = x; a.dem = dem; a.ucmd = d_u; a.B = b + 1; a.ld = ld; a.N = N; a.dt = dt;
   f16_qp_default_settings(&a.s);
-  rc = mpc_launch(ctx, a, nullptr, 1);              // build only
+  void *block = nullptr;
+  rc = mpc_launch(ctx, a, nullptr, 1, &block);      // build only; the workspace stays ours until read back
   std::vector<double> dbg(ndbg), Ppk(np), xcol(18);
   if (!rc) rc = hip_check(hipDeviceSynchronize(), "sync");
   if (!rc) rc = hip_check(hipMemcpy(dbg.data(), a.ext + ndbg * (size_t)b, ndbg * sizeof(double), hipMemcpyDeviceToHost), "copy ext");
@@ -1095,6 +1125,7 @@ extern "C" int f16_mpc_qp_debug(f16_ctx *ctx, const double *Ad, const double *Bd
   for (int k = 0; k < 18 && !rc; ++k)
     rc = hip_check(hipMemcpy(&xcol[k], x + k * ld + b, sizeof(double), hipMemcpyDeviceToHost), "copy x");
   (void)hipFree(d_u);
+  (void)mpc_work_free(block, nullptr);
   if (rc) return rc;
   // reference-format QP (utils.py:111-165): P dense, A = [CC; I; D] (15N x 3N), l/u with +-inf rows kept
   for (int i = 0; i < n; ++i)

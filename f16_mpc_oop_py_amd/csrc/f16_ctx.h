@@ -10,13 +10,18 @@ struct f16_ctx {
   // single-aircraft scratch for the drop-in Nlplant symbol
   double *d_one;    // [18 + 18]
   double *h_one;    // pinned mirror
-  void *d_work;     // QP workspace (packed P and A'A per aircraft), grown on demand
-  size_t work_bytes;
-  // one-shot MPC calls: iteration counts of the last call | dispatch order derived from them ([2][sched_B] int32)
-  int32_t *d_sched;
-  long sched_B;
-  int sched_valid;
+  // One-shot MPC calls keep NO mutable state that two calls could share:
+  //  * the QP workspace (packed P and A'A + extras per aircraft) is allocated and freed PER CALL, stream-ordered
+  //    (hipMallocFromPoolAsync / hipFreeAsync on the caller's stream, legal under stream capture), from this pool, whose
+  //    release threshold keeps the memory cached between calls;
+  //  * the dispatch-order history (iteration counts of the previous call | order derived from them, [2][B] int32) is
+  //    kept per (stream, batch size): calls on one stream are ordered, calls on different streams never touch the same
+  //    buffer.  Beyond F16_MAX_SCHED entries a call simply runs in the caller's order.
+  hipMemPool_t pool;
+  struct sched_entry { void *stream; long B; int32_t *buf; int valid; } sched[16];
+  int n_sched;
 };
+#define F16_MAX_SCHED 16
 
 namespace f16 {
 int set_error(int code, const char *msg);

@@ -131,6 +131,17 @@ class F16Batch:
     def _get_obs_na(self, x9, u=None):
         return x9
 
+    def debug_table_lookup(self, tid, alpha, beta=None, el=None):
+        """One of the reference's 43 table functions (C/hifi_F16_AeroData.c:109-1861) evaluated by the device lookup code
+        at the given points (degrees).  Test entry.  Returns (values, status bits)."""
+        a = np.ascontiguousarray(alpha, dtype=np.float64)
+        b = np.zeros_like(a) if beta is None else np.ascontiguousarray(beta, dtype=np.float64)
+        e = np.zeros_like(a) if el is None else np.ascontiguousarray(el, dtype=np.float64)
+        out, st = np.zeros_like(a), np.zeros(a.shape, dtype=np.int32)
+        hp = lambda v: ctypes.c_void_p(v.ctypes.data)
+        self._check(self.lib.f16_debug_table_lookup(self.ctx.handle, int(tid), hp(a), hp(b), hp(e), a.size, hp(out), hp(st)))
+        return out, st
+
     # ------------------------------------------------------------------ env.py:65-103
     def _calc_xdot(self, x=None, u=None):
         """xdot [B,18] for states x [B,18] and inputs u [B,4] (defaults: resident x.values/u.values)."""
@@ -206,29 +217,59 @@ class F16Batch:
         return out.t()
 
     # ------------------------------------------------------------------ env.py:294-358
-    def linearise(self, eps=1e-5):
-        """Forward-difference linearisation of the reduced (9-state) model at every aircraft's own state
-        (env.py:294-342 with _calc_xdot_na/_get_obs_na).  Returns Ac [B,9,9], Bc [B,9,3], Cc [B,9,9], Dc [B,9,3]."""
+    def linearise(self, x=None, u=None, _calc_xdot=None, get_obs=None, eps=1e-5):
+        """env.py:294 `linearise(self, x, u, _calc_xdot=None, get_obs=None)`: forward-difference linearisation (eps 1e-5,
+        env.py:319) of every aircraft at its own point, with the reference's dispatch on the model function:
+          * default / `self._calc_xdot` + `self.get_obs`: the 18-state model, x [B,18], u [B,4]
+            -> A [B,18,18], B [B,18,4], C [B,10,18], D [B,10,4]                                        (env.py:45)
+          * `self._calc_xdot_na` + `self._get_obs_na`: the reduced model, x = x9 [B,9] (self._get_mpc_x()), u = u3 [B,3]
+            (self._get_mpc_u()); the other states come from x.values as in env.py:172-177
+            -> A [B,9,9], B [B,9,3], C [B,9,9], D [B,9,3]                                              (env.py:49)
+        x / u default to the resident values.  Only these two models exist on the device; another callable raises."""
+        if _calc_xdot is None or _calc_xdot == self._calc_xdot:
+            if get_obs is not None and get_obs != self.get_obs:
+                raise ValueError("the 18-state model is linearised with get_obs (env.py:312-313)")
+            r = self.linearise_full(eps, discretise=False, x=x, u=u)
+            return r["Ac"], r["Bc"], r["Cc"], r["Dc"]
+        if _calc_xdot != self._calc_xdot_na:
+            raise ValueError("linearise knows the reference's two models: _calc_xdot and _calc_xdot_na")
+        if get_obs is not None and get_obs != self._get_obs_na:
+            raise ValueError("the reduced model is linearised with _get_obs_na (env.py:49)")
+        xs, us = self._x, self._u
+        if x is not None or u is not None:          # scatter the given x9 / u3 over a copy of the resident state (env.py:172-177)
+            xs, us = self._x.clone(), self._u.clone()
+            if x is not None:
+                xs[P.mpc_x_idx] = self._soa(x, 9)
+            if u is not None:
+                us[P.mpc_u_idx] = self._soa(u, 3)
+        return self._linearise_na(eps, xs, us)
+
+    def _linearise_na(self, eps=1e-5, xs=None, us=None):
+        """The reduced (9-state) linearisation at the resident point (or at state-major xs [18,B] / us [4,B])."""
+        xs = self._x if xs is None else xs
+        us = self._u if us is None else us
         Ac = torch.empty((81, self.B), dtype=torch.float64, device=self.device)
         Bc = torch.empty((27, self.B), dtype=torch.float64, device=self.device)
         Cc = torch.empty((81, self.B), dtype=torch.float64, device=self.device)
         st = torch.zeros(self.B, dtype=torch.int32, device=self.device)
-        self._check(self.lib.f16_linearise_batch(self.ctx.handle, _vp(self._x), _vp(self._u), _vp(Ac), _vp(Bc), _vp(Cc), _vp(st),
+        self._check(self.lib.f16_linearise_batch(self.ctx.handle, _vp(xs), _vp(us), _vp(Ac), _vp(Bc), _vp(Cc), _vp(st),
                                                  self.B, self.B, eps, self.xcg, self.fi_flag, self.flags, self._stream))
         self.last_status = st
         self._lin = (Ac, Bc, Cc)
         return (Ac.t().reshape(self.B, 9, 9), Bc.t().reshape(self.B, 9, 3), Cc.t().reshape(self.B, 9, 9),
                 torch.zeros((self.B, 9, 3), dtype=torch.float64, device=self.device))
 
-    def linearise_full(self, eps=1e-5, discretise=True):
+    def linearise_full(self, eps=1e-5, discretise=True, x=None, u=None):
         """env.py:45-46: 18-state linearisation (default _calc_xdot/get_obs) at every aircraft's own (x, u) and its
         zero-order-hold discretisation.  Returns dict(Ac [B,18,18], Bc [B,18,4], Cc [B,10,18], Dc, Ad, Bd)."""
         B = self.B
+        xs = self._x if x is None else self._soa(x, 18)
+        us = self._u if u is None else self._soa(u, 4)
         Ac = torch.empty((324, B), dtype=torch.float64, device=self.device)
         Bc = torch.empty((72, B), dtype=torch.float64, device=self.device)
         Cc = torch.empty((180, B), dtype=torch.float64, device=self.device)
         st = torch.zeros(B, dtype=torch.int32, device=self.device)
-        self._check(self.lib.f16_linearise_full_batch(self.ctx.handle, _vp(self._x), _vp(self._u), _vp(Ac), _vp(Bc), _vp(Cc),
+        self._check(self.lib.f16_linearise_full_batch(self.ctx.handle, _vp(xs), _vp(us), _vp(Ac), _vp(Bc), _vp(Cc),
                                                       _vp(st), B, B, eps, self.xcg, self.fi_flag, self.flags, self._stream))
         self.last_status = st
         out = dict(Ac=Ac.t().reshape(B, 18, 18), Bc=Bc.t().reshape(B, 18, 4), Cc=Cc.t().reshape(B, 10, 18),
@@ -255,7 +296,7 @@ class F16Batch:
     def build_ssr(self, eps=1e-5):
         """env.py:49-60: reduced discrete model per aircraft, frozen until called again."""
         self.release_MPC_plan()                 # a new model invalidates a prepared plan
-        self.linearise(eps)
+        self._linearise_na(eps)
         Ad, Bd = self.discretise()
         self.ssr = (Ad, Bd, self._lin[2])
         return self.ssr
@@ -310,6 +351,11 @@ class F16Batch:
             self.release_MPC_plan()
         except Exception:
             pass
+
+    @staticmethod
+    def solver_modes():
+        """Named QP-solver settings (overrides of f16_qp_default_settings) for benchmarks and tests."""
+        return {"builder_rule": None, "rho_0p1_unscaled": dict(rho=0.1)}
 
     def setup_OSQP(self, p_dem, q_dem, r_dem, hzn, b=0):
         """The QP of aircraft b in the reference's own form (utils.py:21-167 `setup_OSQP`): dense host arrays

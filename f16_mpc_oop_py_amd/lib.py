@@ -11,7 +11,11 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.environ.get("F16HIP_SO", os.path.join(HERE, "libf16hip.so"))   # override only for A/B experiments
-SOURCES = ["f16_api.hip", "f16_dynamics.hip", "f16_control.hip", "f16_mpc_solve.hip", "f16_trim.hip", "f16_tables.cpp"]
+SOURCES = ["f16_api.hip", "f16_dynamics.hip", "f16_control.hip", "f16_mpc_solve.hip", "f16_trim.hip", "f16_debug.hip", "f16_tables.cpp"]
+# the expression-exact (F16_STRICT) build of the plant alone: checker-side evidence that the device lookups and the plant
+# reproduce the reference bit for bit where no libm call is involved (tests/test_gpu_dynamics.py); never used by the product
+STRICT_SO_PATH = os.path.join(HERE, "libf16hip_strict.so")
+STRICT_SOURCES = ["f16_api.hip", "f16_dynamics.hip", "f16_debug.hip", "f16_tables.cpp"]
 # Default build: FMA contraction on, tan = sin/cos, tfac^4.14 = tfac^4 * exp(0.14 log tfac), branch-free sincos (each <= 2 ulp away from
 # the strict form; measured: xdot max rel. error vs the CPU restatement unchanged at 5e-14, -16 % kernel time).
 # F16_STRICT=1 builds the expression-by-expression variant (no contraction, libm tan/pow): 97 % of xdot outputs
@@ -38,19 +42,83 @@ class QPSettings(ctypes.Structure):
                 ("check_every", ctypes.c_int), ("rho_every", ctypes.c_int), ("adaptive_rho", ctypes.c_int)]
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into the in-tree libf16hip.so (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".inc"))]
-    deps.append(os.path.join(HERE, "..", "include", "f16_hip.h"))
-    if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(d) for d in deps):
-        return SO_PATH
+def _fingerprint():
+    """Hash of everything the binary depends on: every source / header under csrc/, the public header, the compiler
+    flags (F16_STRICT, F16_HIPCC_EXTRA included).  Stored beside the .so at build time; load() refuses a stale binary."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h", ".hpp", ".inc")))
+    for f in files + [os.path.join("..", "..", "include", "f16_hip.h")]:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(" ".join(HIPCC_FLAGS + os.environ.get("F16_HIPCC_EXTRA", "").split()).encode())
+    return h.hexdigest()
+
+
+def _compile_and_link(srcs, flags, out, verbose=False):
+    """One object per source, compiled in parallel and cached under build/obj/ by a hash of (source, every header, flags);
+    then one link.  A change to one kernel file recompiles that file only."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + os.environ.get("F16_HIPCC_EXTRA", "").split() + ["-o", SO_PATH] + srcs
+    objdir = os.path.join(HERE, "..", "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdr = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".h", ".hpp", ".inc")):
+            hdr.update(open(os.path.join(CSRC, f), "rb").read())
+    hdr.update(open(os.path.join(HERE, "..", "include", "f16_hip.h"), "rb").read())
+    cflags = [f for f in flags if f != "-shared"]
+    hdr.update(" ".join(cflags).encode())
+
+    def one(src):
+        h = hashlib.sha256(hdr.digest() + open(src, "rb").read()).hexdigest()[:24]
+        obj = os.path.join(objdir, os.path.basename(src) + "." + h + ".o")
+        if not os.path.exists(obj):
+            cmd = [hipcc] + cflags + ["-c", "-o", obj + ".tmp", src]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(obj + ".tmp", obj)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    os.replace(out + ".tmp", out)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into the in-tree libf16hip.so (hipcc cross-compiles without a GPU).  Rebuilds
+    when the recorded fingerprint (sources + flags) differs from the tree's."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    fp = _fingerprint()
+    stamp = SO_PATH + ".stamp"
+    if not force and os.path.exists(SO_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == fp:
+        return SO_PATH
+    _compile_and_link(srcs, HIPCC_FLAGS + os.environ.get("F16_HIPCC_EXTRA", "").split(), SO_PATH, verbose)
+    with open(stamp, "w") as f:
+        f.write(fp + "\n")
     return SO_PATH
+
+
+def build_strict(force=False):
+    """The F16_STRICT variant of the plant sources (no FMA contraction, IEEE divisions, libm tan/pow) as a second,
+    test-only library."""
+    import hashlib
+    srcs = [os.path.join(CSRC, s) for s in STRICT_SOURCES]
+    h = hashlib.sha256(_fingerprint().encode() + b"strict").hexdigest()
+    stamp = STRICT_SO_PATH + ".stamp"
+    if not force and os.path.exists(STRICT_SO_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == h:
+        return STRICT_SO_PATH
+    flags = [f for f in HIPCC_FLAGS if f not in _NUMERICS] + ["-ffp-contract=off"]
+    _compile_and_link(srcs, flags, STRICT_SO_PATH)
+    with open(stamp, "w") as f:
+        f.write(h + "\n")
+    return STRICT_SO_PATH
 
 
 _LIB = None
@@ -63,6 +131,15 @@ def load():
     if _LIB is not None:
         return _LIB
     import torch  # noqa: F401  (must precede CDLL, see docstring)
+    stamp = SO_PATH + ".stamp"
+    stale = not os.path.exists(SO_PATH) or not os.path.exists(stamp) or open(stamp).read().strip() != _fingerprint()
+    if stale and "F16HIP_SO" not in os.environ:
+        # csrc/ or the build flags changed since the binary was built (or it was never built): rebuild rather than run
+        # tests against an old binary; without a compiler this is an error, never a fallback
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        if not os.path.exists(hipcc):
+            raise F16HipError(f"{SO_PATH} is missing or stale and {hipcc} is not available to rebuild it")
+        build()
     if not os.path.exists(SO_PATH):
         raise F16HipError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
     L = ctypes.CDLL(SO_PATH)
@@ -82,7 +159,9 @@ def load():
     L.f16_nlplant_batch.argtypes = [vp, vp, vp, vp, l, l, d, i, u, vp]
     L.f16_rollout.argtypes = [vp, vp, vp, vp, vp, l, l, i, i, d, d, i, u, vp]
     L.f16_xdot_na_batch.argtypes = [vp, vp, vp, vp, vp, vp, l, l, d, i, u, vp]
-    L.f16_trim_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, l, l, d, i, u, i, vp, vp]
+    L.f16_debug_table_lookup.argtypes = [vp, i, vp, vp, vp, i, vp, vp]
+    if hasattr(L, "f16_trim_batch"):
+        L.f16_trim_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, l, l, d, i, u, i, vp, vp]
     if hasattr(L, "f16_linearise_batch"):
         L.f16_linearise_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, l, l, d, d, i, u, vp]
         L.f16_c2d_batch.argtypes = [vp, vp, vp, vp, vp, l, l, d, vp]

@@ -62,6 +62,15 @@ size_t f16_table_image_doubles(void);
 /* copy the device table image back to host (tests): n = f16_table_image_doubles() */
 int f16_debug_read_tables(f16_ctx *ctx, double *h_out);
 
+/* Tests: ONE of the reference's 43 hifi table functions (C/hifi_F16_AeroData.c:109-1861: `_Cx(alpha,beta,el)`,
+ * `_CXq(alpha)`, ... each a lazy file read + interpn(), C/mexndinterp.c:97-265) evaluated on the device by the bracket /
+ * interpolation helpers the dynamics kernels use, at n query points given on the HOST (degrees, as the reference's
+ * functions take them; beta / el ignored by tables without that axis).  tid = enum f16_table_id
+ * (csrc/f16_tables_data.inc: 0 Cx, 1 Cz, 2 Cm, 3 Cn, 4 Cl, 5 Cy, 6-8 r30, 9-11 a20, 12-17 lef, 18-20 a20_lef, 21-29 damping,
+ * 30-32 brett, 33-41 lef damping, 42 eta_el).  h_status (may be NULL) receives the F16_ST_* grid-clamp bits. */
+int f16_debug_table_lookup(f16_ctx *ctx, int tid, const double *h_alpha, const double *h_beta, const double *h_el,
+                           int n, double *h_out, int32_t *h_status);
+
 /* ---- (1) drop-in symbols of the reference .so ---------------------------------------------- */
 /* replaces C/nlplant.c:23  void Nlplant(double *xu, double *xdot, int fidelity)
  * host pointers; reads xu[0..16], writes xdot[0..17]; runs ONE aircraft on the GPU. */
@@ -123,8 +132,10 @@ int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double
  * u_cmd[3][ld].  Dense condensed QP of horizon hzn (utils.py:21-167) solved by OSQP-style ADMM with the
  * settings in f16_qp_settings (rho = 0 selects the automatic start value 2 sqrt(tr P / tr A'A)).  u_seq (may be NULL) gets the full [3*hzn][ld] sequence,
  * info (may be NULL) gets [4][ld] = iterations, r_prim, r_dual, rho.
+ * Nothing the results depend on is retained between calls: the QP workspace is allocated and freed per call, stream-ordered
+ * on `stream` (legal under stream capture); calls on different streams of one context do not share buffers.
  * Scheduling only: workgroups are dispatched longest-first by the iteration counts of the previous call of the same
- * batch size on this context (results do not depend on it; F16_MPC_DISPATCH_ORDER=0 keeps the caller's order). */
+ * batch size on the same stream (results do not depend on it; F16_MPC_DISPATCH_ORDER=0 keeps the caller's order). */
 typedef struct f16_qp_settings {
   double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf;
   int max_iter, check_every, rho_every, adaptive_rho;

@@ -43,6 +43,13 @@ MPC_UDOT_UB = np.array([60., 80., 120.])
 
 
 # --------------------------------------------------------------- C oracle
+class CQPSettings(ctypes.Structure):
+    _fields_ = [("rho", ctypes.c_double), ("sigma", ctypes.c_double), ("alpha", ctypes.c_double),
+                ("eps_abs", ctypes.c_double), ("eps_rel", ctypes.c_double), ("eps_prim_inf", ctypes.c_double),
+                ("max_iter", ctypes.c_int), ("check_every", ctypes.c_int), ("rho_every", ctypes.c_int),
+                ("adaptive_rho", ctypes.c_int), ("scaling", ctypes.c_int)]
+
+
 class COracle:
     """ctypes view of oracle/libf16_oracle.so (build: `make -C oracle`)."""
 
@@ -69,6 +76,15 @@ class COracle:
         L.f16o_set_xcg.argtypes = [d]
         L.f16o_last_status.restype = i
         L.atmos.argtypes = [d, d, dp]
+        L.f16o_set_fix_clr.argtypes = [i]
+        # control chain in C (oracle/f16_mpc_oracle.c)
+        sp = ctypes.POINTER(CQPSettings)
+        L.f16o_c2d.argtypes = [dp, dp, i, i, d, dp, dp]
+        L.f16o_dare.argtypes = [dp, dp, dp, i, i, dp]
+        L.f16o_mpc_qp.argtypes = [dp, dp, dp, dp, i, d, dp, dp, dp, dp, dp, dp]
+        L.f16o_admm.argtypes = [i, i, dp, dp, dp, dp, dp, sp, i, dp, dp]
+        L.f16o_qp_default_settings.argtypes = [sp, i]
+        L.f16o_mpc_batch.argtypes = [dp, l, i, d, d, i, dp, sp, i, dp, ip, ip, i]
         L.f16o_init()
 
     @staticmethod
@@ -136,6 +152,58 @@ class COracle:
         self.lib.f16o_linearise_na(self._p(x_full), self._p(x9), self._p(u3), eps,
                                    self._p(A), self._p(B), self._p(C), self._p(D), fi_flag, xcg)
         return A, B, C, D
+
+    # ---- control chain in C (second checker + CPU baseline); mode 0 = admm_osqp_style, 1 = admm_osqp, 2 = admm_osqp with
+    # drop_unbounded_rows
+    def qp_settings(self, mode, **kw):
+        s = CQPSettings()
+        self.lib.f16o_qp_default_settings(ctypes.byref(s), mode)
+        for k, v in kw.items():
+            setattr(s, k, v)
+        return s
+
+    def c2d(self, A, B, dt):
+        A, B = np.ascontiguousarray(A, dtype=np.float64), np.ascontiguousarray(B, dtype=np.float64)
+        ns, ni = B.shape
+        Ad, Bd = np.zeros((ns, ns)), np.zeros((ns, ni))
+        self.lib.f16o_c2d(self._p(A), self._p(B), ns, ni, dt, self._p(Ad), self._p(Bd))
+        return Ad, Bd
+
+    def dare(self, A, B, Q):
+        A, B, Q = (np.ascontiguousarray(a, dtype=np.float64) for a in (A, B, Q))
+        X = np.zeros_like(A)
+        rc = self.lib.f16o_dare(self._p(A), self._p(B), self._p(Q), A.shape[0], B.shape[1], self._p(X))
+        assert rc == 0, rc
+        return X
+
+    def mpc_qp(self, x_full, Ad, Bd, Cd, hzn, dt, dem=(0.0, 0.0, 0.0)):
+        x_full, Ad, Bd, Cd = (np.ascontiguousarray(a, dtype=np.float64) for a in (x_full, Ad, Bd, Cd))
+        dem = np.ascontiguousarray(dem, dtype=np.float64)
+        n, m = 3 * hzn, 15 * hzn
+        P, q, A, l, u = np.zeros((n, n)), np.zeros(n), np.zeros((m, n)), np.zeros(m), np.zeros(m)
+        self.lib.f16o_mpc_qp(self._p(x_full), self._p(Ad), self._p(Bd), self._p(Cd), hzn, dt, self._p(dem), self._p(P), self._p(q),
+                             self._p(A), self._p(l), self._p(u))
+        return P, q, A, l, u
+
+    def admm(self, P, q, A, l, u, mode=1, **kw):
+        P, q, A, l, u = (np.ascontiguousarray(a, dtype=np.float64) for a in (P, q, A, l, u))
+        s = self.qp_settings(mode, **kw)
+        x, info = np.zeros(P.shape[0]), np.zeros(4)
+        st = self.lib.f16o_admm(P.shape[0], A.shape[0], self._p(P), self._p(q), self._p(A), self._p(l), self._p(u), ctypes.byref(s),
+                                mode, self._p(x), self._p(info))
+        return dict(x=x, iters=int(info[0]), r_prim=info[1], r_dual=info[2], rho=info[3], status=st, infeasible=st == 2)
+
+    def mpc_batch(self, x, hzn, dt=0.001, xcg=0.35, fi_flag=1, dem=None, mode=2, nthreads=1, **kw):
+        """calc_MPC_action for every row of x [B,18] on the CPU: linearise + ZOH + setup_OSQP + solve."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        B = x.shape[0]
+        s = self.qp_settings(mode, **kw)
+        u, it, st = np.zeros((B, 3)), np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        ipt = ctypes.POINTER(ctypes.c_int)
+        dm = np.ascontiguousarray(dem, dtype=np.float64) if dem is not None else None
+        self.lib.f16o_mpc_batch(self._p(x), B, hzn, dt, xcg, fi_flag, self._p(dm) if dm is not None else None, ctypes.byref(s), mode,
+                                self._p(u), it.ctypes.data_as(ipt), st.ctypes.data_as(ipt), nthreads)
+        return dict(u=u, iters=it, status=st)
 
     def linearise_full(self, x, u, eps=1e-5, fi_flag=1, xcg=0.25):
         x = np.ascontiguousarray(x, dtype=np.float64)
@@ -325,6 +393,124 @@ def admm_osqp_style(P, q, A, l, u, **kw):
     if infeasible:
         x = np.full(n, np.nan)
     return dict(x=x, y=yfull, z=z, iters=it, r_prim=rp, r_dual=rd, rho=rho, infeasible=infeasible)
+
+
+# ---- OSQP as the reference invokes it (env.py:420-422: osqp.OSQP().setup(P, q, A, l, u, max_iter=40000, verbose=True,
+# polish=False) -> every other setting at its default).  The package is absent (PyPI `osqp`, unpinned: README.md:11), so
+# this restates its PUBLISHED algorithm (Stellato et al. 2020 + the 0.6.x sources scaling.c / auxil.c / osqp.c as
+# summarised in SURVEY.md Appendix C): Ruiz equilibration (10 passes, D / E / c), rho = 0.1 with the per-row rho vector
+# (rho_min on rows without bounds, 1e3 rho on equality rows), sigma 1e-6, alpha 1.6, termination on UNSCALED residuals
+# every 25 iterations, adaptive rho from the SCALED residuals.  OSQP's default update interval is wall-clock based; the
+# deterministic stand-in is its own no-timer constant ADAPTIVE_RHO_FIXED = 100 iterations (`rho_every`).
+OSQP_INFTY, MIN_SCALING, MAX_SCALING = 1e30, 1e-4, 1e4
+RHO_MIN, RHO_MAX, RHO_TOL, RHO_EQ_OVER_RHO_INEQ = 1e-6, 1e6, 1e-4, 1e3
+OSQP_DEFAULTS = dict(rho=0.1, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, eps_prim_inf=1e-4, scaling=10,
+                     check_every=25, rho_every=100, adaptive_rho=True, adaptive_rho_tolerance=5.0, max_iter=40000)
+
+
+def _limit_scaling(v):
+    v = np.where(v < MIN_SCALING, 1.0, v)
+    return np.where(v > MAX_SCALING, MAX_SCALING, v)
+
+
+def osqp_scale(P, q, A, l, u, passes=10):
+    """scaling.c:scale_data -- returns (Ps, qs, As, ls, us, D, E, c) with Ps = c D P D, qs = c D q, As = E A D,
+    ls = E l, us = E u."""
+    n, m = P.shape[0], A.shape[0]
+    P, q, A = np.array(P, dtype=float), np.array(q, dtype=float), np.array(A, dtype=float)
+    D, E, c = np.ones(n), np.ones(m), 1.0
+    for _ in range(passes):
+        Dt = np.maximum(np.abs(P).max(axis=0), np.abs(A).max(axis=0) if m else 0.0)     # compute_inf_norm_cols_KKT
+        Et = np.abs(A).max(axis=1) if m else np.ones(0)
+        Dt, Et = 1.0 / np.sqrt(_limit_scaling(Dt)), 1.0 / np.sqrt(_limit_scaling(Et))
+        P = Dt[:, None] * P * Dt[None, :]
+        A = Et[:, None] * A * Dt[None, :]
+        q = Dt * q
+        D, E = D * Dt, E * Et
+        ct = float(_limit_scaling(np.abs(P).max(axis=0).mean()))                         # cost scaling
+        qn = float(_limit_scaling(np.abs(q).max()))
+        ct = 1.0 / max(ct, qn)
+        P, q, c = P * ct, q * ct, c * ct
+    return P, q, A, E * l, E * u, D, E, c
+
+
+def admm_osqp(P, q, A, l, u, drop_unbounded_rows=False, **kw):
+    """The solve of env.py:420-424 by the published OSQP algorithm (see the block comment above).
+    drop_unbounded_rows: rows with l = -inf and u = +inf take part in the equilibration (they are rows of A) but are then
+    left out of the iteration instead of being carried with rho_min = 1e-6 (their y stays 0 and A x - z stays 0 on them;
+    what is dropped is a 1e-6-weighted term of the KKT matrix) -- this is what the HIP kernels do.
+    Returns dict(x, y, iters, r_prim, r_dual (unscaled), rho, infeasible, D, E, c)."""
+    o = dict(OSQP_DEFAULTS)
+    o.update(kw)
+    l = np.maximum(np.asarray(l, dtype=float), -OSQP_INFTY)       # the Python wrapper clips +-inf to +-1e30
+    u = np.minimum(np.asarray(u, dtype=float), OSQP_INFTY)
+    n = P.shape[0]
+    if o["scaling"]:
+        Ps, qs, As, ls, us, D, E, c = osqp_scale(P, q, A, l, u, o["scaling"])
+    else:
+        Ps, qs, As, ls, us = np.array(P, float), np.array(q, float), np.array(A, float), l.copy(), u.copy()
+        D, E, c = np.ones(n), np.ones(A.shape[0]), 1.0
+    loose = (ls < -OSQP_INFTY * MIN_SCALING) & (us > OSQP_INFTY * MIN_SCALING)
+    keep = ~loose if drop_unbounded_rows else np.ones(len(ls), bool)
+    As, ls, us, Ek, loose_k = As[keep], ls[keep], us[keep], E[keep], loose[keep]
+    m = As.shape[0]
+    eq = (us - ls) < RHO_TOL
+    rho, sigma, alpha = float(o["rho"]), o["sigma"], o["alpha"]
+
+    def rho_vec(r):
+        return np.where(loose_k, RHO_MIN, np.where(eq, RHO_EQ_OVER_RHO_INEQ * r, r))
+
+    def factor(rv):
+        return scipy.linalg.cho_factor(Ps + sigma * np.eye(n) + As.T @ (rv[:, None] * As))
+
+    rv = rho_vec(rho)
+    cho = factor(rv)
+    x, z, y = np.zeros(n), np.zeros(m), np.zeros(m)
+    Einv, Dinv, cinv = 1.0 / Ek, 1.0 / D, 1.0 / c
+    it, rp, rd = 0, np.inf, np.inf
+    infeasible = converged = False
+    for it in range(1, o["max_iter"] + 1):
+        xt = scipy.linalg.cho_solve(cho, sigma * x - qs + As.T @ (rv * z - y))
+        zt = As @ xt
+        x = alpha * xt + (1 - alpha) * x
+        zr = alpha * zt + (1 - alpha) * z
+        z_new = np.clip(zr + y / rv, ls, us)
+        dy = rv * (zr - z_new)
+        y = y + dy
+        z = z_new
+        if it % o["check_every"] == 0 or it == o["max_iter"]:
+            Ax, Px, Aty = As @ x, Ps @ x, As.T @ y
+            rp = np.abs(Einv * (Ax - z)).max()                               # compute_pri_res (unscaled)
+            eps_p = o["eps_abs"] + o["eps_rel"] * max(np.abs(Einv * z).max(), np.abs(Einv * Ax).max())
+            rd = cinv * np.abs(Dinv * (Px + qs + Aty)).max()                 # compute_dua_res (unscaled)
+            eps_d = o["eps_abs"] + o["eps_rel"] * cinv * max(np.abs(Dinv * qs).max(), np.abs(Dinv * Aty).max(),
+                                                              np.abs(Dinv * Px).max())
+            if rp < eps_p and rd < eps_d:
+                converged = True
+                break
+            # is_primal_infeasible
+            ndy = np.abs(Ek * dy).max()
+            if ndy > o["eps_prim_inf"]:
+                supp = np.sum(us * np.maximum(dy, 0) + ls * np.minimum(dy, 0))
+                if supp < -o["eps_prim_inf"] * ndy and np.abs(Dinv * (As.T @ dy)).max() < o["eps_prim_inf"] * ndy:
+                    infeasible = True
+                    break
+            if o["adaptive_rho"] and it % o["rho_every"] == 0 and it < o["max_iter"]:
+                # compute_rho_estimate: SCALED residuals, normalised
+                pr = np.abs(Ax - z).max() / (max(np.abs(z).max(), np.abs(Ax).max()) + 1e-10)
+                dr = np.abs(Px + qs + Aty).max() / (max(np.abs(qs).max(), np.abs(Aty).max(), np.abs(Px).max()) + 1e-10)
+                new = min(max(rho * np.sqrt(pr / (dr + 1e-10)), RHO_MIN), RHO_MAX)
+                if new > rho * o["adaptive_rho_tolerance"] or new < rho / o["adaptive_rho_tolerance"]:
+                    rho = new
+                    rv = rho_vec(rho)
+                    cho = factor(rv)
+    yfull = np.zeros(len(keep))
+    yfull[keep] = cinv * Ek * y                                              # unscale_solution
+    xu = D * x
+    if infeasible:
+        xu = np.full(n, np.nan)
+    return dict(x=xu, y=yfull, iters=it, r_prim=rp, r_dual=rd, rho=rho, infeasible=infeasible, converged=converged,
+                D=D, E=E, c=c)
 
 
 def qp_exact(P, q, A, l, u, tol=1e-9, max_rounds=50):

@@ -37,8 +37,15 @@ def _worker_body(q):
     T, Bt = 5, 12
     full = torch.arange(T * 18 * Bt, dtype=torch.float64).reshape(T, 18, Bt)     # global trajectory, aircraft-major last
     lo, hi = fdist.shard_bounds(Bt, w, r)
-    got = fdist.all_gather_trajectories(full[:, :, lo:hi].contiguous())
+    mine = full[:, :, lo:hi].contiguous()
+    got = fdist.all_gather_trajectories(mine)
     ok = bool(torch.equal(got, full))
+    # chunked collation (two time samples per chunk + a ragged last chunk) and the copy-free [T,18,W,Bl] view
+    ok = ok and bool(torch.equal(fdist.all_gather_trajectories(mine, chunk_bytes=2 * 18 * Bt * 8), full))
+    view = fdist.all_gather_trajectories(mine, layout="ranks")
+    ok = ok and tuple(view.shape) == (T, 18, w, Bt // w) and not view.is_contiguous()
+    ok = ok and bool(torch.equal(view.reshape(T, 18, Bt), full))
+    ok = ok and bool(torch.equal(fdist.all_gather_trajectories(mine, total=Bt - 1), full[..., :Bt - 1]))
     mx = fdist.max_over_ranks(1.0 + r)
     sm = fdist.sum_over_ranks(10.0 * (r + 1))
     st = torch.zeros(4, dtype=torch.int32)
@@ -62,7 +69,39 @@ def test_allgather_collates_shards_in_global_order_world2():
         assert ok and mx == 2.0 and sm == 30.0 and orv == (16 | 128)
 
 
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher (RANK unset): the parent spawns two fresh rank processes, relays rank
+    0's JSON line and its exit status.  --dry-run keeps the kernels out so the launch path runs on a box without GPUs;
+    the same command line without --dry-run is what the driver's SCALE run uses."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["F16_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["requested_gpus"] == 2 and rec["allgather_ok"] and rec["backend"] == "gloo"
+    assert rec["max_over_ranks"] == 2.0
+
+
+def test_bench_parent_propagates_a_rank_failure():
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["F16_DIST_BACKEND"] = "no-such-backend"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 def test_single_process_paths_need_no_group():
     t = torch.zeros(3, 18, 4, dtype=torch.float64)
     assert fdist.all_gather_trajectories(t) is t
+    assert tuple(fdist.all_gather_trajectories(t, layout="ranks").shape) == (3, 18, 1, 4)
     assert fdist.max_over_ranks(3.5) == 3.5 and fdist.world_size() == 1

@@ -33,7 +33,13 @@ def test_linearise_c2d_lqr_vs_reference(xcg):
     g = golden("g567_trim_lin_lqr.npz")
     x = np.tile(g[f"trim_x_xcg{xcg}"], (3, 1))
     env = make_env(x, xcg=xcg / 100)
-    Ac, Bc, Cc, Dc = (t.cpu().numpy() for t in env.linearise())
+    # the reference's own call shape (env.py:49): linearise(x9, u3, _calc_xdot=_calc_xdot_na, get_obs=_get_obs_na)
+    Ac, Bc, Cc, Dc = (t.cpu().numpy() for t in env.linearise(env._get_mpc_x(), env._get_mpc_u(), _calc_xdot=env._calc_xdot_na,
+                                                              get_obs=env._get_obs_na))
+    A18 = env.linearise(env.x_values, env.u_values)[0].cpu().numpy()          # env.py:45: the default is the 18-state model
+    np.testing.assert_allclose(A18[1], g[f"A18_xcg{xcg}"], rtol=0, atol=2e-6)
+    with pytest.raises(ValueError):
+        env.linearise(env.x_values, env.u_values, _calc_xdot=lambda x, u: x)
     for b in range(3):
         np.testing.assert_allclose(Ac[b], g[f"ssr_Ac_xcg{xcg}"], rtol=0, atol=1e-6)
         np.testing.assert_allclose(Bc[b], g[f"ssr_Bc_xcg{xcg}"], rtol=0, atol=1e-6)
@@ -389,3 +395,159 @@ def test_dispatch_order_does_not_change_results(monkeypatch):
     assert len(set(i1["iters"].cpu().numpy().tolist())) > 1                     # a mix of iteration counts to order
     for u, i in ((u2, i2), (u3, i3)):
         assert torch.equal(u, u1) and torch.equal(i["iters"], i1["iters"]) and torch.equal(i["u_seq"], i1["u_seq"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round-2 additions: oracle-checked horizons, closed loop, re-linearised loop, config-3 LQR sample
+def _model_np(env):
+    Ad, Bd, Cd = env.ssr
+    return (Ad.t().cpu().numpy().reshape(-1, 9, 9), Bd.t().cpu().numpy().reshape(-1, 9, 3), Cd.t().cpu().numpy().reshape(-1, 9, 9))
+
+
+HORIZONS = [1, 2, 5, 6, 11, 16, 21, 22, 32, 33, 40]
+
+
+@pytest.mark.parametrize("generic", [False, True])
+def test_every_horizon_instantiation_vs_same_algorithm_oracle(generic):
+    """Regression for the round-1 abort: every N in 1..40 once through the solver that owns it -- the
+    register-resident kernel instantiations k_mpc_fast<2> (N <= 5), <4> (N <= 10), <6> (N <= 32, incl. the padded tile
+    counts at N = 6, 11, 22) and the generic one-wave kernel (N = 33..40; forced for every N when `generic`) -- with
+    status / finiteness for all N and iterate-level parity against mo.admm_osqp_style at the listed horizons."""
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(8, seed=21)
+    env = make_env(x0, u0, xcg=0.35)
+    env.build_ssr()
+    Ad, Bd, Cd = _model_np(env)
+    dem = (0.02, -0.01, 0.01)
+    sett = dict(max_iter=-40000) if generic else None
+    for N in range(1, 41):
+        u, info = env._calc_MPC_action(*dem, N, settings=sett, return_info=True)
+        torch.cuda.synchronize()
+        assert torch.isfinite(u).all() and int(info["status"].max()) == 0, N
+        assert tuple(info["u_seq"].shape) == (8, 3 * N)
+        if N in HORIZONS:
+            for b in (0, 5):
+                P, q, A, l, uu = mo.mpc_qp(x0[b], Ad[b], Bd[b], Cd[b], N, 0.001, *dem)
+                ref = mo.admm_osqp_style(P, q, A, l, uu)
+                assert int(info["iters"][b]) == ref["iters"], (N, b)
+                assert np.abs(info["u_seq"][b].cpu().numpy() - ref["x"]).max() < 1e-6, (N, b)
+    from f16_mpc_oop_py_amd import lib
+    with pytest.raises(lib.F16HipError):
+        env._calc_MPC_action(0, 0, 0, 41)
+    with pytest.raises(lib.F16HipError):
+        env._calc_MPC_action(0, 0, 0, 0)
+
+
+def _oracle_closed_loop(oracle, x0, u0, Ad, Bd, Cd, steps, N, dem, relin, solver):
+    """test_env.py:480-495 on the CPU: cmd = calc_MPC_action(p, q, r, N); u.values[1:] = cmd; step(u.values)."""
+    x, u = x0.copy(), u0.copy()
+    its, cmds = [], []
+    for _ in range(steps):
+        if relin:
+            A_, B_, C_, D_ = oracle.linearise_na(x, u3=u[1:], xcg=0.35)
+            Ad, Bd, Cd, _ = mo.c2d(A_, B_, C_, D_, 0.001)
+        P, q, A, l, uu = mo.mpc_qp(x, Ad, Bd, Cd, N, 0.001, *dem)
+        r = solver(P, q, A, l, uu)
+        its.append(r["iters"])
+        cmds.append(r["x"][:3].copy())
+        u[1:4] = r["x"][:3]
+        x, _, st = oracle.rollout(x[None], u[None], 1, xcg=0.35, store=False)
+        x = x[0]
+        assert st[0] == 0
+    return x, np.array(cmds), np.array(its)
+
+
+def test_closed_loop_mpc_vs_oracle_loop(oracle):
+    """BASELINE config 5 workload on one rank against the same loop on the CPU oracle (reference pattern
+    test_env.py:480-495): 16 config-4 aircraft, 20 steps of calc_MPC_action(N = 30) + step -- commands <= 1e-4, states
+    <= 1e-6 relative, the same iteration counts -- through one-shot calls and through a prepared plan."""
+    from f16_mpc_oop_py_amd.workload import config4_states
+    B, N, steps = 16, 30, 20
+    x0, u0 = config4_states(B, seed=5)
+    dem = (0.02, -0.01, 0.0)
+    runs = {}
+    for use_plan in (False, True):
+        env = make_env(x0, u0, xcg=0.35)
+        env.build_ssr()
+        cmds, its = [], []
+        for _ in range(steps):
+            cmd, info = env._calc_MPC_action(*dem, N, return_info=True, use_plan=use_plan)
+            assert int(info["status"].max()) == 0
+            cmds.append(cmd.cpu().numpy().copy()); its.append(info["iters"].cpu().numpy().copy())
+            env._u[1:4] = cmd.t()
+            env.step()
+        runs[use_plan] = (env.x_values.cpu().numpy(), np.array(cmds), np.array(its), _model_np(env))
+    assert np.array_equal(runs[False][1], runs[True][1])               # plan = one-shot, bit for bit
+    xg, cg, ig, (Ad, Bd, Cd) = runs[False]
+    for b in (0, 3, 7, 12):
+        xr, cr, ir = _oracle_closed_loop(oracle, x0[b], u0[b], Ad[b], Bd[b], Cd[b], steps, N, dem, False, mo.admm_osqp_style)
+        assert np.array_equal(ig[:, b], ir), (b, ig[:, b], ir)
+        assert np.abs(cg[:, b] - cr).max() < 1e-4
+        assert np.max(np.abs(xg[b] - xr) / np.maximum(1.0, np.abs(xr))) < 1e-6
+
+
+def test_relinearised_closed_loop_vs_oracle_loop(oracle):
+    """SURVEY.md 8f-2 (pattern of test_env.py:625-687): the reduced model re-derived at the CURRENT state before every
+    solve, against oracle.linearise_na + mo.c2d + the same QP + solve on the CPU.  A, B come from forward differences
+    with eps 1e-5 (device trigonometry differs from libm in the last ulps, amplified 1e5), hence the looser bands."""
+    from f16_mpc_oop_py_amd.workload import config4_states
+    B, N, steps = 8, 10, 12
+    x0, u0 = config4_states(B, seed=9)
+    dem = (0.03, 0.0, -0.01)
+    env = make_env(x0, u0, xcg=0.35)
+    cmds, its = [], []
+    for k in range(steps):
+        cmd, info = env._calc_MPC_action(*dem, N, return_info=True, relinearise=True)
+        assert int(info["status"].max()) == 0
+        cmds.append(cmd.cpu().numpy().copy()); its.append(info["iters"].cpu().numpy().copy())
+        if k == steps - 1:                                              # the model of the LAST solve, at the moved state
+            Ad, Bd, Cd = _model_np(env)
+            xk, uk = env.x_values.cpu().numpy().copy(), env.u_values.cpu().numpy().copy()
+        env._u[1:4] = cmd.t()
+        env.step()
+    cmds, its = np.array(cmds), np.array(its)
+    xg = env.x_values.cpu().numpy()
+    for b in (0, 2, 5):
+        A_, B_, C_, D_ = oracle.linearise_na(xk[b], u3=uk[b, 1:], xcg=0.35)       # re-linearised AFTER the state moved
+        Ado, Bdo, _, _ = mo.c2d(A_, B_, C_, D_, 0.001)
+        np.testing.assert_allclose(Ad[b], Ado, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(Bd[b], Bdo, rtol=0, atol=1e-9)
+        xr, cr, ir = _oracle_closed_loop(oracle, x0[b], u0[b], None, None, None, steps, N, dem, True, mo.admm_osqp_style)
+        assert np.abs(its[:, b] - ir).max() <= 25                                   # a test interval at most (knife edges)
+        assert np.abs(cmds[:, b] - cr).max() < 2e-3
+        assert np.max(np.abs(xg[b] - xr) / np.maximum(1.0, np.abs(xr))) < 1e-5
+    # frozen vs re-linearised differ once the state has moved (the re-derivation is not a no-op)
+    env2 = make_env(x0, u0, xcg=0.35)
+    env2.build_ssr()
+    env2.rollout(200)
+    fr = env2._calc_MPC_action(*dem, N).clone()
+    rl = env2._calc_MPC_action(*dem, N, relinearise=True)
+    assert float((fr - rl).abs().max()) > 1e-6
+
+
+def test_lqr_gain_on_config3_workload_sample(oracle):
+    """BASELINE config 3 at full size (4096 perturbed flight conditions, xcg 0.25): linearise + ZOH + dlqr per aircraft;
+    a 64-aircraft sample against env.py:344-358 restated on the CPU (oracle.linearise_na + scipy cont2discrete + scipy
+    solve_discrete_are), K <= 1e-6 relative; the DARE kernel alone on the device's own discrete model <= 1e-8."""
+    import scipy.linalg
+    from f16_mpc_oop_py_amd.workload import config2_states
+    from f16_mpc_oop_py_amd.env import _vp
+    B = 4096
+    x0, u0 = config2_states(B)
+    env = make_env(x0, u0, xcg=0.25)
+    K = env._calc_LQR_gain().cpu().numpy()
+    assert np.isfinite(K).all() and int(env.last_status.max()) == 0
+    Ad, Bd, Cd = _model_np(env)
+    Pare = torch.empty((81, B), dtype=torch.float64, device="cuda:0")
+    Kd = torch.empty((27, B), dtype=torch.float64, device="cuda:0")
+    st = torch.zeros(B, dtype=torch.int32, device="cuda:0")
+    assert env.lib.f16_lqr_batch(env.ctx.handle, _vp(env.ssr[0]), _vp(env.ssr[1]), _vp(env.ssr[2]), _vp(Kd), _vp(Pare), _vp(st), B, B, None) == 0
+    Xg = Pare.t().cpu().numpy().reshape(B, 9, 9)
+    worst_k, worst_x = 0.0, 0.0
+    for b in range(0, B, 64):
+        Kref = mo.lqr_gain_from_linearisation(*oracle.linearise_na(x0[b], u3=u0[b, 1:], xcg=0.25), 0.001)
+        worst_k = max(worst_k, np.abs(K[b] - Kref).max() / np.abs(Kref).max())
+        Xref = scipy.linalg.solve_discrete_are(Ad[b], Bd[b], Cd[b].T @ Cd[b], np.eye(3))
+        worst_x = max(worst_x, np.abs(Xg[b] - Xref).max() / np.abs(Xref).max())
+    assert worst_x < 1e-8, worst_x
+    assert worst_k < 1e-6, worst_k
