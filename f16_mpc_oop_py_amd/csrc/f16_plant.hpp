@@ -154,7 +154,9 @@ F16_DEV Axis br_axis(const BrCell &c) {                          // lambda = (v 
   Axis a;
   a.j = c.j;
 #ifdef F16_FAST_DIV
-  a.l = (c.v - c.x0) * f16_rcp(c.x1 - c.x0);
+  // (the Newton-refined reciprocal is <= 1 ulp off 1/d, so d * rcp(d) need not be exactly 1: a hit on the LAST node of an
+  //  axis -- the only node reached as the upper end of a cell -- is pinned, every other node gives lambda = 0 by itself)
+  a.l = c.v == c.x1 ? 1.0 : (c.v - c.x0) * f16_rcp(c.x1 - c.x0);
 #else
   a.l = (c.v - c.x0) / (c.x1 - c.x0);
 #endif

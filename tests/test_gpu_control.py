@@ -423,14 +423,20 @@ def test_every_horizon_instantiation_vs_same_algorithm_oracle(generic):
     for N in range(1, 41):
         u, info = env._calc_MPC_action(*dem, N, settings=sett, return_info=True)
         torch.cuda.synchronize()
-        assert torch.isfinite(u).all() and int(info["status"].max()) == 0, N
+        st = info["status"].cpu().numpy()
+        fin = torch.isfinite(u).all(dim=1).cpu().numpy()
+        # a long horizon can make an aircraft's QP infeasible (its linear model leaves the state box): OSQP's certificate
+        # -> status bit 128 and a NaN command, exactly for those aircraft
+        assert set(np.unique(st)) <= {0, 128} and np.array_equal(fin, st == 0), (N, st)
         assert tuple(info["u_seq"].shape) == (8, 3 * N)
         if N in HORIZONS:
-            for b in (0, 5):
+            for b in (0, 2, 5):
                 P, q, A, l, uu = mo.mpc_qp(x0[b], Ad[b], Bd[b], Cd[b], N, 0.001, *dem)
                 ref = mo.admm_osqp_style(P, q, A, l, uu)
                 assert int(info["iters"][b]) == ref["iters"], (N, b)
-                assert np.abs(info["u_seq"][b].cpu().numpy() - ref["x"]).max() < 1e-6, (N, b)
+                assert bool(ref["infeasible"]) == (st[b] == 128), (N, b)
+                if not ref["infeasible"]:
+                    assert np.abs(info["u_seq"][b].cpu().numpy() - ref["x"]).max() < 1e-6, (N, b)
     from f16_mpc_oop_py_amd import lib
     with pytest.raises(lib.F16HipError):
         env._calc_MPC_action(0, 0, 0, 41)
