@@ -475,8 +475,10 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
   double *x9 = al.take(9), *xref = al.take(9);
   double *qv, *wbuf, *pred;           // q | QQ (x_ref - MM x) | MM x: A^(i+1) x
   double *xs = nullptr, *xt = nullptr, *rhs = nullptr, *tv = nullptr;      // generic solver only
+  double *Dg = nullptr, *E9 = nullptr, *Ec = nullptr, *Er = nullptr;       // generic solver: equilibration, then Gram weights
   if (SETUP_ONLY) { pred = Minv; wbuf = Minv + 9 * N; qv = Minv + 18 * N; }      // 21 N <= 840 < 1100
-  else { qv = al.take(n); wbuf = al.take(m); pred = al.take(9 * N); xs = al.take(n); xt = al.take(n); rhs = al.take(n); tv = al.take(n); }
+  else { qv = al.take(n); wbuf = al.take(m); pred = al.take(9 * N); xs = al.take(n); xt = al.take(n); rhs = al.take(n); tv = al.take(n);
+         Dg = al.take(n); E9 = al.take(9 * N); Ec = al.take(n); Er = al.take(n + 3); }
   double *scr = Minv, *X = Minv + 760;                  // DARE scratch (748 doubles), then X (82)
 
 #ifdef F16_EXP_STAMPB
@@ -574,21 +576,21 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
     __threadfence_block();
     __syncthreads();
     BSTAMP(4)
-    // ---------------- P = 2 (CC' QQ CC + RR) and A'A = CCs'CCs + I + D'D, packed lower, to the workspace.
+    // ---------------- P = 2 (CC' QQ CC + RR), packed lower, to the workspace.  (A'A is no longer formed here: the solvers
+    // need the row-WEIGHTED Gram A'WA of the equilibrated problem, which has no Toeplitz recursion, and build it themselves.)
     // Block (j,l), j >= l, d = j-l:  T(j,l) = TQ(j,l) + G'_{N-1-j} Qbar G_{N-1-l},
-    //   TQ(j,l) = TQ(j+1,l+1) + G'_{N-2-j} Q G_{N-2-l} (0 beyond N-2),  TS likewise with S'S and all i <= N-1.
+    //   TQ(j,l) = TQ(j+1,l+1) + G'_{N-2-j} Q G_{N-2-l} (0 beyond N-2).
     // One chain per (diagonal d, element (ra,cb)), up to MAXCH per lane; all chains walk j together, so the two weighted
     // blocks a step needs (Q G_{N-2-j}, Qbar G_{N-1-j}) are the same for every lane and are formed once per step (jit).
     // This loop is LDS-bandwidth-bound (42 operand reads for 24 FMAs per chain element).  Tried and dropped: one lane per
     // block diagonal (216 FMAs for 27 + 72 reads per step, running sums in registers, no jit broadcast conflicts) --
     // fewer LDS bytes but only N active lanes and as many address computations for the packed stores: 20 % slower.
-    double *Pg = a.Ppk + (size_t)b * np, *Ag = a.Apk + (size_t)b * np;
+    double *Pg = a.Ppk + (size_t)b * np;
     if (!update_only) {
       constexpr int MAXCH = (9 * MAXN + F16_WAVE - 1) / F16_WAVE;
-      constexpr int SR[6] = {2, 3, 4, 5, 6, 8};                            // = SROW at compile time: the S'S operands
-      double tq[MAXCH], ts[MAXCH];                                         // below are six of the nine just read
+      double tq[MAXCH];
 #pragma unroll
-      for (int t = 0; t < MAXCH; ++t) { tq[t] = 0.0; ts[t] = 0.0; }
+      for (int t = 0; t < MAXCH; ++t) tq[t] = 0.0;
       const int wh = l >= 27 ? 1 : 0, je = l - 27 * wh, jr = je / 3, jc = je - 3 * jr;      // jit roles of lanes 0..53
       const double *Qw = wh ? Qb : Q;
       __syncthreads();
@@ -617,21 +619,11 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
             double gc[9];
 #pragma unroll
             for (int p = 0; p < 9; ++p) gc[p] = G[(N - 1 - lcol) * 27 + p * 3 + cb];
-            double sb = 0.0, ss = 0.0;
+            double sb = 0.0;
 #pragma unroll
             for (int p = 0; p < 9; ++p) sb += QbGk[p * 3 + ra] * gc[p];
-#pragma unroll
-            for (int rr = 0; rr < 6; ++rr) ss += G[(N - 1 - j) * 27 + SR[rr] * 3 + ra] * gc[SR[rr]];
-            ts[t] += ss;
             const int gi = 3 * j + ra, gj = 3 * lcol + cb;
-            if (gi >= gj) {
-              double pv = 2.0 * (tq[t] + sb + ((gi == gj) ? 1.0 : 0.0));      // RR = I (env.py:405-407)
-              double av = ts[t];
-              if (gi == gj) av += 1.0 + ((j < N - 1) ? 2.0 : 1.0);         // I'I + D'D diagonal
-              if (d == 1 && ra == cb) av += -1.0;                          // D'D sub-diagonal block -I
-              Pg[tri(gi, gj)] = pv;
-              Ag[tri(gi, gj)] = av;
-            }
+            if (gi >= gj) Pg[tri(gi, gj)] = 2.0 * (tq[t] + sb + ((gi == gj) ? 1.0 : 0.0));      // RR = I (env.py:405-407)
           }
         }
         __syncthreads();                                                    // jit is rewritten by the next step
@@ -674,23 +666,105 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
     if (SETUP_ONLY && a.useq && l == 0) for (int i = 0; i < 7; ++i) { a.useq[i * a.ld + b] = (double)tB[i]; tB[i] = 0; }
 #endif
     if (SETUP_ONLY) { __syncthreads(); continue; }
-    // ---------------- ADMM (OSQP Algorithm 1, reduced dense form; settings a.s)
-    double rho = a.s.rho;
-    if (!(rho > 0.0)) {   // automatic: balance the two terms of P + rho A'A
-      __syncthreads();
-      double tp = 0.0, ta = 0.0;
-      for (int e = l; e < n; e += F16_WAVE) { tp += Pg[tri(e, e)]; ta += Ag[tri(e, e)]; }
-      rho = fmin(fmax(RHO_AUTO_SCALE * sqrt(wave_sum(tp) / wave_sum(ta)), 1e-6), 1e6);
-    }
+    // ---------------- the solve (the published OSQP algorithm; same coordinates as f16_mpc_solve.hip:
+    // x stays unscaled, the linear system is (c P + sigma D^-2 + rho A'WA) x~ = sigma D^-2 x - c q + A' E (rho zb - yb))
     const double sigma = a.s.sigma, alpha = a.s.alpha;
-    auto build_minv = [&](double r) {
+    double cs = 1.0;
+    for (int e = l; e < n; e += F16_WAVE) { Dg[e] = 1.0; Ec[e] = 1.0; Er[e] = 1.0; }
+    for (int e = l; e < 3; e += F16_WAVE) Er[n + e] = 0.0;
+    for (int e = l; e < 9 * N; e += F16_WAVE) E9[e] = 1.0;
+    __syncthreads();
+    for (int pass = 0; pass < a.s.scaling; ++pass) {     // scaling.c:scale_data on the original entries and the running D, E, c
+      for (int e = l; e < n; e += F16_WAVE) {            // column norms of [Pb; Ab]
+        const int jb = e / 3, c = e - 3 * jb;
+        double mp = 0.0, ma = 0.0;
+        for (int i = 0; i < n; ++i) mp = fmax(mp, fabs(Pg[i >= e ? tri(i, e) : tri(e, i)]) * Dg[i]);
+        for (int i = jb; i < N; ++i)
+          for (int r = 0; r < 9; ++r) ma = fmax(ma, fabs(G[(i - jb) * 27 + r * 3 + c]) * E9[9 * i + r]);
+        ma = fmax(fmax(ma, Ec[e]), fmax(Er[e], Er[e + 3]));
+        tv[e] = 1.0 / sqrt(osqp_limit_scaling(Dg[e] * fmax(cs * mp, ma)));
+      }
+      for (int e = l; e < 9 * N; e += F16_WAVE) {        // row norms of the state block
+        const int i = e / 9, r = e - 9 * i;
+        double m_ = 0.0;
+        for (int jb = 0; jb <= i; ++jb)
+          for (int c = 0; c < 3; ++c) m_ = fmax(m_, fabs(G[(i - jb) * 27 + r * 3 + c]) * Dg[3 * jb + c]);
+        wbuf[e] = 1.0 / sqrt(osqp_limit_scaling(E9[e] * m_));          // (m = 12N >= 9N)
+      }
+      for (int e = l; e < n; e += F16_WAVE) {
+        rhs[e] = 1.0 / sqrt(osqp_limit_scaling(Ec[e] * Dg[e]));
+        xt[e] = 1.0 / sqrt(osqp_limit_scaling(Er[e] * fmax(Dg[e], e >= 3 ? Dg[e - 3] : 0.0)));
+      }
       __syncthreads();
-      for (int e = l; e < np; e += F16_WAVE) Minv[e] = Pg[e] + r * Ag[e];
+      for (int e = l; e < n; e += F16_WAVE) { Dg[e] *= tv[e]; Ec[e] *= rhs[e]; Er[e] *= xt[e]; }
+      for (int e = l; e < 9 * N; e += F16_WAVE) E9[e] *= wbuf[e];
       __syncthreads();
-      for (int e = l; e < n; e += F16_WAVE) Minv[tri(e, e)] += sigma;
+      double sm = 0.0, qn = 0.0;                          // cost scaling: mean column norm of Pb, ||qb||
+      for (int e = l; e < n; e += F16_WAVE) {
+        double mp = 0.0;
+        for (int i = 0; i < n; ++i) mp = fmax(mp, fabs(Pg[i >= e ? tri(i, e) : tri(e, i)]) * Dg[i]);
+        sm += cs * Dg[e] * mp;
+        qn = fmax(qn, cs * Dg[e] * fabs(qv[e]));
+      }
+      sm = wave_sum(sm); qn = wave_max(qn);
+      cs *= 1.0 / fmax(osqp_limit_scaling(sm / n), osqp_limit_scaling(qn));
+      __syncthreads();
+    }
+    // per-row E, scaled bounds, rho-vector factor and Gram weight of the kept rows; sigma D^-2 per variable
+    double Eo[MAXT], eqf[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int row = l + 64 * t;
+      Eo[t] = 1.0; eqf[t] = 1.0;
+      if (row < m) {
+        Eo[t] = row < ms ? E9[9 * (row / 6) + SROW[row % 6]] : (row < ms + n ? Ec[row - ms] : Er[row - ms - n]);
+        lo[t] *= Eo[t]; hi[t] *= Eo[t];
+        eqf[t] = (hi[t] - lo[t] < OSQP_RHO_TOL) ? OSQP_RHO_EQ_OVER_RHO_INEQ : 1.0;
+      }
+    }
+    __syncthreads();                                      // E9 / Ec / Er are read; they now become the Gram weights W
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int row = l + 64 * t;
+      if (row < ms) E9[9 * (row / 6) + SROW[row % 6]] = Eo[t] * Eo[t] * eqf[t];
+      else if (row < ms + n) Ec[row - ms] = Eo[t] * Eo[t] * eqf[t];
+      else if (row < m) Er[row - ms - n] = Eo[t] * Eo[t] * eqf[t];
+    }
+    for (int e = l; e < n; e += F16_WAVE) Dg[e] = sigma / (Dg[e] * Dg[e]);     // Dg <- sigma D^-2  (c D of the rho estimate: sqrt back)
+    __syncthreads();
+    const double cinv = 1.0 / cs;
+    auto build_minv = [&](double r) {                     // Minv <- (c P + sigma D^-2 + r A'WA)^-1, packed
+      __syncthreads();
+      for (int e = l; e < np; e += F16_WAVE) {
+        int ia = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while (tri(ia + 1, 0) <= e) ++ia;
+        while (tri(ia, 0) > e) --ia;
+        const int ib = e - tri(ia, 0), ja = ia / 3, ca = ia - 3 * ja, jb = ib / 3, cb = ib - 3 * jb;
+        double s = 0.0;
+        for (int i = ja; i < N; ++i) {
+          const double *ga = G + (i - ja) * 27 + ca, *gb = G + (i - jb) * 27 + cb, *wv = E9 + 9 * i;
+#pragma unroll
+          for (int rr = 0; rr < 6; ++rr) s += wv[SROW[rr]] * ga[SROW[rr] * 3] * gb[SROW[rr] * 3];
+        }
+        if (ia == ib) s += Ec[ia] + Er[ia] + Er[ia + 3];
+        else if (ia == ib + 3) s -= Er[ia];
+        Minv[e] = cs * Pg[e] + r * s + (ia == ib ? Dg[ia] : 0.0);
+      }
       __syncthreads();
       return spd_inverse_packed(Minv, n, tv);
     };
+    double rho = a.s.rho;
+    if (!(rho > 0.0)) {   // the builder's opt-in start value (no equilibration): balance the two terms of P + rho A'A
+      double tp = 0.0, ta = 0.0;
+      for (int e = l; e < n; e += F16_WAVE) {
+        const int jb = e / 3, c = e - 3 * jb;
+        double s = Ec[e] + Er[e] + Er[e + 3];
+        for (int i = jb; i < N; ++i)
+          for (int rr = 0; rr < 6; ++rr) { const double gv = G[(i - jb) * 27 + SROW[rr] * 3 + c]; s += E9[9 * i + SROW[rr]] * gv * gv; }
+        tp += Pg[tri(e, e)]; ta += s;
+      }
+      rho = fmin(fmax(RHO_AUTO_SCALE * sqrt(wave_sum(tp) / wave_sum(ta)), OSQP_RHO_MIN), OSQP_RHO_MAX);
+    }
     bool ok = build_minv(rho);
     for (int e = l; e < n; e += F16_WAVE) xs[e] = 0.0;
     __syncthreads();
@@ -698,23 +772,23 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
     double rp = INFINITY, rd = INFINITY;
     bool converged = false, infeasible = false;
     bool done = !ok || a.s.max_iter <= 0;
+    auto adjoint = [&](const double *wv_, int e) {          // (A' w)_e for w in the [6N | 3N | 3N] layout, tv = CCs' w_s
+      return tv[e] + wv_[ms + e] + (wv_[ms + n + e] - (e + 3 < n ? wv_[ms + n + e + 3] : 0.0));
+    };
     while (!done) {
       ++it;
-      // w = rho z - y -> t = A' w ; rhs = sigma x - q + t
+      // w = E (rho zb - yb) -> t = A' w ; rhs = sigma D^-2 x - c q + t
 #pragma unroll
       for (int t = 0; t < MAXT; ++t) {
         const int row = l + 64 * t;
-        if (row < m) wbuf[row] = rho * z[t] - y[t];
+        if (row < m) wbuf[row] = Eo[t] * (rho * eqf[t] * z[t] - y[t]);
       }
       __syncthreads();
       conv_adjoint<6>(tv, G, wbuf, N, SROW);
-      for (int e = l; e < n; e += F16_WAVE) {
-        const double wr = wbuf[ms + n + e] - (e + 3 < n ? wbuf[ms + n + e + 3] : 0.0);
-        rhs[e] = sigma * xs[e] - qv[e] + (tv[e] + wbuf[ms + e] + wr);
-      }
+      for (int e = l; e < n; e += F16_WAVE) rhs[e] = Dg[e] * xs[e] - cs * qv[e] + adjoint(wbuf, e);
       __syncthreads();
-      symv(xt, Minv, rhs, n);                               // x~ = (P + sigma I + rho A'A)^-1 rhs
-      // z~ = A x~ ; relaxation, projection, dual update
+      symv(xt, Minv, rhs, n);                               // x~
+      // zb~ = E A x~ ; relaxation, projection, dual update
 #pragma unroll
       for (int t = 0; t < MAXT; ++t) {
         const int row = l + 64 * t;
@@ -723,9 +797,11 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
           if (row < ms) zt = conv_forward_row(G, xt, row / 6, SROW[row % 6]);
           else if (row < ms + n) zt = xt[row - ms];
           else { const int k = row - ms - n; zt = xt[k] - (k >= 3 ? xt[k - 3] : 0.0); }
+          zt *= Eo[t];
+          const double ro = rho * eqf[t];
           const double zr = alpha * zt + (1 - alpha) * z[t];
-          const double zn = fmin(fmax(zr + y[t] / rho, lo[t]), hi[t]);
-          dy[t] = rho * (zr - zn);
+          const double zn = fmin(fmax(zr + y[t] / ro, lo[t]), hi[t]);
+          dy[t] = ro * (zr - zn);
           y[t] = y[t] + dy[t];
           z[t] = zn;
         }
@@ -733,8 +809,8 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
       for (int e = l; e < n; e += F16_WAVE) xs[e] = alpha * xt[e] + (1 - alpha) * xs[e];
       __syncthreads();
       if (it % a.s.check_every == 0 || it >= a.s.max_iter) {
-        // residuals (OSQP termination test)
-        double r1 = 0.0, nAx = 0.0, nz = 0.0;
+        // residuals of the UNSCALED problem (OSQP termination test) + the scaled ones for the rho estimate
+        double r1 = 0.0, nAx = 0.0, nz = 0.0, r1s = 0.0, nAxs = 0.0, nzs = 0.0;
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
           const int row = l + 64 * t;
@@ -743,40 +819,37 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
             if (row < ms) ax = conv_forward_row(G, xs, row / 6, SROW[row % 6]);
             else if (row < ms + n) ax = xs[row - ms];
             else { const int k = row - ms - n; ax = xs[k] - (k >= 3 ? xs[k - 3] : 0.0); }
-            r1 = fmax(r1, fabs(ax - z[t]));
-            nAx = fmax(nAx, fabs(ax));
-            nz = fmax(nz, fabs(z[t]));
-            wbuf[row] = y[t];
+            const double zu = z[t] / Eo[t];
+            r1 = fmax(r1, fabs(ax - zu)); nAx = fmax(nAx, fabs(ax)); nz = fmax(nz, fabs(zu));
+            r1s = fmax(r1s, fabs(Eo[t] * ax - z[t])); nAxs = fmax(nAxs, fabs(Eo[t] * ax)); nzs = fmax(nzs, fabs(z[t]));
+            wbuf[row] = Eo[t] * y[t];
           }
         }
         __syncthreads();
         symv(xt, Pg, xs, n);                                // P x (packed P from the workspace)
         conv_adjoint<6>(tv, G, wbuf, N, SROW);
-        double r2 = 0.0, nPx = 0.0, nAty = 0.0, nq = 0.0;
+        double r2 = 0.0, nPx = 0.0, nAty = 0.0, nq = 0.0, r2s = 0.0, nPxs = 0.0, nAtys = 0.0, nqs = 0.0;
         for (int e = l; e < n; e += F16_WAVE) {
-          const double aty = tv[e] + wbuf[ms + e] + (wbuf[ms + n + e] - (e + 3 < n ? wbuf[ms + n + e + 3] : 0.0));
-          r2 = fmax(r2, fabs(xt[e] + qv[e] + aty));
-          nPx = fmax(nPx, fabs(xt[e]));
-          nAty = fmax(nAty, fabs(aty));
-          nq = fmax(nq, fabs(qv[e]));
+          const double aty = cinv * adjoint(wbuf, e), rr_ = xt[e] + qv[e] + aty, cD = cs * sqrt(sigma / Dg[e]);
+          r2 = fmax(r2, fabs(rr_)); nPx = fmax(nPx, fabs(xt[e])); nAty = fmax(nAty, fabs(aty)); nq = fmax(nq, fabs(qv[e]));
+          r2s = fmax(r2s, cD * fabs(rr_)); nPxs = fmax(nPxs, cD * fabs(xt[e])); nAtys = fmax(nAtys, cD * fabs(aty)); nqs = fmax(nqs, cD * fabs(qv[e]));
         }
         rp = wave_max(r1);
         rd = wave_max(r2);
         const double np_ = fmax(wave_max(nAx), wave_max(nz));
         const double nd_ = fmax(fmax(wave_max(nPx), wave_max(nAty)), wave_max(nq));
         __syncthreads();
-        if (rp <= a.s.eps_abs + a.s.eps_rel * np_ && rd <= a.s.eps_abs + a.s.eps_rel * nd_) { done = true; converged = true; }
+        if (rp < a.s.eps_abs + a.s.eps_rel * np_ && rd < a.s.eps_abs + a.s.eps_rel * nd_) { done = true; converged = true; }
         else {
-          // OSQP primal-infeasibility certificate on dy = y_k - y_{k-1}: ||A'dy|| <= eps ||dy|| and
-          // u'(dy)+ + l'(dy)- <= -eps ||dy||  (all kept rows have finite bounds)
+          // OSQP primal-infeasibility certificate on dy (auxil.c:is_primal_infeasible)
           double ndy = 0.0, supp = 0.0;
 #pragma unroll
           for (int t = 0; t < MAXT; ++t) {
             const int row = l + 64 * t;
             if (row < m) {
-              ndy = fmax(ndy, fabs(dy[t]));
+              ndy = fmax(ndy, fabs(Eo[t] * dy[t]));
               supp += hi[t] * fmax(dy[t], 0.0) + lo[t] * fmin(dy[t], 0.0);
-              wbuf[row] = dy[t];
+              wbuf[row] = Eo[t] * dy[t];
             }
           }
           ndy = wave_max(ndy);
@@ -785,8 +858,7 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
           if (ndy > a.s.eps_prim_inf && supp < -a.s.eps_prim_inf * ndy) {
             conv_adjoint<6>(tv, G, wbuf, N, SROW);
             double nat = 0.0;
-            for (int e = l; e < n; e += F16_WAVE)
-              nat = fmax(nat, fabs(tv[e] + wbuf[ms + e] + (wbuf[ms + n + e] - (e + 3 < n ? wbuf[ms + n + e + 3] : 0.0))));
+            for (int e = l; e < n; e += F16_WAVE) nat = fmax(nat, fabs(adjoint(wbuf, e)));
             nat = wave_max(nat);
             if (nat < a.s.eps_prim_inf * ndy) { done = true; infeasible = true; }
           }
@@ -794,10 +866,11 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
         }
         if (done) {}
         else if (it >= a.s.max_iter) done = true;
-        else if (a.s.adaptive_rho && it % a.s.rho_every == 0) {
-          double nw = rho * sqrt((rp / fmax(np_, 1e-10)) / fmax(rd / fmax(nd_, 1e-10), 1e-10));
-          nw = fmin(fmax(nw, 1e-6), 1e6);
-          if (nw > 5 * rho || nw < rho / 5) {
+        else if (a.s.adaptive_rho && it % a.s.rho_every == 0) {     // auxil.c:compute_rho_estimate (scaled residuals)
+          const double pr = wave_max(r1s) / (fmax(wave_max(nzs), wave_max(nAxs)) + 1e-10);
+          const double dr = wave_max(r2s) / (fmax(fmax(wave_max(nqs), wave_max(nAtys)), wave_max(nPxs)) + 1e-10);
+          const double nw = fmin(fmax(rho * sqrt(pr / (dr + 1e-10)), OSQP_RHO_MIN), OSQP_RHO_MAX);
+          if (nw > OSQP_ADAPTIVE_RHO_TOLERANCE * rho || nw < rho / OSQP_ADAPTIVE_RHO_TOLERANCE) {
             rho = nw;
             if (!build_minv(rho)) done = true;
           }
@@ -826,7 +899,7 @@ static size_t mpc_lds_doubles(int N, bool setup_only) {      // mirrors the Bump
   auto ev = [](int v) { return (size_t)((v + 1) & ~1); };
   const int r0 = (!setup_only && np > 1100) ? np : 1100;
   const size_t common = ev(r0) + ev(N * 27) + ev(81) * 3 + ev(54) + ev(9) * 2;
-  return setup_only ? common : common + ev(n) + ev(m) + ev(9 * N) + 4 * ev(n);
+  return setup_only ? common : common + ev(n) + ev(m) + ev(9 * N) + 4 * ev(n) + 2 * ev(n) + ev(9 * N) + ev(n + 3);
 }
 
 }  // namespace f16
@@ -895,8 +968,9 @@ extern "C" int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, c
 }
 
 extern "C" void f16_qp_default_settings(f16_qp_settings *s) {
-  // OSQP defaults with the deterministic schedule of SURVEY.md 8(d) config 4
-  s->rho = 0.0;   // 0 = automatic 2 sqrt(tr P / tr A'A) (OSQP's 0.1 presumes its Ruiz scaling); > 0 = fixed start value
+  // what env.py:420-422 invokes: osqp.OSQP().setup(..., max_iter=40000, polish=False), every other setting at OSQP's
+  // default; the adaptive-rho interval is OSQP's no-timer constant (its default is wall-clock based)
+  s->rho = 0.1; s->scaling = 10;
   s->sigma = 1e-6; s->alpha = 1.6; s->eps_abs = 1e-3; s->eps_rel = 1e-3; s->eps_prim_inf = 1e-4;
   s->max_iter = 40000;            // env.py:421
   s->check_every = 25; s->rho_every = 100; s->adaptive_rho = 1;
@@ -922,15 +996,14 @@ static int mpc_lds_opt_in() {
   return F16_OK;
 }
 
-// Per-call QP workspace, stream-ordered (see f16_ctx.h): [B][np] P | [B][np] A'A | [B][ext] extras.
+// Per-call QP workspace, stream-ordered (see f16_ctx.h): [B][np] P | [B][ext] extras.
 static int mpc_work_alloc(f16_ctx *ctx, MpcArgs &a, bool with_ext, void *stream, void **block) {
   const size_t np = (size_t)(3 * a.N) * (3 * a.N + 1) / 2;
-  const size_t need = (2 * np + (with_ext ? mpc_ext_doubles(a.N) : 0)) * (size_t)a.B * sizeof(double);
+  const size_t need = (np + (with_ext ? mpc_ext_doubles(a.N) : 0)) * (size_t)a.B * sizeof(double);
   *block = nullptr;
   if (int rc = hip_check(hipMallocFromPoolAsync(block, need, ctx->pool, (hipStream_t)stream), "hipMallocFromPoolAsync QP workspace")) return rc;
   a.Ppk = (double *)*block;
-  a.Apk = a.Ppk + np * (size_t)a.B;
-  a.ext = with_ext ? a.Apk + np * (size_t)a.B : nullptr;
+  a.ext = with_ext ? a.Ppk + np * (size_t)a.B : nullptr;
   return F16_OK;
 }
 static int mpc_work_free(void *block, void *stream) {
@@ -1001,7 +1074,9 @@ extern "C" int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, c
   a.Ad = Ad; a.Bd = Bd; a.Cd = Cd; a.x = x; a.dem = dem; a.ucmd = u_cmd; a.useq = u_seq; a.info = info; a.status = status;
   a.B = B; a.ld = ld; a.N = hzn; a.dt = dt;
   if (s) a.s = *s; else f16_qp_default_settings(&a.s);
-  if (a.s.check_every < 1 || a.s.rho_every < 1 || !(a.s.rho >= 0) || !(a.s.sigma > 0)) return set_error(F16_EINVAL, "bad QP settings");
+  if (a.s.check_every < 1 || a.s.rho_every < 1 || !(a.s.rho >= 0) || !(a.s.sigma > 0) || a.s.scaling < 0 || a.s.scaling > 100 ||
+      (a.s.scaling > 0 && !(a.s.rho > 0)))
+    return set_error(F16_EINVAL, "bad QP settings (the automatic start value of rho, rho = 0, needs scaling = 0)");
   // solver selection: the register-resident solver covers N <= 32; a negative max_iter forces the generic kernel (tests)
   const bool generic = hzn > FAST_MAXN || a.s.max_iter < 0;
   if (a.s.max_iter < 0) a.s.max_iter = -a.s.max_iter;
@@ -1042,22 +1117,26 @@ extern "C" int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const doub
   p->ctx = ctx; p->B = B; p->ld = ld; p->N = hzn; p->dt = dt;
   p->warm = nullptr; p->warm_on = false; p->have_prev = false; p->sched = nullptr; p->have_order = false;
   if (s) p->s = *s; else f16_qp_default_settings(&p->s);
-  if (p->s.check_every < 1 || p->s.rho_every < 1 || !(p->s.rho >= 0) || !(p->s.sigma > 0) || p->s.max_iter < 1) {
+  if (p->s.check_every < 1 || p->s.rho_every < 1 || !(p->s.rho >= 0) || !(p->s.sigma > 0) || p->s.max_iter < 1 || p->s.scaling < 0 ||
+      p->s.scaling > 100 || (p->s.scaling > 0 && !(p->s.rho > 0))) {
     delete p;
     return set_error(F16_EINVAL, "bad QP settings");
   }
   const size_t np = (size_t)(3 * hzn) * (3 * hzn + 1) / 2;
-  const size_t per = 2 * np + mpc_ext_doubles(hzn) + MPC_TILE_DOUBLES;
+  const size_t per = np + mpc_ext_doubles(hzn) + MPC_TILE_DOUBLES;
   if (int rc = hip_check(hipMalloc(&p->buf, per * (size_t)B * sizeof(double)), "hipMalloc MPC plan")) { delete p; return rc; }
   if (int rc = hip_check(hipMalloc(&p->sched, 2 * (size_t)B * sizeof(int32_t)), "hipMalloc MPC plan")) { (void)hipFree(p->buf); delete p; return rc; }
   MpcArgs &a = p->a;
   a = MpcArgs{};
   a.Ad = Ad; a.Bd = Bd; a.Cd = Cd; a.B = B; a.ld = ld; a.N = hzn; a.dt = dt; a.s = p->s;
-  a.Ppk = p->buf; a.Apk = a.Ppk + np * (size_t)B; a.ext = a.Apk + np * (size_t)B;
+  a.Ppk = p->buf; a.ext = a.Ppk + np * (size_t)B;
   a.tiles = a.ext + mpc_ext_doubles(hzn) * (size_t)B;
   a.mode = 1;
   int rc = plan_launch_build(p, a, stream);
-  if (!rc) rc = mpc_fast_solve_launch(ctx, a, stream);
+  // Without equilibration the start value of rho and the KKT factorisation depend on the model only and are cached too.
+  // OSQP's equilibration depends on q (the cost scaling c looks at ||q||, and D, E at c), i.e. on the state of the call:
+  // a plan with scaling > 0 keeps the model part (DARE, G_k, P) and redoes equilibration + factorisation per solve.
+  if (!rc && p->s.scaling == 0) rc = mpc_fast_solve_launch(ctx, a, stream);
   a.Ad = a.Bd = a.Cd = nullptr;                        // not retained
   if (rc) { (void)hipFree(p->buf); (void)hipFree(p->sched); delete p; return rc; }
   *plan = p;
@@ -1075,6 +1154,7 @@ extern "C" int f16_mpc_plan_solve(f16_mpc_plan *p, const double *x, const double
   a.iters_out = p->sched;
   a.order = p->have_order ? p->sched + p->B : nullptr;
   if (int rc = plan_launch_build(p, a, stream)) return rc;
+  if (p->s.scaling > 0) a.mode = 0;                    // nothing cached beyond the model part: full solver prologue
   if (int rc = mpc_fast_solve_launch(p->ctx, a, stream)) return rc;
   if (int rc = mpc_plan_order_launch(p->sched, p->sched + p->B, p->B, p->s.check_every, stream)) return rc;
   p->have_order = true;

@@ -9,10 +9,19 @@
 
 namespace f16 {
 
-// Start value of rho when f16_qp_settings.rho <= 0: RHO_AUTO_SCALE * sqrt(tr P / tr A'A).  The square root balances the
-// two terms of P + rho A'A (the QP is not Ruiz-scaled); the factor is tuned on the config-4 workload: mean ADMM
-// iterations 50 -> 38 (checked every 25), worst case 125 -> 75, against factor 1 (the test-side restatement uses the same rule).
+// The builder's opt-in start value of rho (f16_qp_settings.rho <= 0, scaling = 0): RHO_AUTO_SCALE * sqrt(tr P / tr A'A).
+// The square root balances the two terms of P + rho A'A of the UNscaled QP; the factor is tuned on the config-4 workload:
+// mean ADMM iterations 50 -> 38 (checked every 25), worst case 125 -> 75, against factor 1 (the test-side restatement
+// uses the same rule).
 constexpr double RHO_AUTO_SCALE = 2.0;
+// OSQP constants (osqp/include/constants.h as recalled in SURVEY.md Appendix C; the test-side restatement uses the same)
+constexpr double OSQP_MIN_SCALING = 1e-4, OSQP_MAX_SCALING = 1e4, OSQP_RHO_MIN = 1e-6, OSQP_RHO_MAX = 1e6;
+constexpr double OSQP_RHO_TOL = 1e-4, OSQP_RHO_EQ_OVER_RHO_INEQ = 1e3, OSQP_ADAPTIVE_RHO_TOLERANCE = 5.0;
+__host__ __device__ inline double osqp_limit_scaling(double v) {
+  v = v < OSQP_MIN_SCALING ? 1.0 : v;
+  return v > OSQP_MAX_SCALING ? OSQP_MAX_SCALING : v;
+}
+static __constant__ double XLB9[9] = {-1e30, -1e30, -20., -30., -300., -100., -50., -1e30, 0.};   // all nine MPC state rows
 constexpr int MAXN = 40;                         // horizon limit of the LDS-resident solver
 constexpr int MAXT = (12 * MAXN + 63) / 64;      // constraint rows per lane
 static __constant__ int SROW[6] = {2, 3, 4, 5, 6, 8};   // MPC states with finite bounds: alpha,beta,p,q,r,lf2 (parameters.py:59-95,135)
@@ -25,8 +34,8 @@ struct MpcArgs {
   const double *Ad, *Bd, *Cd, *x, *dem;
   double *ucmd, *useq, *info;
   int32_t *status;
-  double *Ppk, *Apk;          // workspace [B][np] packed P and A'A
-  double *ext;                // workspace [B][mpc_ext_doubles(N)]: q | G | pred | A | Q | Qbar | rho (setup kernel -> fast solver / debug)
+  double *Ppk;                // workspace [B][np] packed P (A'A is never stored: the solvers form the weighted Gram themselves)
+  double *ext;                // workspace [B][mpc_ext_doubles(N)]: q | G | pred | A | Q | Qbar | rho, ok | scaling (setup kernel -> solver / debug)
   double *tiles;              // prepared plans: [B][MPC_TILE_DOUBLES] KKT-inverse tiles in accumulator layout
   int mode;                   // 0 one-shot; 1 prepare (build + factor, keep everything, no iterations); 2 solve from a plan
   double *warm;               // plans with warm start: [B][MPC_WARM_DOUBLES] x, z, y of the previous solve (per lane)
@@ -40,7 +49,7 @@ struct MpcArgs {
 };
 
 
-// per-aircraft extras written by the setup kernel: q[n] | G[27N] | pred[9N] | A[81] Q[81] Qbar[81] | rho, pad
+// per-aircraft extras written by the setup kernel: q[n] | G[27N] | pred[9N] | A[81] Q[81] Qbar[81] | rho, ok
 __host__ __device__ inline size_t mpc_ext_doubles(int N) { return (size_t)3 * N + 27 * N + 9 * N + 243 + 2; }
 __host__ __device__ inline size_t mpc_ext_model(int N) { return (size_t)3 * N + 27 * N + 9 * N; }      // offset of A | Q | Qbar | rho
 constexpr int MPC_WARM_DOUBLES = 3 * 512;

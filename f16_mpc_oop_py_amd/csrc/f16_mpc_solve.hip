@@ -1,8 +1,14 @@
-// f16_mpc_solve.hip -- register-resident OSQP-style ADMM for the condensed MPC QP (N <= 32), gfx950.
+// f16_mpc_solve.hip -- register-resident OSQP ADMM for the condensed MPC QP (N <= 32), gfx950.
 //
-// Same algorithm, settings, termination / rho-update / infeasibility rules as the generic solver in
-// f16_control.hip (k_mpc) -- what changes is the mapping: one 512-lane workgroup (8 wavefronts) per aircraft and
-// every operator of an ADMM iteration lives in registers for the whole solve:
+// The solve the reference delegates to `osqp` (env.py:420-424), by OSQP's published algorithm: Ruiz equilibration
+// (D, E, c), rho vector, over-relaxed ADMM, termination on unscaled residuals, rho re-estimated from the scaled ones
+// (the tests compare with a rule-for-rule numpy restatement of it).  Same rules as the generic
+// solver in f16_control.hip (k_mpc) -- what changes is the mapping: one 512-lane workgroup (8 wavefronts) per aircraft
+// and every operator of an ADMM iteration lives in registers for the whole solve.
+// Coordinates.  OSQP iterates on xb = D^-1 x, zb = E z, yb with Pb = c D P D, qb = c D q, Ab = E A D.  Here the
+// variable is kept UNscaled (x = D xb): the linear system becomes (c P + sigma D^-2 + rho A' W A) x~ = sigma D^-2 x - c q
+// + A' E (rho zb - yb) with the row weights W = E^2 (x 1e3 on equality rows) -- the same iterates, but the Toeplitz operators
+// A, A' stay the unscaled block-Toeplitz ones (E enters as one multiply per constraint row, D only through sigma D^-2):
 //     stage 1   t  = CCs' w_s      (3N x 6N, block upper-triangular Toeplitz)      utils.py:163 (A' part)
 //     stage 2   x~ = (P + sigma I + rho A'A)^-1 rhs        (3N x 3N dense)          OSQP linear system
 //     stage 3   z~ = CCs x~        (6N x 3N, block lower-triangular Toeplitz)       utils.py:163 (A part)
@@ -214,8 +220,7 @@ __device__ __forceinline__ void inverse_step(d4_t (&acc)[NT], const double *cb, 
 #define F16_INV_ATTR __forceinline__
 #endif
 template <int NTT>
-__device__ F16_INV_ATTR bool mfma_inverse(d4_t *acc_out, double *Cs, const double *Pg, const double *Ag, double r,
-                                                       double sigma, int n) {
+__device__ F16_INV_ATTR bool mfma_inverse(d4_t *acc_out, double *Cs, const d4_t *acc_in) {
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
   int lc = l & 15, lq = l >> 4;
   // opaque to the optimiser: otherwise the tile index arithmetic below (loop-invariant for the caller's factorisation
@@ -223,25 +228,8 @@ __device__ F16_INV_ATTR bool mfma_inverse(d4_t *acc_out, double *Cs, const doubl
   asm volatile("" : "+v"(lc), "+v"(lq));
   bool ok = true;
   d4_t acc[NT];
-  // tiles straight from the packed lower triangles in the workspace (L2-resident: the build kernel just wrote them).
-  // Two tiles per round trip (scheduling fence): hoisting all 2 x 24 loads to the top costs more registers than there are.
 #pragma unroll
-  for (int J = 0; J < NTT; ++J) {
-    double pv[4], av[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = 16 * w + 4 * q + lq, j = 16 * J + lc;
-      const bool in = i < n && j < n;
-      const int e = in ? (i >= j ? tri(i, j) : tri(j, i)) : 0;
-      pv[q] = Pg[e]; av[q] = Ag[e];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = 16 * w + 4 * q + lq, j = 16 * J + lc;
-      acc[J][q] = (i < n && j < n) ? pv[q] + r * av[q] + (i == j ? sigma : 0.0) : (i == j ? 1.0 : 0.0);
-    }
-    if (J & 1) __builtin_amdgcn_sched_barrier(0);      // two tiles (2 x 16 loads) in flight per round trip
-  }
+  for (int J = 0; J < NTT; ++J) acc[J] = acc_in[J];
   double *c0 = Cs, *c1 = Cs + PAN_SIZE;
   __syncthreads();                        // previous users of Cs are done
   if (w == 0) {
@@ -281,6 +269,22 @@ __device__ F16_INV_ATTR bool mfma_inverse(d4_t *acc_out, double *Cs, const doubl
   return __syncthreads_and(ok) != 0;      // uniform over the workgroup (only the tile-row waves looked at pivots)
 }
 
+// tiles of a packed (lower triangle, row-major) symmetric matrix: element (16w + 4q + l/16, 16J + l%16), identity padding
+template <int NTT>
+__device__ __forceinline__ void load_packed_tiles(d4_t (&acc)[NT], const double *Pg, int n, int w, int lc, int lq) {
+#pragma unroll
+  for (int J = 0; J < NTT; ++J) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 16 * w + 4 * q + lq, j = 16 * J + lc;
+      const bool in = i < n && j < n;
+      const int e = in ? (i >= j ? tri(i, j) : tri(j, i)) : 0;
+      const double pv = Pg[e];
+      acc[J][q] = in ? pv : (i == j ? 1.0 : 0.0);
+    }
+  }
+}
+
 // diagnostic / test entry: inverse of B packed SPD matrices through mfma_inverse
 __global__ __launch_bounds__(FT) void k_dbg_inverse(const double *pk, double *out, int n, long B) {
   __shared__ __attribute__((aligned(16))) double cv[2 * FN * 4 + 40];
@@ -289,8 +293,9 @@ __global__ __launch_bounds__(FT) void k_dbg_inverse(const double *pk, double *ou
   for (long b = blockIdx.x; b < B; b += gridDim.x) {
     const double *Pg = pk + (size_t)b * np;
     double *o = out + (size_t)b * n * n;
-    d4_t acc[NT];
-    const bool ok = mfma_inverse<NT>(acc, cv, Pg, Pg, 0.0, 0.0, n);
+    d4_t acc[NT], m0[NT];
+    load_packed_tiles<NT>(m0, Pg, n, w, lc, lq);
+    const bool ok = mfma_inverse<NT>(acc, cv, m0);
 #pragma unroll
     for (int J = 0; J < NT; ++J)
 #pragma unroll
@@ -409,17 +414,199 @@ constexpr int WSP = WROW * 64;         // zero-padded state-row vectors (stage 1
 constexpr int XOFF = 3 * 32;           // zeros in front of x~ (stage 3 reads down to block -31)
 constexpr int XTP = XOFF + FN + 8;
 
+// max over the 16 lanes of a DPP row, the result in every lane (values >= 0)
+__device__ __forceinline__ double row_allmax(double v) {
+  v = fmax(v, dpp_f64<DPP_XOR1>(v));
+  v = fmax(v, dpp_f64<DPP_XOR2>(v));
+  v = fmax(v, dpp_f64<DPP_HMIRROR>(v));
+  v = fmax(v, dpp_f64<DPP_MIRROR>(v));
+  return v;
+}
+
+constexpr int ES9 = 9 * 64;            // E of all nine state rows per horizon step (equilibration), zero padded like wsP
+constexpr int WGN = 6 * FAST_MAXN + 8; // Gram weights of the kept state rows, zero padded to whole k-steps
+
+
+// ---- Ruiz equilibration (OSQP scaling.c:scale_data), out of line: its register
+// needs (|P| tiles, eighteen E / six D operands per pass) stay out of the iteration loop's allocation.  Norms of the scaled
+// matrices are formed from the ORIGINAL entries and the running D, E, c:
+//   columns / rows of Pb = c D P D    from |P| held as matrix-core tiles (tile-row waves, DPP row maxima)
+//   columns of Ab = E A D             the stage-1 pattern with (max, x) instead of (+, x) on |G_d| and E
+//   rows of Ab                        the stage-3 pattern likewise on |G_d| and D
+// All nine state rows take part (rows without bounds are rows of A as OSQP sees it).  On entry Dv / Es9 / Ecv / Erv hold
+// D = E = 1 (zero padded); on return they hold the final D, E; De / Eo / cs are this lane's D, E and the cost scaling c.
+template <int NTT>
+__device__ __noinline__ void ruiz_equilibrate(const double *Pg, const double *Gl, double *Dv, double *Es9, double *Ecv, double *Erv,
+                                              double *nPm, double *red, int N, int passes, double qe, double *out3) {
+  const int n = 3 * N;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lc = l & 15, lq = l >> 4, blk = tid >> 4, q = lc;
+  const bool inb = blk < N;
+  int kind = 0, sub = 0;
+  if (inb) {
+    if (lc == 0 || lc == 2 || lc == 4) { kind = 1; sub = lc >> 1; }
+    else if (lc == 8 || lc == 10 || lc == 12) { kind = 1; sub = 3 + ((lc - 8) >> 1); }
+    else if (lc == 1 || lc == 3 || lc == 5) { kind = 2; sub = (lc - 1) >> 1; }
+    else if (lc == 9 || lc == 11 || lc == 13) { kind = 3; sub = (lc - 9) >> 1; }
+  }
+  const int r9 = kind == 1 ? (sub < 5 ? sub + 2 : 8) : (lc == 6 ? 0 : (lc == 14 ? 1 : (lc == 7 ? 7 : -1)));
+  const bool srow = inb && r9 >= 0;
+  const int k3 = 3 * blk + sub;
+  const bool xown = inb && (lc == 0 || lc == 4 || lc == 8);
+  const int xe = 3 * blk + (lc >> 2);
+  double De = 1.0, Eo = 1.0, cs = 1.0;
+  d4_t pt[NT];                                               // |P| tiles
+  if (w < NTT) {
+    load_packed_tiles<NTT>(pt, Pg, n, w, lc, lq);
+#pragma unroll
+    for (int J = 0; J < NTT; ++J)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
+        pt[J][qq] = (i < n && j < n) ? fabs(pt[J][qq]) : 0.0;
+      }
+  }
+  auto p_row_norms = [&]() {                                 // nPm[i] = D_i max_j |P_ij| D_j   (c applied by the reader)
+    if (w < NTT) {
+      double dj[NTT];
+#pragma unroll
+      for (int J = 0; J < NTT; ++J) dj[J] = Dv[XOFF + 16 * J + lc];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        double m = 0.0;
+#pragma unroll
+        for (int J = 0; J < NTT; ++J) m = fmax(m, pt[J][qq] * dj[J]);
+        m = row_allmax(m);
+        const int i = 16 * w + 4 * qq + lq;
+        if (lc == qq && i < n) nPm[i] = Dv[XOFF + i] * m;
+      }
+    }
+  };
+  p_row_norms();
+  __syncthreads();
+  const int d0 = 2 * q, d1 = 2 * q + 1;
+  const double *g0 = Gl + (d0 < N ? d0 : 0) * 27, *g1 = Gl + (d1 < N ? d1 : 0) * 27;
+  const double m0 = d0 < N ? 1.0 : 0.0, m1 = d1 < N ? 1.0 : 0.0;
+  for (int pass = 0; pass < passes; ++pass) {
+    // column norms of the state block of Ab (before the D of the column) and row norms (before the E of the row):
+    // lane q covers the blocks d = 2q, 2q+1
+    double colS[3] = {0.0, 0.0, 0.0}, rowS[9];
+    const double *ep = Es9 + 9 * (blk + 2 * q), *dp = Dv + XOFF + 3 * (blk - 2 * q - 1);
+    double dv[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dv[k] = dp[k];               // D of step i-2q-1 (3), of step i-2q (3)
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const double e0 = ep[r] * m0, e1 = ep[9 + r] * m1;
+      double m = 0.0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double a0 = fabs(g0[r * 3 + c]), a1 = fabs(g1[r * 3 + c]);
+        colS[c] = fmax(colS[c], fmax(a0 * e0, a1 * e1));
+        m = fmax(m, fmax(a0 * m0 * dv[3 + c], a1 * m1 * dv[c]));
+      }
+      rowS[r] = row_allmax(m);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) colS[c] = row_allmax(colS[c]);
+    double Dt = 1.0, Et = 1.0;
+    if (xown) {
+      const int c = lc >> 2;
+      const double cS = c == 0 ? colS[0] : (c == 1 ? colS[1] : colS[2]);
+      const double colA = De * fmax(fmax(cS, Ecv[xe]), fmax(Erv[xe], Erv[xe + 3]));
+      Dt = 1.0 / sqrt(osqp_limit_scaling(fmax(cs * nPm[xe], colA)));
+    }
+    if (srow) {
+      double rs = rowS[0];
+#pragma unroll
+      for (int r = 1; r < 9; ++r) rs = r9 == r ? rowS[r] : rs;
+      Et = 1.0 / sqrt(osqp_limit_scaling(Eo * rs));
+    } else if (kind == 2) {
+      Et = 1.0 / sqrt(osqp_limit_scaling(Eo * Dv[XOFF + k3]));
+    } else if (kind == 3) {
+      Et = 1.0 / sqrt(osqp_limit_scaling(Eo * fmax(Dv[XOFF + k3], Dv[XOFF + k3 - 3])));
+    }
+    __syncthreads();                                        // every lane has read the old D and E
+    De *= Dt; Eo *= Et;
+    if (xown) Dv[XOFF + xe] = De;
+    if (srow) Es9[9 * blk + r9] = Eo;
+    if (kind == 2) Ecv[k3] = Eo;
+    if (kind == 3) Erv[k3] = Eo;
+    __syncthreads();
+    p_row_norms();                                           // with the new D: cost scaling now, column norms of the next pass
+    __syncthreads();
+    double v2[2] = {xown ? cs * nPm[xe] : 0.0, xown ? cs * De * fabs(qe) : 0.0};
+    const bool s2[2] = {true, false};
+    block_reduce<2>(v2, s2, red);
+    cs *= 1.0 / fmax(osqp_limit_scaling(v2[0] / n), osqp_limit_scaling(v2[1]));
+  }
+  out3[0] = De; out3[1] = Eo; out3[2] = cs;
+}
+
+// ---- A'WA as matrix-core tiles, out of line (same reason).  A'WA = sum over the kept constraint rows of w a a': the state
+// rows (6N x 3N block lower-triangular Toeplitz, never formed) as a Gram product on the matrix cores -- k-step kk covers rows
+// 4kk..4kk+3, the operand of column tile T is G_(i-j)[S r][c] gathered from LDS, the SAME value serves as the A operand of
+// tile row T and (times w) as the B operand of tile column T --, the command rows (identity) and rate rows (D = I - shift_3)
+// as a diagonal / third-off-diagonal fix-up.  gram: tile row w of this lane (24 values).
+template <int NTT>
+__device__ __noinline__ void gram_tiles(d4_t *gram, const double *Gl, const double *Wg, const double *Wcv, const double *Wrv, int N) {
+  const int n = 3 * N;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lc = l & 15, lq = l >> 4;
+  d4_t acc[NT];
+#pragma unroll
+  for (int J = 0; J < NTT; ++J) acc[J] = d4_t{0.0, 0.0, 0.0, 0.0};
+  if (w < NTT) {
+    int offT[NTT], jT[NTT];
+#pragma unroll
+    for (int T = 0; T < NTT; ++T) {
+      const int col = 16 * T + lc;
+      jT[T] = col < n ? col / 3 : 1 << 20;                   // padding columns: never reached (i >= jT fails)
+      offT[T] = (col - 3 * (col / 3)) - 27 * (col / 3);
+    }
+    const int colw = 16 * w + lc;
+    const int jW = colw < n ? colw / 3 : 1 << 20, offW = (colw - 3 * (colw / 3)) - 27 * (colw / 3);
+    const int nk = (6 * N + 3) >> 2;
+    for (int kk = 0; kk < nk; ++kk) {
+      const int rw = 4 * kk + lq, i = rw / 6, rr = rw - 6 * i;
+      const int base = 27 * i + 3 * (rr < 5 ? rr + 2 : 8);
+      const double wgt = Wg[rw];                             // 0 beyond row 6N
+      const bool vi = i < N;
+      const double a_op = (vi && i >= jW) ? Gl[base + offW] : 0.0;
+      double b_op[NTT];
+#pragma unroll
+      for (int T = 0; T < NTT; ++T) b_op[T] = (vi && i >= jT[T]) ? Gl[base + offT[T]] * wgt : 0.0;
+#pragma unroll
+      for (int J = 0; J < NTT; ++J) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op[J], acc[J], 0, 0, 0);
+    }
+#pragma unroll
+    for (int J = 0; J < NTT; ++J)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
+        if (i < n && j < n) {
+          if (i == j) acc[J][qq] += Wcv[i] + Wrv[i] + Wrv[i + 3];
+          else if (i == j + 3) acc[J][qq] -= Wrv[i];
+          else if (j == i + 3) acc[J][qq] -= Wrv[j];
+        }
+      }
+  }
+#pragma unroll
+  for (int J = 0; J < NTT; ++J) gram[J] = acc[J];
+}
+
 // One 512-lane workgroup per aircraft, three barriers per ADMM iteration:
-//   A  stage 1 partials + row reduce -> rhs = sigma x - q + A'(rho z - y)                      | barrier
+//   A  stage 1 partials + row reduce -> rhs = sigma D^-2 x - c q + A' E (rho zb - yb)              | barrier
 //   B  stage 2: x~ = Minv rhs straight from the MFMA accumulators of the inverse (tile-row waves) | barrier
-//   C  stage 3 partials + row reduce -> z~ ; relaxation, projection, dual update, w = rho z - y  | barrier
+//   C  stage 3 partials + row reduce -> zb~ = E A x~ ; relaxation, projection, dual update, w = E (rho zb - yb) | barrier
 // Lane roles inside DPP row blk (= horizon step): lanes 0,2,4,8,10,12 own the six kept state rows of step blk (that is
-// where reduce6 leaves their z~), lanes 1,3,5 the command rows, 9,11,13 the rate rows, lanes 0,4,8 also own x[3 blk + c].
+// where reduce6 leaves their z~), lanes 1,3,5 the command rows, 9,11,13 the rate rows, lanes 0,4,8 also own x[3 blk + c];
+// during the equilibration lanes 6, 14, 7 stand in for the three state rows without bounds (phi, theta, lf1).
 template <int NTT>
 __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
   __shared__ __attribute__((aligned(16))) double wsP[WSP], ysP[WSP], xtP[XTP], Cs[2 * FN * 4 + 40];
   __shared__ double rhs[FN], wc[FN], wr[FN + 4], yc[FN], yr[FN + 4], red[8 * 9], xcP[XTP];
-  extern __shared__ double pxL[];       // [18][FT]: this lane's 18 entries of P for the dual residual (termination test)
+  __shared__ double Dv[XTP], Es9[ES9], Ecv[FN], Erv[FN + 4], Wg[WGN], Wcv[FN], Wrv[FN + 4], nPm[FN];
+  __shared__ __attribute__((aligned(16))) double Gl[27 * FAST_MAXN];
+  extern __shared__ double pxL[];       // [18][FT] this lane's 18 entries of P (termination test) | [3][FT] lane constants
 
   const int N = a.N, n = 3 * N;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lc = l & 15, lq = l >> 4, blk = tid >> 4, q = lc;
@@ -433,6 +620,9 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
     else if (lc == 1 || lc == 3 || lc == 5) { kind = 2; sub = (lc - 1) >> 1; }
     else if (lc == 9 || lc == 11 || lc == 13) { kind = 3; sub = (lc - 9) >> 1; }
   }
+  // x9 row of a state-row owner (kept rows: SROW[sub]; rows without bounds: lanes 6 -> phi, 14 -> theta, 7 -> lf1)
+  const int r9 = kind == 1 ? (sub < 5 ? sub + 2 : 8) : (lc == 6 ? 0 : (lc == 14 ? 1 : (lc == 7 ? 7 : -1)));
+  const bool srow = inb && r9 >= 0;
   const int k3 = 3 * blk + sub;                                // index of a command / rate row
   const bool xown = inb && (lc == 0 || lc == 4 || lc == 8);
   const int xe = 3 * blk + (lc >> 2);
@@ -441,23 +631,28 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
   double *const ydst = kind == 1 ? ysP + WROW * blk + sub : (kind == 2 ? yc + k3 : yr + k3);
   const int dup = (kind == 1 && sub < 3) ? 6 : 0;              // state rows 0..2 are stored twice (stage1_load)
   const double *const wsrc = wsP + WROW * (blk + 2 * q) + (h ? 3 : 0), *const ysrc = ysP + WROW * (blk + 2 * q) + (h ? 3 : 0);
+  double *const lcst = pxL + 18 * FT + tid;                   // lane constants: [0] 1/E  [FT] q (unscaled)  [2 FT] c D
   // zero everything once: the pads are never written again
   for (int i = tid; i < WSP; i += FT) { wsP[i] = 0.0; ysP[i] = 0.0; }
-  for (int i = tid; i < XTP; i += FT) { xtP[i] = 0.0; xcP[i] = 0.0; }
-  for (int i = tid; i < FN + 4; i += FT) { wr[i] = 0.0; yr[i] = 0.0; }
-  for (int i = tid; i < FN; i += FT) { rhs[i] = 0.0; wc[i] = 0.0; yc[i] = 0.0; }
-  __syncthreads();
+  for (int i = tid; i < XTP; i += FT) { xtP[i] = 0.0; xcP[i] = 0.0; Dv[i] = 0.0; }
+  for (int i = tid; i < FN + 4; i += FT) { wr[i] = 0.0; yr[i] = 0.0; Erv[i] = 0.0; Wrv[i] = 0.0; }
+  for (int i = tid; i < FN; i += FT) { rhs[i] = 0.0; wc[i] = 0.0; yc[i] = 0.0; Ecv[i] = 0.0; Wcv[i] = 0.0; nPm[i] = 0.0; }
+  for (int i = tid; i < ES9; i += FT) Es9[i] = 0.0;
+  for (int i = tid; i < WGN; i += FT) Wg[i] = 0.0;
 
   const double sigma = a.s.sigma, alpha = a.s.alpha;
 
   {
     const long b = a.order ? a.order[blockIdx.x] : blockIdx.x;    // one aircraft per workgroup (grid = B)
-    const double *ex = a.ext + (size_t)b * mpc_ext_doubles(N);
-    const double *Pg = a.Ppk + (size_t)b * (n * (n + 1) / 2), *Ag = a.Apk + (size_t)b * (n * (n + 1) / 2);
+    double *const exw = a.ext + (size_t)b * mpc_ext_doubles(N);
+    const double *ex = exw;
+    const double *Pg = a.Ppk + (size_t)b * (n * (n + 1) / 2);
     const double *Gg = ex + n, *pred = ex + n + 27 * N;
+    double *const exm = exw + mpc_ext_model(N);                 // A | Q | Qbar | rho, ok of a prepared plan
 #ifdef F16_EXP_STAMPM
     const unsigned long long tP0 = __builtin_amdgcn_s_memtime();
 #endif
+    for (int i = tid; i < 27 * N; i += FT) Gl[i] = Gg[i];      // all nine rows of every G_k: equilibration + Gram
     const double qe = xown ? ex[xe] : 0.0;
     // the termination test needs P x: row blk's 16 lanes split the columns six apiece, so a lane touches the SAME 18
     // entries of P at every test -- fetched once here, with the other prologue loads, into per-lane LDS slots (a test
@@ -476,9 +671,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
 #pragma unroll
       for (int k = 0; k < 18; ++k) pxL[k * FT + tid] = pv[k];
     };
-    // (stored further down: every other load of the prologue is issued first, so that they share one round trip)
-    const double trP = (a.mode != 2 && xown) ? Pg[tri(xe, xe)] : 0.0, trA = (a.mode != 2 && xown) ? Ag[tri(xe, xe)] : 0.0;
-    d4_t acc[NT];                                              // MINUS (P + sigma I + rho A'A)^-1, tile row w (slot order)
+    d4_t acc[NT];                                              // MINUS (c P + sigma D^-2 + rho A'WA)^-1, tile row w (slot order)
     double Gd[2][6][3];                                        // this lane's two Toeplitz blocks
     // stage 2 reads the inverse in slot order (reduce4_slots): one lane-dependent register permutation per
     // factorisation instead of twelve selects per iteration
@@ -501,9 +694,9 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         const int d = 2 * q + bb;
 #pragma unroll
         for (int rr = 0; rr < 6; ++rr) {
-          const int srow = h ? SR[(rr + 3) % 6] : SR[rr];
+          const int srw = h ? SR[(rr + 3) % 6] : SR[rr];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) Gd[bb][rr][c] = d < N ? Gg[d * 27 + srow * 3 + c] : 0.0;
+          for (int c = 0; c < 3; ++c) Gd[bb][rr][c] = d < N ? Gg[d * 27 + srw * 3 + c] : 0.0;
         }
       }
     };
@@ -517,7 +710,22 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         for (int qq = 0; qq < 4; ++qq) acc[J][qq] = w < NTT ? tl[(J * 4 + qq) * 64] : 0.0;
       load_Gd();
     }
-    // ---- bounds of this lane's constraint row (utils.py:129-152; rows with two infinite bounds are not kept)
+    // ---- equilibration state: De = D of this lane's variable (x owners), Eo = E of this lane's constraint row, cs = c
+    double De = 1.0, Eo = 1.0, cs = 1.0;
+    // (a cached plan -- modes 1 and 2 -- exists only without equilibration: D = E = c = 1 there)
+    if (xown) Dv[XOFF + xe] = De;
+    if (srow) Es9[9 * blk + r9] = Eo;
+    if (kind == 2) Ecv[k3] = Eo;
+    if (kind == 3) Erv[k3] = Eo;
+    __syncthreads();                                            // zeros, Gl, D / E = 1 (or the plan's) are in place
+
+    if (a.mode != 2 && a.s.scaling > 0) {
+      double o3[3];
+      ruiz_equilibrate<NTT>(Pg, Gl, Dv, Es9, Ecv, Erv, nPm, red, N, a.s.scaling, qe, o3);
+      De = o3[0]; Eo = o3[1]; cs = o3[2];
+    }
+    if (kind == 0) Eo = 1.0;                                     // (lanes that stood in for an unbounded row)
+    // ---- bounds of this lane's constraint row (utils.py:129-152; rows with two infinite bounds are not kept), scaled by E
     double lo = 0.0, hi = 0.0, z = 0.0, y = 0.0, dy = 0.0, xs = 0.0;
     if (kind == 1) {
       const double pm = pred[blk * 9 + SROW[sub]];
@@ -530,21 +738,64 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         lo = act + RLB[sub] * a.dt; hi = act + RUB[sub] * a.dt;
       } else { lo = RLB[sub]; hi = RUB[sub]; }               // reference quirk: not scaled by dt (utils.py:151-152)
     }
+    lo *= Eo; hi *= Eo;
+    // rho vector (osqp auxil.c:set_rho_vec): an equality row (u - l < 1e-4 after scaling) carries 1e3 rho
+    const double eqf = (kind && hi - lo < OSQP_RHO_TOL) ? OSQP_RHO_EQ_OVER_RHO_INEQ : 1.0;
+    if (kind == 1) Wg[6 * blk + sub] = Eo * Eo * eqf;
+    else if (kind == 2) Wcv[k3] = Eo * Eo * eqf;
+    else if (kind == 3) Wrv[k3] = Eo * Eo * eqf;
+    const double sg2 = xown ? sigma / (De * De) : 0.0, qc = cs * qe;      // sigma D^-2, c q (x owners)
+    if (xown) Dv[XOFF + xe] = sg2;                               // Dv now holds sigma D^-2 for the KKT diagonal
+    lcst[0] = 1.0 / Eo; lcst[FT] = qe; lcst[2 * FT] = cs * De;
+    const double cinv = 1.0 / cs;
     double *const wm = a.warm ? a.warm + (size_t)b * MPC_WARM_DOUBLES + tid : nullptr;
-    if (wm && a.warm_load) {                                   // warm start: x, z, y of the previous solve of this plan
-      const double x0 = wm[0], z0 = wm[FT], y0 = wm[2 * FT];
-      if (isfinite(x0) && isfinite(z0) && isfinite(y0)) { xs = x0; z = z0; y = y0; }
+    if (wm && a.warm_load) {   // warm start: x, z, y of the previous solve of this plan, kept UNscaled (the equilibration of an
+      const double x0 = wm[0], z0 = wm[FT], y0 = wm[2 * FT];      // OSQP-default plan is redone per solve: it depends on q)
+      if (isfinite(x0) && isfinite(z0) && isfinite(y0)) { xs = x0; z = Eo * z0; y = cs * y0 / Eo; }
     }
-    double *const exm = const_cast<double *>(ex) + mpc_ext_model(N);      // A | Q | Qbar | rho of a prepared plan
     double rho = a.mode == 2 ? exm[243] : a.s.rho;
-    if (kind) { const double w0 = (a.mode == 2 ? rho : 0.0) * z - y; wdst[0] = w0; wdst[dup] = w0; }   // w = rho z - y of the start point (zero unless warm)
-    if (a.mode != 2) store_pv();
-    if (!(rho > 0.0)) {   // automatic: balance the two terms of P + rho A'A (our QP is not Ruiz-scaled as OSQP's would be)
-      double tr[2] = {trP, trA};
-      const bool sums[2] = {true, true};
-      block_reduce<2>(tr, sums, red);
-      rho = fmin(fmax(RHO_AUTO_SCALE * sqrt(tr[0] / tr[1]), 1e-6), 1e6);
+    store_pv();
+    __syncthreads();                                            // Wg / Wcv / Wrv / sigma D^-2 are in place
+
+    // ---- KKT matrix  c P + sigma D^-2 + rho A'WA  as matrix-core tiles (gram_tiles above)
+    d4_t gram[NT];
+    auto build_gram = [&]() { gram_tiles<NTT>(gram, Gl, Wg, Wcv, Wrv, N); };
+    auto kkt_tiles = [&](double r) {                             // acc <- c P + sigma D^-2 + r A'WA (identity on the padding)
+      if (w < NTT) {
+        d4_t pp[NT];
+        load_packed_tiles<NTT>(pp, Pg, n, w, lc, lq);
+#pragma unroll
+        for (int J = 0; J < NTT; ++J)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
+            acc[J][qq] = (i < n && j < n) ? cs * pp[J][qq] + r * gram[J][qq] + (i == j ? Dv[XOFF + i] : 0.0) : (i == j ? 1.0 : 0.0);
+          }
+      } else {
+#pragma unroll
+        for (int J = 0; J < NTT; ++J) acc[J] = d4_t{0.0, 0.0, 0.0, 0.0};
+      }
+    };
+    if (a.mode != 2) {
+      build_gram();
+      if (!(rho > 0.0)) {   // the builder's opt-in start value (no equilibration): balance the two terms of P + rho A'A
+        double tr[2] = {xown ? Pg[tri(xe, xe)] : 0.0, 0.0};
+        if (w < NTT) {
+#pragma unroll
+          for (int J = 0; J < NTT; ++J)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+              const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
+              if (i == j && i < n) tr[1] += gram[J][qq];
+            }
+        }
+        const bool sums[2] = {true, true};
+        block_reduce<2>(tr, sums, red);
+        rho = fmin(fmax(RHO_AUTO_SCALE * sqrt(tr[0] / tr[1]), OSQP_RHO_MIN), OSQP_RHO_MAX);
+      }
+      kkt_tiles(rho);
     }
+    if (kind) { const double w0 = Eo * (rho * eqf * z - y); wdst[0] = w0; wdst[dup] = w0; }   // start point (zero unless warm)
     int it = 0, to_check = a.s.check_every > 0 ? a.s.check_every : 1;
     double rp = INFINITY, rd = INFINITY;
     bool converged = false, infeasible = false, ok = true;
@@ -557,14 +808,12 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
 #else
 #define MSTAMP(i)
 #endif
-    bool plan_loaded = false;
+    bool plan_loaded = false, have_tiles = a.mode != 2;
     if (from_plan) {                                           // (loads issued at the top of the prologue)
       from_plan = false; plan_loaded = true;
-      store_pv();
       permute_acc();
     }
-    // outer loop: one trip per KKT factorisation (rho changes at most every rho_every iterations).  The inverse is a
-    // real call; it sits OUTSIDE the iteration loop so that nothing big is live across it.
+    // outer loop: one trip per KKT factorisation (rho changes at most every rho_every iterations).
     while (!done) {
       {
 #ifdef F16_EXP_STAMPM
@@ -574,10 +823,9 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         if (plan_loaded) {
           plan_loaded = false;
         } else {
-          d4_t tmp[NT];                                        // the call hands the tiles over in memory: copy them into
-          ok = mfma_inverse<NTT>(tmp, Cs, Pg, Ag, rho, sigma, n) && ok;   // an array whose address never escapes
-#pragma unroll
-          for (int J = 0; J < NTT; ++J) acc[J] = tmp[J];
+          if (!have_tiles) { build_gram(); kkt_tiles(rho); }   // a rho update (or the first one inside a plan's solve)
+          have_tiles = false;
+          ok = mfma_inverse<NTT>(acc, Cs, acc) && ok;
           if (a.mode == 1) {                                   // prepare: keep the factorisation and its rho, no iterations
             if (w < NTT) {
 #pragma unroll
@@ -589,20 +837,20 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
             done = true;
           }
           permute_acc();
-          load_Gd();                                           // after the call: nothing big is live across it
+          load_Gd();                                           // after the factorisation: nothing big is live across it
         }
 #ifdef F16_EXP_STAMPM
         tP2 = __builtin_amdgcn_s_memtime();
         t0 = tP2;
 #endif
       }
-      const double rinv = 1.0 / rho;
+      const double rho_o = rho * eqf, rinv = 1.0 / rho_o;      // this lane's entry of the rho vector
       bool refactor = false;
       if (!ok || a.s.max_iter <= 0) done = true;
       __syncthreads();
     while (!done && !refactor) {
       ++it;
-      // ---- A: rhs = sigma x - q + A'(rho z - y)
+      // ---- A: rhs = sigma D^-2 x - c q + A' E (rho zb - yb)
       {
         double wv[12], o1[3];
         stage1_load(wsrc, wv);
@@ -610,7 +858,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         MPC_PHASE();
         stage1_fma(Gd, wv, o1);
         const double t = reduce3(o1[0], o1[1], o1[2], h, g);
-        if (xown) rhs[xe] = sigma * xs - qe + (t + wce + (wre - wrn));
+        if (xown) rhs[xe] = sg2 * xs - qc + (t + wce + (wre - wrn));
       }
       MSTAMP(0)
       __syncthreads();
@@ -634,7 +882,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
       MSTAMP(2)
       __syncthreads();
       MSTAMP(3)
-      // ---- C: z~ = A x~, relaxation, projection, dual update
+      // ---- C: zb~ = E A x~, relaxation, projection, dual update
       {
         double xv[6], o3[6];
         stage3_load(xtP + XOFF + 3 * (blk - 2 * q - 1), xv);
@@ -644,10 +892,10 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         const double zs = reduce6_slots(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], g, e);
         if (xown) xs = alpha * xte + (1 - alpha) * xs;
         if (kind) {
-          const double zt = kind == 1 ? zs : (kind == 2 ? xk : xk - xkm);
+          const double zt = Eo * (kind == 1 ? zs : (kind == 2 ? xk : xk - xkm));
           const double zr = alpha * zt + (1 - alpha) * z;
           const double zn = fmin(fmax(fma(y, rinv, zr), lo), hi);
-          dy = rho * (zr - zn);
+          dy = rho_o * (zr - zn);
           y = y + dy;
           z = zn;
         }
@@ -655,10 +903,10 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
       const bool check = --to_check == 0 || it >= a.s.max_iter;      // it % check_every == 0, without the division
       if (to_check == 0) to_check = a.s.check_every;
       if (check) {
-        // ---- residuals (OSQP termination test): A x, P x, A' y.  x goes to its own zero-padded buffer (x~ may still be
-        // read by slower waves), y to the state-row layout; one barrier, then everything of the test in one reduction
-        // (the two quantities of the primal-infeasibility certificate ride along: they only depend on dy)
-        if (kind) { ydst[0] = y; ydst[dup] = y; }
+        // ---- residuals (OSQP termination test on the UNSCALED problem): A x, P x, A' E yb / c.  x goes to its own zero-padded
+        // buffer (x~ may still be read by slower waves), E yb to the state-row layout; one barrier, then everything of the
+        // test in one reduction (the two quantities of the primal-infeasibility certificate ride along)
+        if (kind) { const double ye = Eo * y; ydst[0] = ye; ydst[dup] = ye; }
         if (xown) xcP[XOFF + xe] = xs;
         __syncthreads();
         double o3[6], o1[3], px3[3] = {0.0, 0.0, 0.0};
@@ -673,26 +921,28 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
           for (int c = 0; c < 3; ++c) px3[c] = fma(pxL[(cc * 3 + c) * FT + tid], xv, px3[c]);
         }
         const double px = reduce3(px3[0], px3[1], px3[2], h, g);
-        double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};              // r1, |Ax|, |z|, r2, |Px|, |A'y|, |q|, |dy|, support(dy)
+        const double Ei = lcst[0], qu = lcst[FT];
+        double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};              // r1, |Ax|, |z|, r2, |Px|, |A'y|, |q|, |E dy|, support(dy)
+        double ax = 0.0, aty = 0.0;
         if (kind) {
-          const double ax = kind == 1 ? axs : (kind == 2 ? xcP[XOFF + k3] : xcP[XOFF + k3] - xcP[XOFF + k3 - 3]);
-          v[0] = fabs(ax - z); v[1] = fabs(ax); v[2] = fabs(z);
-          v[7] = fabs(dy); v[8] = hi * fmax(dy, 0.0) + lo * fmin(dy, 0.0);
+          ax = kind == 1 ? axs : (kind == 2 ? xcP[XOFF + k3] : xcP[XOFF + k3] - xcP[XOFF + k3 - 3]);
+          v[0] = fabs(ax - z * Ei); v[1] = fabs(ax); v[2] = fabs(z * Ei);
+          v[7] = fabs(Eo * dy); v[8] = hi * fmax(dy, 0.0) + lo * fmin(dy, 0.0);
         }
         if (xown) {
-          const double aty = atys + yc[xe] + (yr[xe] - yr[xe + 3]);
-          v[3] = fabs(px + qe + aty); v[4] = fabs(px); v[5] = fabs(aty); v[6] = fabs(qe);
+          aty = cinv * (atys + yc[xe] + (yr[xe] - yr[xe + 3]));
+          v[3] = fabs(px + qu + aty); v[4] = fabs(px); v[5] = fabs(aty); v[6] = fabs(qu);
         }
         const bool issum[9] = {false, false, false, false, false, false, false, false, true};
         block_reduce<9>(v, issum, red);
         rp = v[0]; rd = v[3];
         const double np_ = fmax(v[1], v[2]), nd_ = fmax(fmax(v[4], v[5]), v[6]);
-        if (rp <= a.s.eps_abs + a.s.eps_rel * np_ && rd <= a.s.eps_abs + a.s.eps_rel * nd_) { done = true; converged = true; }
+        if (rp < a.s.eps_abs + a.s.eps_rel * np_ && rd < a.s.eps_abs + a.s.eps_rel * nd_) { done = true; converged = true; }
         else {
-          // OSQP primal-infeasibility certificate on dy
+          // OSQP primal-infeasibility certificate on dy (auxil.c:is_primal_infeasible)
           const double ndy = v[7], supp = v[8];
           if (ndy > a.s.eps_prim_inf && supp < -a.s.eps_prim_inf * ndy) {
-            if (kind) { ydst[0] = dy; ydst[dup] = dy; }
+            if (kind) { const double de = Eo * dy; ydst[0] = de; ydst[dup] = de; }
             __syncthreads();
             { double wv[12]; stage1_load(ysrc, wv); stage1_fma(Gd, wv, o1); }
             const double t = reduce3(o1[0], o1[1], o1[2], h, g);
@@ -704,15 +954,22 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
           if (!done) {
             if (it >= a.s.max_iter) done = true;
             else if (a.s.adaptive_rho && it % a.s.rho_every == 0) {
-              double nw = rho * sqrt((rp / fmax(np_, 1e-10)) / fmax(rd / fmax(nd_, 1e-10), 1e-10));
-              nw = fmin(fmax(nw, 1e-6), 1e6);
-              if (nw > 5 * rho || nw < rho / 5) { rho = nw; refactor = true; }
+              // auxil.c:compute_rho_estimate on the SCALED residuals: ||Ab xb - zb||, ||Pb xb + qb + Ab' yb|| and their norms
+              const double cD = lcst[2 * FT];
+              double s[7] = {0, 0, 0, 0, 0, 0, 0};
+              if (kind) { s[0] = fabs(Eo * ax - z); s[1] = fabs(Eo * ax); s[2] = fabs(z); }
+              if (xown) { s[3] = cD * fabs(px + qu + aty); s[4] = cD * fabs(px); s[5] = cD * fabs(aty); s[6] = cD * fabs(qu); }
+              const bool mx[7] = {false, false, false, false, false, false, false};
+              block_reduce<7>(s, mx, red);
+              const double pr = s[0] / (fmax(s[2], s[1]) + 1e-10), dr = s[3] / (fmax(fmax(s[6], s[5]), s[4]) + 1e-10);
+              const double nw = fmin(fmax(rho * sqrt(pr / (dr + 1e-10)), OSQP_RHO_MIN), OSQP_RHO_MAX);
+              if (nw > OSQP_ADAPTIVE_RHO_TOLERANCE * rho || nw < rho / OSQP_ADAPTIVE_RHO_TOLERANCE) { rho = nw; refactor = true; }
             }
           }
         }
       }
-      // w = rho z - y for the next iteration
-      if (kind) { const double wn = rho * z - y; wdst[0] = wn; wdst[dup] = wn; }
+      // w = E (rho zb - yb) for the next iteration
+      if (kind) { const double wn = Eo * ((refactor ? rho * eqf : rho_o) * z - y); wdst[0] = wn; wdst[dup] = wn; }
       MSTAMP(4)
       __syncthreads();
       MSTAMP(5)
@@ -723,7 +980,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
     if (a.mode == 1) return;                                   // a plan has no solution yet
     if (wm) {                                                  // keep the solution for the next warm start
       const bool good = converged && !infeasible;
-      wm[0] = good ? xs : NAN; wm[FT] = good ? z : NAN; wm[2 * FT] = good ? y : NAN;
+      wm[0] = good ? xs : NAN; wm[FT] = good ? z / Eo : NAN; wm[2 * FT] = good ? Eo * y * cinv : NAN;
     }
     if (xown) {
       if (xe < 3) a.ucmd[xe * a.ld + b] = infeasible ? NAN : xs;
@@ -780,7 +1037,7 @@ int mpc_fast_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
   if (a.B > 0x7fffffffL) return set_error(F16_EINVAL, "batch too large for one launch");
   const unsigned grid = (unsigned)a.B;
   const int nt = (3 * a.N + 15) / 16;       // 16x16 tiles per side of the KKT matrix, instantiated for 2 / 4 / 6
-  constexpr size_t dyn = 18 * FT * sizeof(double);      // per-lane P entries for the termination test (73.7 KB)
+  constexpr size_t dyn = 21 * FT * sizeof(double);      // per-lane P entries for the termination test + lane constants (86 KB)
   {   // static + dynamic LDS exceed 64 KB: opt in, once per device (not per launch: a plan's solve may run under capture)
     static std::mutex mu;
     static bool ready[64] = {};

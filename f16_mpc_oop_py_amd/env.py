@@ -355,7 +355,10 @@ class F16Batch:
     @staticmethod
     def solver_modes():
         """Named QP-solver settings (overrides of f16_qp_default_settings) for benchmarks and tests."""
-        return {"builder_rule": None, "rho_0p1_unscaled": dict(rho=0.1)}
+        return {"osqp_defaults": None,                                        # what env.py:420-422 invokes (the library default)
+                "osqp_defaults_rho_every_25": dict(rho_every=25),             # OSQP's wall-clock interval typically lands here
+                "builder_rule": dict(scaling=0, rho=0.0),                     # no equilibration, rho0 = 2 sqrt(tr P / tr A'A)
+                "rho_0p1_unscaled": dict(scaling=0, rho=0.1)}
 
     def setup_OSQP(self, p_dem, q_dem, r_dem, hzn, b=0):
         """The QP of aircraft b in the reference's own form (utils.py:21-167 `setup_OSQP`): dense host arrays

@@ -39,7 +39,8 @@ class QPSettings(ctypes.Structure):
     _fields_ = [("rho", ctypes.c_double), ("sigma", ctypes.c_double), ("alpha", ctypes.c_double),
                 ("eps_abs", ctypes.c_double), ("eps_rel", ctypes.c_double), ("eps_prim_inf", ctypes.c_double),
                 ("max_iter", ctypes.c_int),
-                ("check_every", ctypes.c_int), ("rho_every", ctypes.c_int), ("adaptive_rho", ctypes.c_int)]
+                ("check_every", ctypes.c_int), ("rho_every", ctypes.c_int), ("adaptive_rho", ctypes.c_int),
+                ("scaling", ctypes.c_int)]
 
 
 def _fingerprint():

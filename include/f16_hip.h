@@ -129,9 +129,18 @@ int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double
                   int32_t *status, long B, long ld, void *stream);
 /* env.py:373-424 _calc_MPC_action for B aircraft: per aircraft (Ad,Bd,Cd) + current state x[18][ld]
  * + demands dem[3][ld] (p,q,r; written to x_ref[5:8] exactly as the reference does) -> first move
- * u_cmd[3][ld].  Dense condensed QP of horizon hzn (utils.py:21-167) solved by OSQP-style ADMM with the
- * settings in f16_qp_settings (rho = 0 selects the automatic start value 2 sqrt(tr P / tr A'A)).  u_seq (may be NULL) gets the full [3*hzn][ld] sequence,
- * info (may be NULL) gets [4][ld] = iterations, r_prim, r_dual, rho.
+ * u_cmd[3][ld].  Dense condensed QP of horizon hzn (utils.py:21-167) solved as the reference's call solves it
+ * (env.py:420-422: osqp.OSQP().setup(P, q, A, l, u, max_iter=40000, polish=False), every other setting at its default):
+ * OSQP's published ADMM with Ruiz equilibration (`scaling` passes, D / E / c), rho = 0.1, sigma 1e-6, alpha 1.6,
+ * termination on the UNSCALED residuals (eps 1e-3) every `check_every` iterations, rho re-estimated from the SCALED
+ * residuals every `rho_every` iterations (OSQP's own interval is wall-clock based; 100 is its no-timer constant
+ * ADAPTIVE_RHO_FIXED) and applied when it moves by more than 5x, primal-infeasibility certificate (-> NaN command +
+ * F16_ST_QP_INFEASIBLE, as OSQP returns).  Rows of A with two infinite bounds (phi, theta, lf1) take part in the
+ * equilibration and are then left out of the iteration (OSQP carries them with rho_min = 1e-6; they never bind).
+ * Opt-in alternative (the builder's rule, faster on this family of QPs): scaling = 0, rho = 0 -> no equilibration and
+ * the start value rho = 2 sqrt(tr P / tr A'A); scaling = 0, rho > 0 -> no equilibration, fixed start value.
+ * u_seq (may be NULL) gets the full [3*hzn][ld] sequence, info (may be NULL) gets [4][ld] = iterations, r_prim, r_dual
+ * (unscaled), rho.
  * Nothing the results depend on is retained between calls: the QP workspace is allocated and freed per call, stream-ordered
  * on `stream` (legal under stream capture); calls on different streams of one context do not share buffers.
  * Scheduling only: workgroups are dispatched longest-first by the iteration counts of the previous call of the same
@@ -139,6 +148,7 @@ int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double
 typedef struct f16_qp_settings {
   double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf;
   int max_iter, check_every, rho_every, adaptive_rho;
+  int scaling;     /* Ruiz equilibration passes (OSQP default 10; 0 = none) */
 } f16_qp_settings;
 void f16_qp_default_settings(f16_qp_settings *s);
 int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,

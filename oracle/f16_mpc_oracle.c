@@ -8,7 +8,8 @@
  *   (2) a second, independent checker next to oracle/mpc_oracle.py (numpy/scipy): tests/test_oracle_vs_golden.py
  *       requires both to agree (same iteration counts, x to 1e-9) on the golden QPs.
  * The ADMM follows oracle/mpc_oracle.py rule for rule:
- *   mode 0  admm_osqp_style: no scaling, rows without bounds dropped, rho0 = settings.rho or 2 sqrt(tr P / tr A'A)
+ *   mode 0  admm_osqp_style: the same rules without scaling, rows without bounds dropped, rho0 = settings.rho or
+ *           2 sqrt(tr P / tr A'A) (the builder's opt-in settings)
  *   mode 1  admm_osqp(drop_unbounded_rows = 0): OSQP's published algorithm -- Ruiz equilibration, rho vector, unscaled
  *           termination test, scaled rho estimate
  *   mode 2  the same with the unbounded rows left out of the iteration after the equilibration (what the HIP kernels do)
@@ -282,8 +283,8 @@ int f16o_admm(int n, int m_all, const double *P_in, const double *q_in, const do
   memcpy(A, A_in, sizeof(double) * (size_t)m_all * n);
   int m = m_all;
   for (int i = 0; i < m; ++i) {
-    l[i] = mode == 0 ? l_in[i] : dmax(l_in[i], -OSQP_INFTY);
-    u[i] = mode == 0 ? u_in[i] : dmin(u_in[i], OSQP_INFTY);
+    l[i] = dmax(l_in[i], -OSQP_INFTY);
+    u[i] = dmin(u_in[i], OSQP_INFTY);
     E[i] = 1.0;
   }
   for (int j = 0; j < n; ++j) D[j] = 1.0;
@@ -324,8 +325,7 @@ int f16o_admm(int n, int m_all, const double *P_in, const double *q_in, const do
   {
     int k = 0;
     for (int i = 0; i < m; ++i) {
-      const int lo = mode == 0 ? (isinf(l[i]) && l[i] < 0 && isinf(u[i]) && u[i] > 0)
-                               : (l[i] < -OSQP_INFTY * MIN_SCALING && u[i] > OSQP_INFTY * MIN_SCALING);
+      const int lo = l[i] < -OSQP_INFTY * MIN_SCALING && u[i] > OSQP_INFTY * MIN_SCALING;
       if (lo && mode != 1) continue;
       if (k != i) { memcpy(A + (size_t)k * n, A + (size_t)i * n, sizeof(double) * n); l[k] = l[i]; u[k] = u[i]; E[k] = E[i]; }
       loose[k] = lo;
@@ -344,12 +344,12 @@ int f16o_admm(int n, int m_all, const double *P_in, const double *q_in, const do
     for (int j = 0; j < n; ++j) tp += P[j * n + j];
     for (int i = 0; i < m; ++i)
       for (int j = 0; j < ncol[i]; ++j) ta += A[(size_t)i * n + j] * A[(size_t)i * n + j];
-    rho = dmin(dmax(2.0 * sqrt(tp / ta), 1e-6), 1e6);
+    rho = dmin(dmax(2.0 * sqrt(tp / ta), RHO_MIN), RHO_MAX);
   }
   const double sigma = o->sigma, alpha = o->alpha;
   int rc_f = 0;
 #define SET_RV()                                                                                                      \
-  for (int i = 0; i < m; ++i) rv[i] = mode == 0 ? rho : (loose[i] ? RHO_MIN : ((u[i] - l[i]) < RHO_TOL ? RHO_EQ * rho : rho))
+  for (int i = 0; i < m; ++i) rv[i] = loose[i] ? RHO_MIN : ((u[i] - l[i]) < RHO_TOL ? RHO_EQ * rho : rho)
 #define FACTOR()                                                                                                      \
   do {                                                                                                                \
     for (int a = 0; a < n; ++a)                                                                                       \
@@ -412,13 +412,12 @@ int f16o_admm(int n, int m_all, const double *P_in, const double *q_in, const do
       rp = r1; rd = cinv * r2;
       const double eps_p = o->eps_abs + o->eps_rel * dmax(nAx, nz);
       const double eps_d = o->eps_abs + o->eps_rel * cinv * dmax(dmax(nPx, nAty), nq);
-      const int conv = mode == 0 ? (rp <= eps_p && rd <= eps_d) : (rp < eps_p && rd < eps_d);
-      if (conv) { status = 0; break; }
+      if (rp < eps_p && rd < eps_d) { status = 0; break; }
       /* primal infeasibility certificate on dy */
       double ndy = 0.0, supp = 0.0;
       for (int i = 0; i < m; ++i) {
         ndy = dmax(ndy, fabs(E[i] * dy[i]));
-        supp += (isfinite(u[i]) ? u[i] : 0.0) * dmax(dy[i], 0.0) + (isfinite(l[i]) ? l[i] : 0.0) * dmin(dy[i], 0.0);
+        supp += u[i] * dmax(dy[i], 0.0) + l[i] * dmin(dy[i], 0.0);
       }
       if (ndy > o->eps_prim_inf && supp < -o->eps_prim_inf * ndy) {
         for (int j = 0; j < n; ++j) tn[j] = 0.0;
@@ -431,13 +430,8 @@ int f16o_admm(int n, int m_all, const double *P_in, const double *q_in, const do
         if (nat < o->eps_prim_inf * ndy) { status = 2; break; }
       }
       if (o->adaptive_rho && it % o->rho_every == 0 && it < o->max_iter) {
-        double nw;
-        if (mode == 0) nw = rho * sqrt((rp / dmax(dmax(nAx, nz), 1e-10)) / dmax(rd / dmax(dmax(dmax(nPx, nAty), nq), 1e-10), 1e-10));
-        else {
-          const double pr = r1s / (dmax(nzs, nAxs) + 1e-10), dr = r2s / (dmax(dmax(nqs, nAtys), nPxs) + 1e-10);
-          nw = rho * sqrt(pr / (dr + 1e-10));
-        }
-        nw = dmin(dmax(nw, RHO_MIN), RHO_MAX);
+        const double pr = r1s / (dmax(nzs, nAxs) + 1e-10), dr = r2s / (dmax(dmax(nqs, nAtys), nPxs) + 1e-10);
+        const double nw = dmin(dmax(rho * sqrt(pr / (dr + 1e-10)), RHO_MIN), RHO_MAX);      /* compute_rho_estimate */
         if (nw > 5 * rho || nw < rho / 5) { rho = nw; SET_RV(); FACTOR(); }
       }
     }

@@ -336,63 +336,16 @@ def mpc_qp(x_full, Ad, Bd, Cd, hzn, dt, p_dem=0.0, q_dem=0.0, r_dem=0.0):
 # ------------------------------------------------------------- QP solvers
 RHO_AUTO_SCALE = 2.0      # start value of rho when rho <= 0: RHO_AUTO_SCALE * sqrt(tr P / tr A'A) (same constant as csrc/f16_mpc.hpp)
 ADMM_DEFAULTS = dict(rho=0.0, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, eps_prim_inf=1e-4,
-                     check_every=25, rho_every=100, max_iter=40000, adaptive_rho=True)
+                     check_every=25, rho_every=100, max_iter=40000, adaptive_rho=True)      # the builder's opt-in rule
 
 
 def admm_osqp_style(P, q, A, l, u, **kw):
-    """OSQP Algorithm 1 in reduced dense form, deterministic:
-    rows with l=-inf and u=+inf are dropped (they can never bind; OSQP gives them rho_min),
-    no Ruiz scaling, termination checked every `check_every` iterations with OSQP's criteria,
-    rho re-estimated every `rho_every` iterations (OSQP's interval when built without timers)
-    and applied when it moves by more than 5x.  Returns dict(x, y, z, iters, r_prim, r_dual, rho)."""
+    """The builder's opt-in settings of the same solver (see admm_osqp below): no equilibration, rows with l = -inf and
+    u = +inf dropped, start value rho = RHO_AUTO_SCALE * sqrt(tr P / tr A'A) unless a positive rho is given -- every other
+    rule (iteration, termination test, rho update, infeasibility certificate) is admm_osqp's."""
     o = dict(ADMM_DEFAULTS)
     o.update(kw)
-    keep = ~(np.isneginf(l) & np.isposinf(u))
-    A, l, u = A[keep], l[keep], u[keep]
-    n, mrow = P.shape[0], A.shape[0]
-    rho, sigma, alpha = o["rho"], o["sigma"], o["alpha"]
-    AtA = A.T @ A
-    if not rho > 0:     # automatic start value: balance the two terms of P + rho A'A (no Ruiz scaling here)
-        rho = float(min(max(RHO_AUTO_SCALE * np.sqrt(np.trace(P) / np.trace(AtA)), 1e-6), 1e6))
-    cho = scipy.linalg.cho_factor(P + sigma * np.eye(n) + rho * AtA)
-    x, z, y = np.zeros(n), np.zeros(mrow), np.zeros(mrow)
-    it, rp, rd = 0, np.inf, np.inf
-    infeasible = False
-    for it in range(1, o["max_iter"] + 1):
-        xt = scipy.linalg.cho_solve(cho, sigma * x - q + A.T @ (rho * z - y))
-        zt = A @ xt
-        x = alpha * xt + (1 - alpha) * x
-        zr = alpha * zt + (1 - alpha) * z
-        z_new = np.clip(zr + y / rho, l, u)
-        dy = rho * (zr - z_new)
-        y = y + dy
-        z = z_new
-        if it % o["check_every"] == 0:
-            Ax, Px, Aty = A @ x, P @ x, A.T @ y
-            rp = np.abs(Ax - z).max()
-            rd = np.abs(Px + q + Aty).max()
-            np_ = max(np.abs(Ax).max(), np.abs(z).max())
-            nd_ = max(np.abs(Px).max(), np.abs(Aty).max(), np.abs(q).max())
-            if rp <= o["eps_abs"] + o["eps_rel"] * np_ and rd <= o["eps_abs"] + o["eps_rel"] * nd_:
-                break
-            # OSQP primal infeasibility certificate (all kept rows have at least one finite bound here)
-            ndy = np.abs(dy).max()
-            supp = np.sum(np.where(np.isfinite(u), u, 0) * np.maximum(dy, 0) + np.where(np.isfinite(l), l, 0) * np.minimum(dy, 0))
-            if ndy > o["eps_prim_inf"] and supp < -o["eps_prim_inf"] * ndy and \
-                    np.abs(A.T @ dy).max() < o["eps_prim_inf"] * ndy:
-                infeasible = True
-                break
-            if o["adaptive_rho"] and it % o["rho_every"] == 0:
-                new = rho * np.sqrt((rp / max(np_, 1e-10)) / max(rd / max(nd_, 1e-10), 1e-10))
-                new = min(max(new, 1e-6), 1e6)
-                if new > 5 * rho or new < rho / 5:
-                    rho = new
-                    cho = scipy.linalg.cho_factor(P + sigma * np.eye(n) + rho * AtA)
-    yfull = np.zeros(keep.size)
-    yfull[keep] = y
-    if infeasible:
-        x = np.full(n, np.nan)
-    return dict(x=x, y=yfull, z=z, iters=it, r_prim=rp, r_dual=rd, rho=rho, infeasible=infeasible)
+    return admm_osqp(P, q, A, l, u, drop_unbounded_rows=True, scaling=0, **o)
 
 
 # ---- OSQP as the reference invokes it (env.py:420-422: osqp.OSQP().setup(P, q, A, l, u, max_iter=40000, verbose=True,
@@ -456,6 +409,8 @@ def admm_osqp(P, q, A, l, u, drop_unbounded_rows=False, **kw):
     m = As.shape[0]
     eq = (us - ls) < RHO_TOL
     rho, sigma, alpha = float(o["rho"]), o["sigma"], o["alpha"]
+    if not rho > 0:     # the builder's automatic start value (only meaningful without equilibration): balance P and rho A'A
+        rho = float(min(max(RHO_AUTO_SCALE * np.sqrt(np.trace(Ps) / np.trace(As.T @ As)), RHO_MIN), RHO_MAX))
 
     def rho_vec(r):
         return np.where(loose_k, RHO_MIN, np.where(eq, RHO_EQ_OVER_RHO_INEQ * r, r))
