@@ -8,7 +8,9 @@
 // Coordinates.  OSQP iterates on xb = D^-1 x, zb = E z, yb with Pb = c D P D, qb = c D q, Ab = E A D.  Here the
 // variable is kept UNscaled (x = D xb): the linear system becomes (c P + sigma D^-2 + rho A' W A) x~ = sigma D^-2 x - c q
 // + A' E (rho zb - yb) with the row weights W = E^2 (x 1e3 on equality rows) -- the same iterates, but the Toeplitz operators
-// A, A' stay the unscaled block-Toeplitz ones (E enters as one multiply per constraint row, D only through sigma D^-2):
+// A, A' stay the unscaled block-Toeplitz ones.  The constraint variables are kept unscaled as well (z = zb / E, y = yb / E):
+// projection bounds are the original l, u, and E enters ONLY as the row weight W = E^2 in w = W (rho z - y) and in A'WA;
+// D only through sigma D^-2; c through c q and the dual residual:
 //     stage 1   t  = CCs' w_s      (3N x 6N, block upper-triangular Toeplitz)      utils.py:163 (A' part)
 //     stage 2   x~ = (P + sigma I + rho A'A)^-1 rhs        (3N x 3N dense)          OSQP linear system
 //     stage 3   z~ = CCs x~        (6N x 3N, block lower-triangular Toeplitz)       utils.py:163 (A part)
@@ -542,15 +544,19 @@ __device__ __noinline__ void ruiz_equilibrate(const double *Pg, const double *Gl
   out3[0] = De; out3[1] = Eo; out3[2] = cs;
 }
 
-// ---- A'WA as matrix-core tiles, out of line (same reason).  A'WA = sum over the kept constraint rows of w a a': the state
+// ---- A'WA as matrix-core tiles.  A'WA = sum over the kept constraint rows of w a a': the state
 // rows (6N x 3N block lower-triangular Toeplitz, never formed) as a Gram product on the matrix cores -- k-step kk covers rows
 // 4kk..4kk+3, the operand of column tile T is G_(i-j)[S r][c] gathered from LDS, the SAME value serves as the A operand of
 // tile row T and (times w) as the B operand of tile column T --, the command rows (identity) and rate rows (D = I - shift_3)
 // as a diagonal / third-off-diagonal fix-up.  gram: tile row w of this lane (24 values).
 template <int NTT>
-__device__ __noinline__ void gram_tiles(d4_t *gram, const double *Gl, const double *Wg, const double *Wcv, const double *Wrv, int N) {
+__device__ __forceinline__ void gram_tiles(d4_t *gram, const double *Gl, const double *Wg, const double *Wcv, const double *Wrv, int N) {
   const int n = 3 * N;
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lc = l & 15, lq = l >> 4;
+  const int tid = threadIdx.x, w = tid >> 6;
+  // (inlined: a real call inside the factorisation loop pins every value that lives across it to the callee-saved half of
+  //  the register file.  Opaque lane indices keep the index arithmetic from being hoisted out of that loop.)
+  int lc = tid & 15, lq = (tid & 63) >> 4;
+  asm volatile("" : "+v"(lc), "+v"(lq));
   d4_t acc[NT];
 #pragma unroll
   for (int J = 0; J < NTT; ++J) acc[J] = d4_t{0.0, 0.0, 0.0, 0.0};
@@ -602,11 +608,17 @@ __device__ __noinline__ void gram_tiles(d4_t *gram, const double *Gl, const doub
 // during the equilibration lanes 6, 14, 7 stand in for the three state rows without bounds (phi, theta, lf1).
 template <int NTT>
 __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
-  __shared__ __attribute__((aligned(16))) double wsP[WSP], ysP[WSP], xtP[XTP], Cs[2 * FN * 4 + 40];
-  __shared__ double rhs[FN], wc[FN], wr[FN + 4], yc[FN], yr[FN + 4], red[8 * 9], xcP[XTP];
+  // the iteration's zero-padded vectors in ONE block: between iterations (during a factorisation) the same memory carries
+  // one tile row of the inverse on its way to the per-lane layout (Mst, 16 x 96 doubles)
+  __shared__ __attribute__((aligned(16))) double itv[2 * WSP + 2 * XTP];
+  double *const wsP = itv, *const ysP = itv + WSP, *const xtP = itv + 2 * WSP, *const xcP = itv + 2 * WSP + XTP, *const Mst = itv;
+  static_assert(2 * WSP + 2 * XTP >= 16 * FN, "the relayout buffer must fit in the iteration vectors");
+  __shared__ __attribute__((aligned(16))) double Cs[2 * FN * 4 + 40];
+  __shared__ double rhs[FN], wc[FN], wr[FN + 4], yc[FN], yr[FN + 4], red[8 * 9];
+  __shared__ double xo_sg2[FN], xo_cq[FN], xo_q[FN], xo_cD[FN], sh_cinv;      // constants of the x-owner lanes, by variable; 1/c
   __shared__ double Dv[XTP], Es9[ES9], Ecv[FN], Erv[FN + 4], Wg[WGN], Wcv[FN], Wrv[FN + 4], nPm[FN];
   __shared__ __attribute__((aligned(16))) double Gl[27 * FAST_MAXN];
-  extern __shared__ double pxL[];       // [18][FT] this lane's 18 entries of P (termination test) | [3][FT] lane constants
+  extern __shared__ double pxL[];       // [18][FT] this lane's 18 entries of P (termination test) | [6][FT] lane constants
 
   const int N = a.N, n = 3 * N;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lc = l & 15, lq = l >> 4, blk = tid >> 4, q = lc;
@@ -628,22 +640,23 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
   const int xe = 3 * blk + (lc >> 2);
   const int xec = xe < FN ? xe : FN - 1;                        // in-range index for lanes that own no variable
   double *const wdst = kind == 1 ? wsP + WROW * blk + sub : (kind == 2 ? wc + k3 : wr + k3);
-  double *const ydst = kind == 1 ? ysP + WROW * blk + sub : (kind == 2 ? yc + k3 : yr + k3);
   const int dup = (kind == 1 && sub < 3) ? 6 : 0;              // state rows 0..2 are stored twice (stage1_load)
-  const double *const wsrc = wsP + WROW * (blk + 2 * q) + (h ? 3 : 0), *const ysrc = ysP + WROW * (blk + 2 * q) + (h ? 3 : 0);
-  double *const lcst = pxL + 18 * FT + tid;                   // lane constants: [0] 1/E  [FT] q (unscaled)  [2 FT] c D
+  const double *const wsrc = wsP + WROW * (blk + 2 * q) + (h ? 3 : 0);
+  double *const lcst = pxL + 18 * FT + tid;                   // lane constants (see below)
   // zero everything once: the pads are never written again
-  for (int i = tid; i < WSP; i += FT) { wsP[i] = 0.0; ysP[i] = 0.0; }
-  for (int i = tid; i < XTP; i += FT) { xtP[i] = 0.0; xcP[i] = 0.0; Dv[i] = 0.0; }
+  for (int i = tid; i < XTP; i += FT) Dv[i] = 0.0;                // (the iteration vectors are zeroed after each factorisation)
   for (int i = tid; i < FN + 4; i += FT) { wr[i] = 0.0; yr[i] = 0.0; Erv[i] = 0.0; Wrv[i] = 0.0; }
-  for (int i = tid; i < FN; i += FT) { rhs[i] = 0.0; wc[i] = 0.0; yc[i] = 0.0; Ecv[i] = 0.0; Wcv[i] = 0.0; nPm[i] = 0.0; }
+  for (int i = tid; i < FN; i += FT) { rhs[i] = 0.0; wc[i] = 0.0; yc[i] = 0.0; Ecv[i] = 0.0; Wcv[i] = 0.0; nPm[i] = 0.0;
+                                       xo_sg2[i] = 0.0; xo_cq[i] = 0.0; xo_q[i] = 0.0; xo_cD[i] = 0.0; }
   for (int i = tid; i < ES9; i += FT) Es9[i] = 0.0;
   for (int i = tid; i < WGN; i += FT) Wg[i] = 0.0;
 
   const double sigma = a.s.sigma, alpha = a.s.alpha;
 
   {
-    const long b = a.order ? a.order[blockIdx.x] : blockIdx.x;    // one aircraft per workgroup (grid = B)
+    // one aircraft per workgroup (grid = B).  readfirstlane: the index is uniform, so every per-aircraft pointer below lives in
+    // scalar registers instead of a VGPR pair each
+    const long b = a.order ? (long)__builtin_amdgcn_readfirstlane(a.order[blockIdx.x]) : (long)blockIdx.x;
     double *const exw = a.ext + (size_t)b * mpc_ext_doubles(N);
     const double *ex = exw;
     const double *Pg = a.Ppk + (size_t)b * (n * (n + 1) / 2);
@@ -671,24 +684,49 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
 #pragma unroll
       for (int k = 0; k < 18; ++k) pxL[k * FT + tid] = pv[k];
     };
-    d4_t acc[NT];                                              // MINUS (c P + sigma D^-2 + rho A'WA)^-1, tile row w (slot order)
+    // The inverse K^-1 of c P + sigma D^-2 + rho A'WA is computed as matrix-core tiles (tile row w on wave w) and then
+    // RE-LAID for the iterations: lane q of DPP row blk holds K^-1[3 blk + c][6 q + cc] (c < 3, cc < 6) -- the layout of the
+    // cached P entries.  Stage 2 is then 18 FMAs on ALL eight waves and ends in the same reduce3 as stage 1, which leaves
+    // x~[3 blk + c] in the lane that owns that variable (24 FMAs on six waves + a four-value reduction before, and six
+    // more registers per lane: the N = 30 instantiation spilled its Toeplitz blocks inside the iteration loop).
+    double mrow[3][6];
     double Gd[2][6][3];                                        // this lane's two Toeplitz blocks
-    // stage 2 reads the inverse in slot order (reduce4_slots): one lane-dependent register permutation per
-    // factorisation instead of twelve selects per iteration
-    auto permute_acc = [&]() {
-      const int i0 = slot_of(0, h, g), i1 = slot_of(1, h, g), i2 = slot_of(2, h, g), i3 = slot_of(3, h, g);
+    auto relayout = [&](const d4_t (&acc)[NT]) {               // acc = MINUS the inverse, tile layout
+      // (opaque copies of the lane indices: otherwise the address arithmetic below, invariant for the factorisation loop, is
+      //  hoisted to the top of the kernel and held in registers across the iteration loop -- 87 VGPRs of such values made
+      //  the N = 30 instantiation spill its operators inside the loop)
+      int lc = (threadIdx.x & 15), lq = (threadIdx.x & 63) >> 4, blk = threadIdx.x >> 4;
+      asm volatile("" : "+v"(lc), "+v"(lq), "+v"(blk));
+      const int q = lc;
 #pragma unroll
-      for (int J = 0; J < NTT; ++J) {
-        const d4_t t = acc[J];
-        acc[J][0] = sel4(t[0], t[1], t[2], t[3], i0);
-        acc[J][1] = sel4(t[0], t[1], t[2], t[3], i1);
-        acc[J][2] = sel4(t[0], t[1], t[2], t[3], i2);
-        acc[J][3] = sel4(t[0], t[1], t[2], t[3], i3);
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) mrow[c][cc] = 0.0;
+      for (int ww = 0; ww < NTT; ++ww) {
+        __syncthreads();
+        if (w == ww) {
+#pragma unroll
+          for (int J = 0; J < NTT; ++J)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) Mst[(4 * qq + lq) * FN + 16 * J + lc] = -acc[J][qq];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int i = 3 * blk + c;
+          if ((i >> 4) == ww) {
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) mrow[c][cc] = (6 * q + cc) < 16 * NTT ? Mst[(i & 15) * FN + 6 * q + cc] : 0.0;
+          }
+        }
       }
     };
     // the lane's two Toeplitz blocks (utils.py:171-197: CC[i,j] = A^(i-j) B, rows S kept, slot order of reduce6_slots)
     auto load_Gd = [&]() {
       constexpr int SR[6] = {2, 3, 4, 5, 6, 8};
+      int q = threadIdx.x & 15;
+      asm volatile("" : "+v"(q));
+      const bool h = q & 8;
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb) {
         const int d = 2 * q + bb;
@@ -700,14 +738,14 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         }
       }
     };
-    double *const tl = a.tiles ? a.tiles + (size_t)b * MPC_TILE_DOUBLES + (size_t)(w * NT * 4) * 64 + l : nullptr;
+    double *const tl = a.tiles ? a.tiles + (size_t)b * MPC_TILE_DOUBLES + tid : nullptr;      // [18][FT]: the re-laid inverse
     if (a.mode == 2) {
-      // a plan's solve starts from HBM-cold data: tiles (24 loads per lane, 512-byte runs), Toeplitz blocks (36) and the
-      // P entries (18) go out in ONE batch, ahead of everything that waits for a load, instead of three serial round trips
+      // a plan's solve starts from HBM-cold data: the inverse (18 loads per lane, 512-byte runs), Toeplitz blocks (36) and
+      // the P entries (18) go out in ONE batch, ahead of everything that waits for a load, instead of three serial round trips
 #pragma unroll
-      for (int J = 0; J < NTT; ++J)
+      for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) acc[J][qq] = w < NTT ? tl[(J * 4 + qq) * 64] : 0.0;
+        for (int cc = 0; cc < 6; ++cc) mrow[c][cc] = tl[(c * 6 + cc) * FT];
       load_Gd();
     }
     // ---- equilibration state: De = D of this lane's variable (x owners), Eo = E of this lane's constraint row, cs = c
@@ -738,29 +776,34 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         lo = act + RLB[sub] * a.dt; hi = act + RUB[sub] * a.dt;
       } else { lo = RLB[sub]; hi = RUB[sub]; }               // reference quirk: not scaled by dt (utils.py:151-152)
     }
-    lo *= Eo; hi *= Eo;
-    // rho vector (osqp auxil.c:set_rho_vec): an equality row (u - l < 1e-4 after scaling) carries 1e3 rho
-    const double eqf = (kind && hi - lo < OSQP_RHO_TOL) ? OSQP_RHO_EQ_OVER_RHO_INEQ : 1.0;
-    if (kind == 1) Wg[6 * blk + sub] = Eo * Eo * eqf;
-    else if (kind == 2) Wcv[k3] = Eo * Eo * eqf;
-    else if (kind == 3) Wrv[k3] = Eo * Eo * eqf;
-    const double sg2 = xown ? sigma / (De * De) : 0.0, qc = cs * qe;      // sigma D^-2, c q (x owners)
+    // rho vector (osqp auxil.c:set_rho_vec): an equality row (E (u - l) < 1e-4, i.e. after scaling) carries 1e3 rho
+    const double eqf = (kind && Eo * (hi - lo) < OSQP_RHO_TOL) ? OSQP_RHO_EQ_OVER_RHO_INEQ : 1.0;
+    const double Wrow = kind ? Eo * Eo : 0.0;                    // the row weight E^2: all the iteration sees of E
+    if (kind == 1) Wg[6 * blk + sub] = Wrow * eqf;
+    else if (kind == 2) Wcv[k3] = Wrow * eqf;
+    else if (kind == 3) Wrv[k3] = Wrow * eqf;
+    const double sg2 = xown ? sigma / (De * De) : 0.0;           // sigma D^-2 (x owners)
     if (xown) Dv[XOFF + xe] = sg2;                               // Dv now holds sigma D^-2 for the KKT diagonal
-    lcst[0] = 1.0 / Eo; lcst[FT] = qe; lcst[2 * FT] = cs * De;
-    const double cinv = 1.0 / cs;
+    // lane constants live in LDS (registers are the scarce resource of the iteration loop).  Per constraint row:
+    // [0] lower bound  [1] upper bound  [2] row weight W = E^2  [3] rho-vector factor  (+ [4] this lane's rho-vector
+    // entry, [5] its reciprocal: written per factorisation); per variable (x owners): sigma D^-2, c q, q, c D; 1/c in red.
+    lcst[0] = lo; lcst[FT] = hi; lcst[2 * FT] = Wrow; lcst[3 * FT] = eqf;
+    if (xown) { xo_sg2[xe] = sg2; xo_cq[xe] = cs * qe; xo_q[xe] = qe; xo_cD[xe] = cs * De; }
+    if (tid == 0) sh_cinv = 1.0 / cs;
     double *const wm = a.warm ? a.warm + (size_t)b * MPC_WARM_DOUBLES + tid : nullptr;
     if (wm && a.warm_load) {   // warm start: x, z, y of the previous solve of this plan, kept UNscaled (the equilibration of an
       const double x0 = wm[0], z0 = wm[FT], y0 = wm[2 * FT];      // OSQP-default plan is redone per solve: it depends on q)
-      if (isfinite(x0) && isfinite(z0) && isfinite(y0)) { xs = x0; z = Eo * z0; y = cs * y0 / Eo; }
+      if (isfinite(x0) && isfinite(z0) && isfinite(y0)) { xs = x0; z = z0; y = kind ? cs * y0 / Wrow : 0.0; }
     }
     double rho = a.mode == 2 ? exm[243] : a.s.rho;
     store_pv();
     __syncthreads();                                            // Wg / Wcv / Wrv / sigma D^-2 are in place
 
-    // ---- KKT matrix  c P + sigma D^-2 + rho A'WA  as matrix-core tiles (gram_tiles above)
-    d4_t gram[NT];
-    auto build_gram = [&]() { gram_tiles<NTT>(gram, Gl, Wg, Wcv, Wrv, N); };
-    auto kkt_tiles = [&](double r) {                             // acc <- c P + sigma D^-2 + r A'WA (identity on the padding)
+    // ---- KKT matrix  c P + sigma D^-2 + rho A'WA  as matrix-core tiles (gram_tiles above); formed inside the factorisation
+    // block below so that the 24 Gram values per lane do not live across the iteration loop
+    auto kkt_tiles = [&](d4_t (&acc)[NT], const d4_t (&gram)[NT], double r) {     // acc <- c P + sigma D^-2 + r A'WA (identity on the padding)
+      int lc = (threadIdx.x & 15), lq = (threadIdx.x & 63) >> 4;  // (opaque: see relayout)
+      asm volatile("" : "+v"(lc), "+v"(lq));
       if (w < NTT) {
         d4_t pp[NT];
         load_packed_tiles<NTT>(pp, Pg, n, w, lc, lq);
@@ -776,26 +819,6 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         for (int J = 0; J < NTT; ++J) acc[J] = d4_t{0.0, 0.0, 0.0, 0.0};
       }
     };
-    if (a.mode != 2) {
-      build_gram();
-      if (!(rho > 0.0)) {   // the builder's opt-in start value (no equilibration): balance the two terms of P + rho A'A
-        double tr[2] = {xown ? Pg[tri(xe, xe)] : 0.0, 0.0};
-        if (w < NTT) {
-#pragma unroll
-          for (int J = 0; J < NTT; ++J)
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-              const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
-              if (i == j && i < n) tr[1] += gram[J][qq];
-            }
-        }
-        const bool sums[2] = {true, true};
-        block_reduce<2>(tr, sums, red);
-        rho = fmin(fmax(RHO_AUTO_SCALE * sqrt(tr[0] / tr[1]), OSQP_RHO_MIN), OSQP_RHO_MAX);
-      }
-      kkt_tiles(rho);
-    }
-    if (kind) { const double w0 = Eo * (rho * eqf * z - y); wdst[0] = w0; wdst[dup] = w0; }   // start point (zero unless warm)
     int it = 0, to_check = a.s.check_every > 0 ? a.s.check_every : 1;
     double rp = INFINITY, rd = INFINITY;
     bool converged = false, infeasible = false, ok = true;
@@ -808,10 +831,9 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
 #else
 #define MSTAMP(i)
 #endif
-    bool plan_loaded = false, have_tiles = a.mode != 2;
+    bool plan_loaded = false;
     if (from_plan) {                                           // (loads issued at the top of the prologue)
       from_plan = false; plan_loaded = true;
-      permute_acc();
     }
     // outer loop: one trip per KKT factorisation (rho changes at most every rho_every iterations).
     while (!done) {
@@ -823,20 +845,38 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         if (plan_loaded) {
           plan_loaded = false;
         } else {
-          if (!have_tiles) { build_gram(); kkt_tiles(rho); }   // a rho update (or the first one inside a plan's solve)
-          have_tiles = false;
-          ok = mfma_inverse<NTT>(acc, Cs, acc) && ok;
-          if (a.mode == 1) {                                   // prepare: keep the factorisation and its rho, no iterations
-            if (w < NTT) {
+          {
+            d4_t gram[NT], acc[NT];
+            gram_tiles<NTT>(gram, Gl, Wg, Wcv, Wrv, N);
+            if (!(rho > 0.0)) {   // the builder's opt-in start value (no equilibration): balance the two terms of P + rho A'A
+              int lc_ = (threadIdx.x & 15), lq_ = (threadIdx.x & 63) >> 4;
+              asm volatile("" : "+v"(lc_), "+v"(lq_));
+              double tr[2] = {xown ? Pg[tri(xe, xe)] : 0.0, 0.0};
+              if (w < NTT) {
 #pragma unroll
-              for (int J = 0; J < NTT; ++J)
+                for (int J = 0; J < NTT; ++J)
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) tl[(J * 4 + qq) * 64] = acc[J][qq];
+                  for (int qq = 0; qq < 4; ++qq) {
+                    const int i = 16 * w + 4 * qq + lq_, j = 16 * J + lc_;
+                    if (i == j && i < n) tr[1] += gram[J][qq];
+                  }
+              }
+              const bool sums[2] = {true, true};
+              block_reduce<2>(tr, sums, red);
+              rho = fmin(fmax(RHO_AUTO_SCALE * sqrt(tr[0] / tr[1]), OSQP_RHO_MIN), OSQP_RHO_MAX);
             }
+            kkt_tiles(acc, gram, rho);
+            ok = mfma_inverse<NTT>(acc, Cs, acc) && ok;
+            relayout(acc);
+          }
+          if (a.mode == 1) {                                   // prepare: keep the factorisation and its rho, no iterations
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+              for (int cc = 0; cc < 6; ++cc) tl[(c * 6 + cc) * FT] = mrow[c][cc];
             if (tid == 0) { exm[243] = rho; exm[244] = ok ? 1.0 : 0.0; }
             done = true;
           }
-          permute_acc();
           load_Gd();                                           // after the factorisation: nothing big is live across it
         }
 #ifdef F16_EXP_STAMPM
@@ -844,90 +884,105 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         t0 = tP2;
 #endif
       }
-      const double rho_o = rho * eqf, rinv = 1.0 / rho_o;      // this lane's entry of the rho vector
+      // the iteration vectors (their memory carried the inverse during the re-layout): zero pads, then w = W (rho z - y) of
+      // the current point (zero at a cold start)
+      __syncthreads();
+      for (int i = tid; i < 2 * WSP + 2 * XTP; i += FT) itv[i] = 0.0;
+      __syncthreads();
+      {
+        const double ro = rho * lcst[3 * FT];                    // this lane's entry of the rho vector
+        lcst[4 * FT] = ro; lcst[5 * FT] = 1.0 / ro;
+        if (kind) { const double w0 = lcst[2 * FT] * (ro * z - y); wdst[0] = w0; wdst[dup] = w0; }
+      }
       bool refactor = false;
       if (!ok || a.s.max_iter <= 0) done = true;
       __syncthreads();
     while (!done && !refactor) {
       ++it;
-      // ---- A: rhs = sigma D^-2 x - c q + A' E (rho zb - yb)
+      // ---- A: rhs = sigma D^-2 x - c q + A' W (rho z - y)
       {
         double wv[12], o1[3];
         stage1_load(wsrc, wv);
-        const double wce = wc[xec], wre = wr[xec], wrn = wr[xec + 3];
+        const double wce = wc[xec], wre = wr[xec], wrn = wr[xec + 3], sgl = xo_sg2[xec], qcl = xo_cq[xec];
         MPC_PHASE();
         stage1_fma(Gd, wv, o1);
         const double t = reduce3(o1[0], o1[1], o1[2], h, g);
-        if (xown) rhs[xe] = sg2 * xs - qc + (t + wce + (wre - wrn));
+        if (xown) rhs[xe] = sgl * xs - qcl + (t + wce + (wre - wrn));
       }
       MSTAMP(0)
       __syncthreads();
       MSTAMP(1)
-      // ---- B: x~ = Minv rhs from the accumulators (element (16w + 4 slot_of(qq) + lq, 16J + lc) in acc[J][qq])
-      if (w < NTT) {
-        d4_t part = {0.0, 0.0, 0.0, 0.0};
-        double rj[NTT];
+      // ---- B: x~ = K^-1 rhs, three rows x six columns per lane; reduce3 leaves x~[3 blk + c] in lane 4c of the row
+      double xt_own;
+      {
+        double rj[6], p3[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-        for (int J = 0; J < NTT; ++J) rj[J] = rhs[16 * J + lc];
+        for (int cc = 0; cc < 6; ++cc) rj[cc] = rhs[6 * q + cc];
         MPC_PHASE();
 #pragma unroll
-        for (int J = 0; J < NTT; ++J) {
+        for (int cc = 0; cc < 6; ++cc)
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq) part[qq] = fma(acc[J][qq], rj[J], part[qq]);
-        }
-        const double v = reduce4_slots(part);
-        const int row = 16 * w + (lc & 12) + lq;
-        if ((lc & 3) == 0 && row < n) xtP[XOFF + row] = -v;
+          for (int c = 0; c < 3; ++c) p3[c] = fma(mrow[c][cc], rj[cc], p3[c]);
+        xt_own = reduce3(p3[0], p3[1], p3[2], h, g);
+        if (xown) xtP[XOFF + xe] = xt_own;
       }
       MSTAMP(2)
       __syncthreads();
       MSTAMP(3)
-      // ---- C: zb~ = E A x~, relaxation, projection, dual update
+      // ---- C: z~ = A x~, relaxation, projection, dual update (unscaled z, y = yb / E)
+      double wnext = 0.0;
       {
         double xv[6], o3[6];
         stage3_load(xtP + XOFF + 3 * (blk - 2 * q - 1), xv);
-        const double xte = xtP[XOFF + xec], xk = xtP[XOFF + k3], xkm = xtP[XOFF + k3 - 3];
+        const double xk = xtP[XOFF + k3], xkm = xtP[XOFF + k3 - 3], lo = lcst[0], hi = lcst[FT];
+        const double Wl = lcst[2 * FT], rho_o = lcst[4 * FT], rinv = lcst[5 * FT];
         MPC_PHASE();
         stage3_fma(Gd, xv, o3);
         const double zs = reduce6_slots(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], g, e);
-        if (xown) xs = alpha * xte + (1 - alpha) * xs;
+        if (xown) xs = alpha * xt_own + (1 - alpha) * xs;
         if (kind) {
-          const double zt = Eo * (kind == 1 ? zs : (kind == 2 ? xk : xk - xkm));
+          const double zt = kind == 1 ? zs : (kind == 2 ? xk : xk - xkm);
           const double zr = alpha * zt + (1 - alpha) * z;
           const double zn = fmin(fmax(fma(y, rinv, zr), lo), hi);
           dy = rho_o * (zr - zn);
           y = y + dy;
           z = zn;
+          wnext = Wl * (rho_o * z - y);                          // w = W (rho z - y) for the next iteration
         }
       }
       const bool check = --to_check == 0 || it >= a.s.max_iter;      // it % check_every == 0, without the division
       if (to_check == 0) to_check = a.s.check_every;
       if (check) {
-        // ---- residuals (OSQP termination test on the UNSCALED problem): A x, P x, A' E yb / c.  x goes to its own zero-padded
+        // ---- residuals (OSQP termination test on the UNSCALED problem): A x, P x, A' W y / c.  x goes to its own zero-padded
         // buffer (x~ may still be read by slower waves), E yb to the state-row layout; one barrier, then everything of the
         // test in one reduction (the two quantities of the primal-infeasibility certificate ride along)
-        if (kind) { const double ye = Eo * y; ydst[0] = ye; ydst[dup] = ye; }
+        const double Wt = lcst[2 * FT], cinv = sh_cinv;
+        int blk_ = blk, q_ = q;                                   // (opaque: keep the test's address arithmetic inside the test)
+        asm volatile("" : "+v"(blk_), "+v"(q_));
+        double *const ydst = kind == 1 ? ysP + WROW * blk_ + sub : (kind == 2 ? yc + 3 * blk_ + sub : yr + 3 * blk_ + sub);
+        const double *const ysrc = ysP + WROW * (blk_ + 2 * q_) + ((q_ & 8) ? 3 : 0);
+        if (kind) { const double ye = Wt * y; ydst[0] = ye; ydst[dup] = ye; }
         if (xown) xcP[XOFF + xe] = xs;
         __syncthreads();
         double o3[6], o1[3], px3[3] = {0.0, 0.0, 0.0};
-        { double xv[6]; stage3_load(xcP + XOFF + 3 * (blk - 2 * q - 1), xv); stage3_fma(Gd, xv, o3); }
+        { double xv[6]; stage3_load(xcP + XOFF + 3 * (blk_ - 2 * q_ - 1), xv); stage3_fma(Gd, xv, o3); }
         const double axs = reduce6_slots(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], g, e);
         { double wv[12]; stage1_load(ysrc, wv); stage1_fma(Gd, wv, o1); }
         const double atys = reduce3(o1[0], o1[1], o1[2], h, g);
 #pragma unroll
         for (int cc = 0; cc < 6; ++cc) {                          // P x from the cached entries (zeros outside the matrix)
-          const double xv = xcP[XOFF + 6 * q + cc];
+          const double xv = xcP[XOFF + 6 * q_ + cc];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) px3[c] = fma(pxL[(cc * 3 + c) * FT + tid], xv, px3[c]);
+          for (int c = 0; c < 3; ++c) px3[c] = fma(pxL[(cc * 3 + c) * FT + 16 * blk_ + q_], xv, px3[c]);
         }
         const double px = reduce3(px3[0], px3[1], px3[2], h, g);
-        const double Ei = lcst[0], qu = lcst[FT];
-        double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};              // r1, |Ax|, |z|, r2, |Px|, |A'y|, |q|, |E dy|, support(dy)
+        const double qu = xo_q[xec];
+        double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};              // r1, |Ax|, |z|, r2, |Px|, |A'y|, |q|, |E dyb|, support(dyb)
         double ax = 0.0, aty = 0.0;
         if (kind) {
           ax = kind == 1 ? axs : (kind == 2 ? xcP[XOFF + k3] : xcP[XOFF + k3] - xcP[XOFF + k3 - 3]);
-          v[0] = fabs(ax - z * Ei); v[1] = fabs(ax); v[2] = fabs(z * Ei);
-          v[7] = fabs(Eo * dy); v[8] = hi * fmax(dy, 0.0) + lo * fmin(dy, 0.0);
+          v[0] = fabs(ax - z); v[1] = fabs(ax); v[2] = fabs(z);
+          v[7] = Wt * fabs(dy); v[8] = Wt * (lcst[FT] * fmax(dy, 0.0) + lcst[0] * fmin(dy, 0.0));
         }
         if (xown) {
           aty = cinv * (atys + yc[xe] + (yr[xe] - yr[xe + 3]));
@@ -942,7 +997,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
           // OSQP primal-infeasibility certificate on dy (auxil.c:is_primal_infeasible)
           const double ndy = v[7], supp = v[8];
           if (ndy > a.s.eps_prim_inf && supp < -a.s.eps_prim_inf * ndy) {
-            if (kind) { const double de = Eo * dy; ydst[0] = de; ydst[dup] = de; }
+            if (kind) { const double de = Wt * dy; ydst[0] = de; ydst[dup] = de; }
             __syncthreads();
             { double wv[12]; stage1_load(ysrc, wv); stage1_fma(Gd, wv, o1); }
             const double t = reduce3(o1[0], o1[1], o1[2], h, g);
@@ -955,9 +1010,9 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
             if (it >= a.s.max_iter) done = true;
             else if (a.s.adaptive_rho && it % a.s.rho_every == 0) {
               // auxil.c:compute_rho_estimate on the SCALED residuals: ||Ab xb - zb||, ||Pb xb + qb + Ab' yb|| and their norms
-              const double cD = lcst[2 * FT];
+              const double cD = xo_cD[xec], Er = sqrt(Wt);
               double s[7] = {0, 0, 0, 0, 0, 0, 0};
-              if (kind) { s[0] = fabs(Eo * ax - z); s[1] = fabs(Eo * ax); s[2] = fabs(z); }
+              if (kind) { s[0] = Er * fabs(ax - z); s[1] = Er * fabs(ax); s[2] = Er * fabs(z); }
               if (xown) { s[3] = cD * fabs(px + qu + aty); s[4] = cD * fabs(px); s[5] = cD * fabs(aty); s[6] = cD * fabs(qu); }
               const bool mx[7] = {false, false, false, false, false, false, false};
               block_reduce<7>(s, mx, red);
@@ -968,8 +1023,9 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
           }
         }
       }
-      // w = E (rho zb - yb) for the next iteration
-      if (kind) { const double wn = Eo * ((refactor ? rho * eqf : rho_o) * z - y); wdst[0] = wn; wdst[dup] = wn; }
+      if (kind) {
+        wdst[0] = wnext; wdst[dup] = wnext;                    // (after a rho update the next factorisation rewrites it)
+      }
       MSTAMP(4)
       __syncthreads();
       MSTAMP(5)
@@ -980,7 +1036,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
     if (a.mode == 1) return;                                   // a plan has no solution yet
     if (wm) {                                                  // keep the solution for the next warm start
       const bool good = converged && !infeasible;
-      wm[0] = good ? xs : NAN; wm[FT] = good ? z / Eo : NAN; wm[2 * FT] = good ? Eo * y * cinv : NAN;
+      wm[0] = good ? xs : NAN; wm[FT] = good ? z : NAN; wm[2 * FT] = good ? lcst[2 * FT] * y * sh_cinv : NAN;
     }
     if (xown) {
       if (xe < 3) a.ucmd[xe * a.ld + b] = infeasible ? NAN : xs;
@@ -1037,7 +1093,7 @@ int mpc_fast_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
   if (a.B > 0x7fffffffL) return set_error(F16_EINVAL, "batch too large for one launch");
   const unsigned grid = (unsigned)a.B;
   const int nt = (3 * a.N + 15) / 16;       // 16x16 tiles per side of the KKT matrix, instantiated for 2 / 4 / 6
-  constexpr size_t dyn = 21 * FT * sizeof(double);      // per-lane P entries for the termination test + lane constants (86 KB)
+  constexpr size_t dyn = 24 * FT * sizeof(double);      // per-lane P entries for the termination test + lane constants (98 KB)
   {   // static + dynamic LDS exceed 64 KB: opt in, once per device (not per launch: a plan's solve may run under capture)
     static std::mutex mu;
     static bool ready[64] = {};
