@@ -570,18 +570,23 @@ __device__ __forceinline__ void gram_tiles(d4_t *gram, const double *Gl, const d
     }
     const int colw = 16 * w + lc;
     const int jW = colw < n ? colw / 3 : 1 << 20, offW = (colw - 3 * (colw / 3)) - 27 * (colw / 3);
+    // causality: row (i, r) of the state block has entries only in columns of steps j <= i, so column tile T sees nothing of
+    // the k-steps before kk0(T) = 6 floor(16 T / 3) / 4 -- tile (w, J) starts at kk0(max(w, J)): 620 instead of 1,620
+    // tile-k-steps at N = 30
     const int nk = (6 * N + 3) >> 2;
-    for (int kk = 0; kk < nk; ++kk) {
+    for (int kk = (6 * ((16 * w) / 3)) >> 2; kk < nk; ++kk) {
       const int rw = 4 * kk + lq, i = rw / 6, rr = rw - 6 * i;
       const int base = 27 * i + 3 * (rr < 5 ? rr + 2 : 8);
       const double wgt = Wg[rw];                             // 0 beyond row 6N
       const bool vi = i < N;
       const double a_op = (vi && i >= jW) ? Gl[base + offW] : 0.0;
-      double b_op[NTT];
 #pragma unroll
-      for (int T = 0; T < NTT; ++T) b_op[T] = (vi && i >= jT[T]) ? Gl[base + offT[T]] * wgt : 0.0;
-#pragma unroll
-      for (int J = 0; J < NTT; ++J) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op[J], acc[J], 0, 0, 0);
+      for (int J = 0; J < NTT; ++J) {
+        if (kk >= ((6 * ((16 * J) / 3)) >> 2)) {             // (uniform)
+          const double b_op = (vi && i >= jT[J]) ? Gl[base + offT[J]] * wgt : 0.0;
+          acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op, acc[J], 0, 0, 0);
+        }
+      }
     }
 #pragma unroll
     for (int J = 0; J < NTT; ++J)
@@ -826,7 +831,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
     bool from_plan = a.mode == 2;                              // first factorisation comes out of the plan
     if (from_plan && !(exm[244] > 0.5)) ok = false;
 #ifdef F16_EXP_STAMPM
-    unsigned long long tS[6] = {0, 0, 0, 0, 0, 0}, tP1 = 0, tP2 = 0, t0 = 0;
+    unsigned long long tS[6] = {0, 0, 0, 0, 0, 0}, tP1 = 0, tP2 = 0, t0 = 0, tF[5] = {0, 0, 0, 0, 0};
 #define MSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t1 = __builtin_amdgcn_s_memtime(); tS[i] += t1 - t0; t0 = t1; }
 #else
 #define MSTAMP(i)
@@ -847,7 +852,14 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
         } else {
           {
             d4_t gram[NT], acc[NT];
+#ifdef F16_EXP_STAMPM
+#define FSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); tF[i] = __builtin_amdgcn_s_memtime(); }
+#else
+#define FSTAMP(i)
+#endif
+            FSTAMP(0)
             gram_tiles<NTT>(gram, Gl, Wg, Wcv, Wrv, N);
+            FSTAMP(1)
             if (!(rho > 0.0)) {   // the builder's opt-in start value (no equilibration): balance the two terms of P + rho A'A
               int lc_ = (threadIdx.x & 15), lq_ = (threadIdx.x & 63) >> 4;
               asm volatile("" : "+v"(lc_), "+v"(lq_));
@@ -866,8 +878,11 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
               rho = fmin(fmax(RHO_AUTO_SCALE * sqrt(tr[0] / tr[1]), OSQP_RHO_MIN), OSQP_RHO_MAX);
             }
             kkt_tiles(acc, gram, rho);
+            FSTAMP(2)
             ok = mfma_inverse<NTT>(acc, Cs, acc) && ok;
+            FSTAMP(3)
             relayout(acc);
+            FSTAMP(4)
           }
           if (a.mode == 1) {                                   // prepare: keep the factorisation and its rho, no iterations
 #pragma unroll
@@ -1056,7 +1071,8 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
 #ifdef F16_EXP_STAMPM
     __syncthreads();      // diagnostic build: aircraft 0's u_seq column is replaced by the stamps
     if ((tid & 63) == 0 && a.useq && b == 0) for (int i = 0; i < 6; ++i) a.useq[(6 * (tid >> 6) + i) * a.ld] = (double)tS[i] / it;
-    if (tid == 0 && a.useq && b == 0) { a.useq[48 * a.ld] = (double)(tP1 - tP0); a.useq[49 * a.ld] = (double)(tP2 - tP1); }
+    if (tid == 0 && a.useq && b == 0) { a.useq[48 * a.ld] = (double)(tP1 - tP0); a.useq[49 * a.ld] = (double)(tP2 - tP1);
+      for (int i = 0; i < 4; ++i) a.useq[(66 + i) * a.ld] = (double)(tF[i + 1] - tF[i]); }
     if (tid < 16 && a.useq && b == 0) a.useq[(50 + tid) * a.ld] = g_inv_stamp[tid];
 #endif
   }
