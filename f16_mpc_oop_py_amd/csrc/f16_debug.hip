@@ -55,6 +55,7 @@ __global__ __launch_bounds__(64) void k_dbg_table(const double *__restrict__ tab
       const bool hi_a = ca.j > N_A2 - 2;
       if (hi_a) { ja = N_A2 - 2; a1.j = ja; a1.l = 1.0; a1.m = 0.0; if (a > cT[OFF_BP_A1 + N_A2 - 1]) st |= ST_ALPHA2; }
     }
+    const W4 W1 = bil_weights(a1, bx);
     double v;
     if (L.dims == 0) {
       v = lerp(cT[OFF_ETA + cd.j], cT[OFF_ETA + cd.j + 1], dx);
@@ -67,10 +68,10 @@ __global__ __launch_bounds__(64) void k_dbg_table(const double *__restrict__ tab
       const int sa = L.stride, sb = L.stride * L.na;
       const double *p2 = cT + L.off + (cb.j * L.na + ja) * sa + L.k;
       if (L.dims == 2) {
-        v = bil4(ld4(p2, sa, sb), a1, bx);
+        v = bil4w(ld4(p2, sa, sb), a1, bx, W1);
       } else {
         const int sd = L.stride * L.na * N_B1;
-        v = lerp(bil4(ld4(p2 + cd.j * sd, sa, sb), a1, bx), bil4(ld4(p2 + (cd.j + 1) * sd, sa, sb), a1, bx), dx);
+        v = lerp(bil4w(ld4(p2 + cd.j * sd, sa, sb), a1, bx, W1), bil4w(ld4(p2 + (cd.j + 1) * sd, sa, sb), a1, bx, W1), dx);
         if (offd) st |= ST_EL;
       }
       if (offa) st |= ST_ALPHA1;

@@ -85,13 +85,16 @@ __global__ __launch_bounds__(BLOCK) void k_nlplant(DynArgs a) {
 template <int BLOCK, int FI>
 __global__ __launch_bounds__(BLOCK) void k_rollout(DynArgs a) {
   __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
+  // the four inputs of a lane are constant over the rollout and used once per step: kept in lane-indexed (conflict-free) LDS
+  // slots rather than in eight registers that the 512-lane instantiation (256 registers per lane) spilled and reloaded per step
+  __shared__ double us[4][BLOCK];
   if (a.fi == 1) stage_tables(tab, a.tab);
   for (long b = (long)blockIdx.x * BLOCK + threadIdx.x; b < a.B; b += (long)gridDim.x * BLOCK) {
-    double x[18], u[4];
+    double x[18];
 #pragma unroll
     for (int k = 0; k < 18; ++k) x[k] = a.out[k * a.ld + b];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) u[k] = a.u[k * a.ld + b];
+    for (int k = 0; k < 4; ++k) us[k][threadIdx.x] = a.u[k * a.ld + b];
     int st = a.status ? a.status[b] : 0;
     double *tr = a.traj ? a.traj + b : nullptr;
     int until_store = a.traj_every;
@@ -99,7 +102,9 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DynArgs a) {
       // env.py:117-124: the reference exit()s; here the aircraft is frozen and flagged
       if (!(a.flags & FLAG_NO_ENVELOPE) && outside_envelope(x)) st |= ST_ENVELOPE;
       if (!(st & ST_ENVELOPE)) {
-        double xd[18];
+        double xd[18], u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = us[k][threadIdx.x];
         calc_xdot<FI>((const double *)tab, a.lofi, x, u, xd, a.xcg, a.fi, a.flags, st);
 #pragma unroll
         for (int k = 0; k < 18; ++k) x[k] += xd[k] * a.dt;   // env.py:126

@@ -169,6 +169,17 @@ F16_DEV Q4 ld4(TP p, int sa, int sb) { Q4 c; c.f00 = p[0]; c.f10 = p[sa]; c.f01 
 F16_DEV double bil4(const Q4 &c, const Axis &a, const Axis &b) {   // alpha collapsed first, then beta (mexndinterp.c:178-209)
   return lerp(lerp(c.f00, c.f10, a), lerp(c.f01, c.f11, a), b);
 }
+// Default build: a bilinear interpolation as a weighted sum of the four corners.  The weights depend on the (alpha, beta)
+// cell only, so the 31 bilinear evaluations of a plant call share two weight sets (ALPHA1 x BETA1, ALPHA2 x BETA1): four
+// operations each instead of the six of the nested form, <= 2 ulp away from it, and still EXACT on a grid node (the
+// weights are then 0 / 1).  F16_STRICT keeps the reference's nested form (mexndinterp.c:178-209).
+struct W4 { double w00, w10, w01, w11; };
+F16_DEV W4 bil_weights(const Axis &a, const Axis &b) { W4 w; w.w00 = a.m * b.m; w.w10 = a.l * b.m; w.w01 = a.m * b.l; w.w11 = a.l * b.l; return w; }
+#ifdef F16_FAST_DIV
+F16_DEV double bil4w(const Q4 &c, const Axis &, const Axis &, const W4 &w) { return w.w00 * c.f00 + w.w10 * c.f10 + w.w01 * c.f01 + w.w11 * c.f11; }
+#else
+F16_DEV double bil4w(const Q4 &c, const Axis &a, const Axis &b, const W4 &) { return bil4(c, a, b); }
+#endif
 #ifndef F16_PHASE_MASK
 #define F16_PHASE_MASK 0x7        // LDS / memory instructions stay in their phase, ALU instructions may float (2 % over 0)
 #endif
@@ -215,6 +226,8 @@ F16_DEV void aero_totals_phased(TP T, const double *xu, double xcg, unsigned fla
   const Axis a1 = br_axis(ca), b = br_axis(cb), d1 = br_axis(c1), d2 = br_axis(c2);
   Axis a2 = a1;
   if (hi_a) { a2.j = N_A2 - 2; a2.l = 1.0; a2.m = 0.0; }
+  // (each weight set is formed inside the phase that uses it -- W1 twice, W2 in phase 4 only -- to keep live ranges short:
+  //  the 512-lane workgroup has 256 registers per lane)
   TP g = T + OFF_G1A + ca.j * S_G1A, h = T + OFF_G1B + j2 * S_G1B;
   // (2) longitudinal: G3A (3-D + el = 0 plane), G2B lef, pitch damping, eta_el
   {
@@ -231,11 +244,12 @@ F16_DEV void aero_totals_phased(TP T, const double *xu, double xcg, unsigned fla
     }
     const double m0 = g[11], m1 = g[S_G1A + 11], e0 = T[OFF_ETA + c1.j], e1 = T[OFF_ETA + c1.j + 1];
     F16_PHASE();
+    const W4 W1 = bil_weights(a1, b);
     double Cf[3], dC[3], dQ[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      Cf[k] = lerp(bil4(qlo[k], a1, b), bil4(qhi[k], a1, b), d1);
-      dC[k] = bil4(ql[k], a2, b) - bil4(q0[k], a1, b);                         // hifi_C_lef
+      Cf[k] = lerp(bil4w(qlo[k], a1, b, W1), bil4w(qhi[k], a1, b, W1), d1);
+      dC[k] = bil4(ql[k], a2, b) - bil4w(q0[k], a1, b, W1);                            // hifi_C_lef
       const double Cq = lerp(g0[k], g1[k], a1), dq = lerp(h0[k], h1[k], a2);
       dQ[k] = kq * (Cq + (k == 1 ? dC[k] : dq) * dlef);                        // dXdQ, dZdQ (reference quirk :339), dMdQ
     }
@@ -260,17 +274,18 @@ F16_DEV void aero_totals_phased(TP T, const double *xu, double xcg, unsigned fla
 #pragma unroll
     for (int k = 0; k < 7; ++k) qa[k] = ld4(pa + k, S_G2A, S_G2A * N_A1);
     F16_PHASE();
-    const double Cy = bil4(qa[0], a1, b);
+    const W4 W1 = bil_weights(a1, b);
+    const double Cy = bil4w(qa[0], a1, b, W1);
     base[0] = Cy; base0[0] = Cy;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      base[k + 1] = lerp(bil4(qlo[k], a1, b), bil4(qhi[k], a1, b), d2);
-      base0[k + 1] = bil4(q0[k], a1, b);
+      base[k + 1] = lerp(bil4w(qlo[k], a1, b, W1), bil4w(qhi[k], a1, b, W1), d2);
+      base0[k + 1] = bil4w(q0[k], a1, b, W1);
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      dr30[k] = bil4(qa[1 + k], a1, b) - base0[k];                              // hifi_rudder
-      da20[k] = bil4(qa[4 + k], a1, b) - base0[k];                              // hifi_ailerons
+      dr30[k] = bil4w(qa[1 + k], a1, b, W1) - base0[k];                              // hifi_rudder
+      da20[k] = bil4w(qa[4 + k], a1, b, W1) - base0[k];                              // hifi_ailerons
     }
   }
   F16_PHASE();
@@ -288,10 +303,11 @@ F16_DEV void aero_totals_phased(TP T, const double *xu, double xcg, unsigned fla
     }
     const double nb0 = g[9], nb1 = g[S_G1A + 9], lb0 = g[10], lb1 = g[S_G1A + 10];
     F16_PHASE();
+    const W4 W2 = bil_weights(a2, b);
     double dl[3], dA[3], dR[3], dP[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const double Clef = bil4(ql[k], a2, b), Ca20lef = bil4(qal[k], a2, b);
+      const double Clef = bil4w(ql[k], a2, b, W2), Ca20lef = bil4w(qal[k], a2, b, W2);
       double Cr = lerp(r0[k], r1v[k], a1);
       if (k == 2 && !(flags & FLAG_FIX_CLR)) Cr = 0.0;                          // reference defect: _CLr never loaded
       const double Cp = lerp(p0[k], p1[k], a1), dCr = lerp(hr0[k], hr1[k], a2), dCp = lerp(hp0[k], hp1[k], a2);
@@ -360,10 +376,11 @@ F16_DEV void aero_part(TP T, const double *xu, unsigned flags, double *out, int 
     const Axis a1 = br_axis(ca), b = br_axis(cb), d1 = br_axis(cd);
     Axis a2 = a1;
     if (hi_a) { a2.j = N_A2 - 2; a2.l = 1.0; a2.m = 0.0; }
+    const W4 W1 = bil_weights(a1, b), W2 = bil_weights(a2, b);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const double Cf = lerp(bil4(qlo[k], a1, b), bil4(qhi[k], a1, b), d1);
-      const double dC = bil4(ql[k], a2, b) - bil4(q0[k], a1, b);             // hifi_C_lef :1892-1899
+      const double Cf = lerp(bil4w(qlo[k], a1, b, W1), bil4w(qhi[k], a1, b, W1), d1);
+      const double dC = bil4w(ql[k], a2, b, W2) - bil4w(q0[k], a1, b, W1);             // hifi_C_lef :1892-1899
       out[k] = (k == 2 ? Cf * lerp(e0, e1, d1) : Cf) + dC * dlef + (k == 1 ? kq * (dC * dlef) * Q : 0.0);   // dZdQ quirk
     }
   } else if (PART == 3) {
@@ -394,15 +411,16 @@ F16_DEV void aero_part(TP T, const double *xu, unsigned flags, double *out, int 
     const Axis a1 = br_axis(ca), b = br_axis(cb), d2 = br_axis(cd);
     Axis a2 = a1;
     if (hi_a) { a2.j = N_A2 - 2; a2.l = 1.0; a2.m = 0.0; }
+    const W4 W1 = bil_weights(a1, b), W2 = bil_weights(a2, b);
     double base[3], base0[3], dr30[3], da20[3];
-    base[0] = base0[0] = bil4(qa[0], a1, b);
+    base[0] = base0[0] = bil4w(qa[0], a1, b, W1);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      base[k + 1] = lerp(bil4(qlo[k], a1, b), bil4(qhi[k], a1, b), d2);
-      base0[k + 1] = bil4(q0[k], a1, b);
+      base[k + 1] = lerp(bil4w(qlo[k], a1, b, W1), bil4w(qhi[k], a1, b, W1), d2);
+      base0[k + 1] = bil4w(q0[k], a1, b, W1);
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { dr30[k] = bil4(qa[1 + k], a1, b) - base0[k]; da20[k] = bil4(qa[4 + k], a1, b) - base0[k]; }
+    for (int k = 0; k < 3; ++k) { dr30[k] = bil4w(qa[1 + k], a1, b, W1) - base0[k]; da20[k] = bil4w(qa[4 + k], a1, b, W1) - base0[k]; }
     F16_PHASE();
     TP pb = T + OFF_G2B + n2 * S_G2B;
     Q4 ql[3], qal[3];
@@ -411,7 +429,7 @@ F16_DEV void aero_part(TP T, const double *xu, unsigned flags, double *out, int 
     F16_PHASE();
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const double Clef = bil4(ql[k], a2, b), Ca20lef = bil4(qal[k], a2, b);
+      const double Clef = bil4w(ql[k], a2, b, W2), Ca20lef = bil4w(qal[k], a2, b, W2);
       out[k] = base[k] + (Clef - base0[k]) * dlef + (da20[k] + (Ca20lef - Clef - da20[k]) * dlef) * dail + dr30[k] * drud;
     }
   } else {
@@ -610,7 +628,10 @@ F16_DEV void plant_pre(const double *xu, Pre &p, double *xdot) {
   F16_SINCOS(theta, &p.st, &p.ct);
   F16_SINCOS(phi, &p.sphi, &p.cphi);
   F16_SINCOS(psi, &spsi, &cpsi);
-#ifdef F16_FAST_TAN
+#ifdef F16_FAST_DIV
+  const double rct = f16_rcp(p.ct);
+  const double tt = p.st * rct;
+#elif defined(F16_FAST_TAN)
   const double tt = p.st / p.ct;
 #else
   const double tt = tan(theta);
@@ -624,7 +645,11 @@ F16_DEV void plant_pre(const double *xu, Pre &p, double *xdot) {
   xdot[2] = U * st - V * (sphi * ct) - W * (cphi * ct);
   xdot[3] = P + tt * (Q * sphi + R * cphi);
   xdot[4] = Q * cphi - R * sphi;
+#ifdef F16_FAST_DIV
+  xdot[5] = (Q * sphi + R * cphi) * rct;
+#else
   xdot[5] = (Q * sphi + R * cphi) / ct;
+#endif
 }
 
 // Force equations (C/nlplant.c:383-405): xdot[6..8].
@@ -636,9 +661,15 @@ F16_DEV void plant_forces(const double *xu, const Pre &p, double Cx_tot, double 
   const double Udot = R * V - Q * W - g * st + F16_DIVC(qbar * S * Cx_tot, m) + F16_DIVC(Thr, m);
   const double Vdot = P * W - R * U + g * ct * sphi + F16_DIVC(qbar * S * Cy_tot, m);
   const double Wdot = Q * U - P * V + g * ct * cphi + F16_DIVC(qbar * S * Cz_tot, m);
+#ifdef F16_FAST_DIV      // reciprocals by v_rcp_f64 + two Newton steps (<= 1 ulp) instead of three IEEE division sequences
+  xdot[6] = (U * Udot + V * Vdot + W * Wdot) * f16_rcp(vt);
+  xdot[7] = (U * Wdot - W * Udot) * f16_rcp(U * U + W * W);
+  xdot[8] = (Vdot * vt - V * xdot[6]) * f16_rcp(vt * vt * cb);
+#else
   xdot[6] = (U * Udot + V * Vdot + W * Wdot) / vt;
   xdot[7] = (U * Wdot - W * Udot) / (U * U + W * W);
   xdot[8] = (Vdot * vt - V * xdot[6]) / (vt * vt * cb);
+#endif
 }
 
 // Moment equations (C/nlplant.c:413-436): xdot[9..11].  Needs the body rates, qbar and Cl, Cm, Cn only.

@@ -121,9 +121,10 @@ F16_DEV double quad_long(TP T, const double *xu, int s, double xcg, unsigned fla
   quad_br_axes(qb, a1, b, d1);
   Axis a2 = a1;
   if (hi_a) { a2.j = N_A2 - 2; a2.l = 1.0; a2.m = 0.0; }
-  const double Cf = lerp(bil4(qlo, a1, b), bil4(qhi, a1, b), d1);
-  const double C0 = bil4(q0, a1, b);
-  const double dC = bil4(qlef, a2, b) - C0;                       // hifi_C_lef :1892-1899
+  const W4 W1 = bil_weights(a1, b), W2 = bil_weights(a2, b);
+  const double Cf = lerp(bil4w(qlo, a1, b, W1), bil4w(qhi, a1, b, W1), d1);
+  const double C0 = bil4w(q0, a1, b, W1);
+  const double dC = bil4w(qlef, a2, b, W2) - C0;                       // hifi_C_lef :1892-1899
   const double Cq = lerp(g0, g1, a1), dCm = lerp(m0, m1, a1), dq = lerp(h0, h1, a2), eta = lerp(e0, e1, d1);
   const double dql = k == 1 ? dC : dq;                            // reference quirk: dZdQ uses delta_Cz_lef
   double tot = Cf * (k == 2 ? eta : 1.0) + dC * in.dlef + in.kq * (Cq + dql * in.dlef) * in.Q + (k == 2 ? dCm : 0.0);
@@ -174,9 +175,10 @@ F16_DEV double quad_lat(TP T, const double *xu, int s, int &status) {
   quad_br_axes(qb, a1, b, d2);
   Axis a2 = a1;
   if (hi_a) { a2.j = N_A2 - 2; a2.l = 1.0; a2.m = 0.0; }
-  const double C3 = lerp(bil4(qlo, a1, b), bil4(qhi, a1, b), d2), C30 = bil4(q0, a1, b);
-  const double Cy = bil4(qy, a1, b), Cr30 = bil4(qr, a1, b), Ca20 = bil4(qa, a1, b);
-  const double Clef = bil4(ql, a2, b), Ca20lef = bil4(qal, a2, b);
+  const W4 W1 = bil_weights(a1, b), W2 = bil_weights(a2, b);
+  const double C3 = lerp(bil4w(qlo, a1, b, W1), bil4w(qhi, a1, b, W1), d2), C30 = bil4w(q0, a1, b, W1);
+  const double Cy = bil4w(qy, a1, b, W1), Cr30 = bil4w(qr, a1, b, W1), Ca20 = bil4w(qa, a1, b, W1);
+  const double Clef = bil4w(ql, a2, b, W2), Ca20lef = bil4w(qal, a2, b, W2);
   const double base = k == 0 ? Cy : C3, base0 = k == 0 ? Cy : C30;
   const double dlefC = Clef - base0;                             // hifi_C_lef
   const double dr30 = Cr30 - base0;                              // hifi_rudder
