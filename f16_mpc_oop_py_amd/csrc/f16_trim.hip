@@ -5,9 +5,14 @@
 // scipy.optimize.minimize(method='Nelder-Mead', tol=1e-10, maxiter=5e4) -- 1,932 sequential _calc_xdot calls
 // per aircraft.  Here the same Nelder-Mead iteration (scipy/optimize/_optimize.py:_minimize_neldermead: rho 1,
 // chi 2, psi 0.5, sigma 0.5, initial simplex +5 % / 0.00025, termination max|sim[1:]-sim[0]| <= xatol and
-// max|f0 - f[1:]| <= fatol) runs as a per-lane state machine in which EVERY loop trip evaluates exactly one
-// candidate point, so lanes that reflect, expand, contract or shrink stay convergent on the expensive part
-// (the plant evaluation, same device code as the dynamics kernels); the simplex lives in a lane-private LDS column.
+// max|f0 - f[1:]| <= fatol) with SIXTEEN LANES PER CONDITION (one DPP row): every point an iteration could need depends
+// on the simplex at the start of the iteration only -- the reflected, expanded and both contracted points, and the five
+// vertices of a shrink -- so the row evaluates all nine at once (lane s takes candidate s) and an iteration costs ONE plant
+// evaluation of latency whatever branch scipy's rules then take; the decisions, the accepted coordinates and the
+// evaluation COUNT are those of the sequential algorithm (nfev counts what scipy would have evaluated).  The simplex is
+// replicated in the registers of the row's lanes (identical bookkeeping on every lane: no LDS, no synchronisation).
+// A condition that cannot be trimmed runs to the reference's maxiter = 50,000 iterations as scipy does: 50,000 evaluation
+// latencies (~0.15 s) instead of the ~350,000 of the one-evaluation-per-trip form this replaces.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -64,132 +69,185 @@ __device__ __forceinline__ double trim_cost(TP T, const double *LT, const double
   return c;
 }
 
-enum { TS_INIT = 0, TS_REFLECT, TS_EXPAND, TS_CONTRACT_OUT, TS_CONTRACT_IN, TS_SHRINK, TS_DONE };
+// value of lane `src` of this lane's 16-lane row
+__device__ __forceinline__ double row_get(double v, int src) {
+  const int lane = (threadIdx.x & 48) | src;                      // within the wavefront
+  const int lo = __shfl(__double2loint(v), lane, 64), hi = __shfl(__double2hiint(v), lane, 64);
+  return __hiloint2double(hi, lo);
+}
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_trim(TrimArgs a) {
+// stable sort of the six vertices by cost (numpy argsort on six elements: insertion sort, i.e. stable)
+__device__ __forceinline__ void sort_simplex(double (&sim)[6][5], double (&fs)[6]) {
+  int rank[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    int r = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) r += (fs[j] < fs[i] || (j < i && fs[j] == fs[i])) ? 1 : 0;
+    rank[i] = r;
+  }
+  double ns[6][5], nf[6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    nf[r] = fs[0];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) ns[r][k] = sim[0][k];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) {
+      const bool here = rank[i] == r;
+      nf[r] = here ? fs[i] : nf[r];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) ns[r][k] = here ? sim[i][k] : ns[r][k];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    fs[r] = nf[r];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sim[r][k] = ns[r][k];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_trim(TrimArgs a) {
   __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
-  __shared__ double simx[36][BLOCK];     // rows p*5+k: simplex vertex p (sorted by cost), coordinate k; rows 30+p: cost
   if (a.fi == 1) {
     const double2 *src = reinterpret_cast<const double2 *>(a.tab);
     double2 *dst = reinterpret_cast<double2 *>(tab);
-    for (int i = threadIdx.x; i < TABLE_IMAGE_DOUBLES / 2; i += BLOCK) dst[i] = src[i];
+    for (int i = threadIdx.x; i < TABLE_IMAGE_DOUBLES / 2; i += 256) dst[i] = src[i];
     __syncthreads();
   }
-  const int t = threadIdx.x;
-#define SIM(p, k) simx[(p) * 5 + (k)][t]
-#define FS(p) simx[30 + (p)][t]
-  for (long b0 = (long)blockIdx.x * BLOCK; b0 < a.B; b0 += (long)gridDim.x * BLOCK) {
-    const long b = b0 + t;
+  const int s = threadIdx.x & 15;                                 // candidate slot of this lane
+  // one row per condition, four conditions per wavefront; wavefronts stride over the batch independently (no barrier below)
+  for (long b = (long)blockIdx.x * 16 + (threadIdx.x >> 4); b < ((a.B + 3) & ~3L); b += (long)gridDim.x * 16) {
     const bool valid = b < a.B;
     const double h = valid ? a.h[b] : 10000.0, V = valid ? a.v[b] : 700.0;
+    double sim[6][5], fs[6];
     // initial simplex (scipy: nonzdelt 0.05, zdelt 0.00025)
+#pragma unroll
     for (int p = 0; p < 6; ++p)
+#pragma unroll
       for (int k = 0; k < 5; ++k) {
         double y = a.x0[k];
         if (p == k + 1) y = (y != 0.0) ? (1 + 0.05) * y : 0.00025;
-        SIM(p, k) = y;
+        sim[p][k] = y;
       }
-    int state = TS_INIT, sub = 0, iters = 0, nfev = 0, st = 0;
-    double xr[5], fxr = 0.0, xbar[5];
-    bool done = !valid;
-    while (true) {
-      // ---- termination test / next candidate
+    int iters = 0, nfev = 6, st = 0;
+    {
       double q[5];
-      if (state == TS_REFLECT && !done) {
-        double dx = 0.0, df = 0.0;
-        for (int p = 1; p < 6; ++p) {
-          for (int k = 0; k < 5; ++k) dx = fmax(dx, fabs(SIM(p, k) - SIM(0, k)));
-          df = fmax(df, fabs(FS(0) - FS(p)));
-        }
-        if ((dx <= a.xatol && df <= a.fatol) || iters >= a.maxiter) done = true;
-        else {
-          ++iters;
-          for (int k = 0; k < 5; ++k) {
-            double s = SIM(0, k);
-            for (int p = 1; p < 5; ++p) s += SIM(p, k);
-            xbar[k] = s / 5;
-            xr[k] = (1 + 1.0) * xbar[k] - 1.0 * SIM(5, k);
-          }
-        }
-      }
-      if (__all(done)) break;
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
-        double v;
-        switch (state) {
-          case TS_INIT: v = SIM(sub, k); break;
-          case TS_REFLECT: v = xr[k]; break;
-          case TS_EXPAND: v = (1 + 1.0 * 2.0) * xbar[k] - 1.0 * 2.0 * SIM(5, k); break;
-          case TS_CONTRACT_OUT: v = (1 + 0.5 * 1.0) * xbar[k] - 0.5 * 1.0 * SIM(5, k); break;
-          case TS_CONTRACT_IN: v = (1 - 0.5) * xbar[k] + 0.5 * SIM(5, k); break;
-          default: v = SIM(sub, k); break;   // TS_SHRINK: vertex `sub` was already moved
+        q[k] = sim[0][k];
+#pragma unroll
+        for (int p = 1; p < 6; ++p) q[k] = s == p ? sim[p][k] : q[k];
+      }
+      int stq = 0;
+      const double fq = trim_cost((const double *)tab, a.lofi, q, h, V, a.xcg, a.fi, a.flags, stq, nullptr);
+#pragma unroll
+      for (int p = 0; p < 6; ++p) fs[p] = row_get(fq, p);
+      sort_simplex(sim, fs);
+    }
+    bool done = !valid;
+    while (true) {
+      if (!done) {
+        double dx = 0.0, df = 0.0;
+#pragma unroll
+        for (int p = 1; p < 6; ++p) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) dx = fmax(dx, fabs(sim[p][k] - sim[0][k]));
+          df = fmax(df, fabs(fs[0] - fs[p]));
         }
+        if ((dx <= a.xatol && df <= a.fatol) || iters >= a.maxiter) done = true;
+      }
+      if (__all(done)) break;
+      if (!done) ++iters;
+      // every point this iteration can need, from the simplex as it stands
+      double xr[5], xe[5], xc[5], xcc[5], q[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        double sb = sim[0][k];
+#pragma unroll
+        for (int p = 1; p < 5; ++p) sb += sim[p][k];
+        const double xbar = sb / 5;
+        xr[k] = (1 + 1.0) * xbar - 1.0 * sim[5][k];
+        xe[k] = (1 + 1.0 * 2.0) * xbar - 1.0 * 2.0 * sim[5][k];
+        xc[k] = (1 + 0.5 * 1.0) * xbar - 0.5 * 1.0 * sim[5][k];
+        xcc[k] = (1 - 0.5) * xbar + 0.5 * sim[5][k];
+        double v = s == 1 ? xe[k] : (s == 2 ? xc[k] : (s == 3 ? xcc[k] : xr[k]));
+#pragma unroll
+        for (int j = 1; j < 6; ++j) v = s == 3 + j ? sim[0][k] + 0.5 * (sim[j][k] - sim[0][k]) : v;
         q[k] = done ? a.x0[k] : v;
       }
       int stq = 0;
       const double fq = trim_cost((const double *)tab, a.lofi, q, h, V, a.xcg, a.fi, a.flags, stq, nullptr);
+      const double fxr = row_get(fq, 0), fxe = row_get(fq, 1), fxc = row_get(fq, 2), fxcc = row_get(fq, 3);
+      double fsh[6];
+#pragma unroll
+      for (int j = 1; j < 6; ++j) fsh[j] = row_get(fq, 3 + j);
       if (done) continue;
-      ++nfev;
-      // ---- bookkeeping (scipy _minimize_neldermead, one branch per evaluated point)
-      bool accept = false, shrink = false, resort = false;
-      double xa[5], fa = fq;
-      for (int k = 0; k < 5; ++k) xa[k] = q[k];
-      if (state == TS_INIT) {
-        FS(sub) = fq;
-        if (++sub == 6) { resort = true; state = TS_REFLECT; }
-      } else if (state == TS_REFLECT) {
-        fxr = fq;
-        if (fxr < FS(0)) state = TS_EXPAND;
-        else if (fxr < FS(4)) accept = true;
-        else if (fxr < FS(5)) state = TS_CONTRACT_OUT;
-        else state = TS_CONTRACT_IN;
-      } else if (state == TS_EXPAND) {
-        if (!(fq < fxr)) { for (int k = 0; k < 5; ++k) xa[k] = xr[k]; fa = fxr; }
+      // ---- scipy _minimize_neldermead, one iteration (nfev: the evaluations the sequential algorithm makes)
+      bool accept = false, shrink = false;
+      double xa[5], fa = fxr;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) xa[k] = xr[k];
+      nfev += 1;
+      if (fxr < fs[0]) {
+        nfev += 1;
+        if (fxe < fxr) {
+          fa = fxe;
+#pragma unroll
+          for (int k = 0; k < 5; ++k) xa[k] = xe[k];
+        }
         accept = true;
-      } else if (state == TS_CONTRACT_OUT) {
-        if (fq <= fxr) accept = true; else shrink = true;
-      } else if (state == TS_CONTRACT_IN) {
-        if (fq < FS(5)) accept = true; else shrink = true;
-      } else if (state == TS_SHRINK) {
-        FS(sub) = fq;
-        if (++sub == 6) { resort = true; state = TS_REFLECT; }
-        else for (int k = 0; k < 5; ++k) SIM(sub, k) = SIM(0, k) + 0.5 * (SIM(sub, k) - SIM(0, k));
+      } else if (fxr < fs[4]) {
+        accept = true;
+      } else if (fxr < fs[5]) {
+        nfev += 1;
+        if (fxc <= fxr) {
+          accept = true; fa = fxc;
+#pragma unroll
+          for (int k = 0; k < 5; ++k) xa[k] = xc[k];
+        } else shrink = true;
+      } else {
+        nfev += 1;
+        if (fxcc < fs[5]) {
+          accept = true; fa = fxcc;
+#pragma unroll
+          for (int k = 0; k < 5; ++k) xa[k] = xcc[k];
+        } else shrink = true;
       }
       if (accept) {   // replace the worst vertex, keep the list sorted (stable: after equal costs, like numpy's argsort)
         int pos = 5;
-        for (int p = 4; p >= 0; --p) if (fa < FS(p)) pos = p;
-        for (int p = 5; p > pos; --p) {
-          for (int k = 0; k < 5; ++k) SIM(p, k) = SIM(p - 1, k);
-          FS(p) = FS(p - 1);
+#pragma unroll
+        for (int p = 4; p >= 0; --p) pos = fa < fs[p] ? p : pos;
+#pragma unroll
+        for (int p = 5; p >= 1; --p) {
+          const bool shift = p > pos, here = p == pos;
+          fs[p] = shift ? fs[p - 1] : (here ? fa : fs[p]);
+#pragma unroll
+          for (int k = 0; k < 5; ++k) sim[p][k] = shift ? sim[p - 1][k] : (here ? xa[k] : sim[p][k]);
         }
-        for (int k = 0; k < 5; ++k) SIM(pos, k) = xa[k];
-        FS(pos) = fa;
-        state = TS_REFLECT;
+        if (pos == 0) {
+          fs[0] = fa;
+#pragma unroll
+          for (int k = 0; k < 5; ++k) sim[0][k] = xa[k];
+        }
       }
       if (shrink) {
-        state = TS_SHRINK; sub = 1;
-        for (int k = 0; k < 5; ++k) SIM(1, k) = SIM(0, k) + 0.5 * (SIM(1, k) - SIM(0, k));
-      }
-      if (resort) {   // insertion sort of the six vertices by cost
-        for (int i = 1; i < 6; ++i) {
-          double fi_ = FS(i), xi[5];
-          for (int k = 0; k < 5; ++k) xi[k] = SIM(i, k);
-          int j = i - 1;
-          while (j >= 0 && FS(j) > fi_) {
-            for (int k = 0; k < 5; ++k) SIM(j + 1, k) = SIM(j, k);
-            FS(j + 1) = FS(j);
-            --j;
-          }
-          for (int k = 0; k < 5; ++k) SIM(j + 1, k) = xi[k];
-          FS(j + 1) = fi_;
+        nfev += 5;
+#pragma unroll
+        for (int j = 1; j < 6; ++j) {
+          fs[j] = fsh[j];
+#pragma unroll
+          for (int k = 0; k < 5; ++k) sim[j][k] = sim[0][k] + 0.5 * (sim[j][k] - sim[0][k]);
         }
+        sort_simplex(sim, fs);
       }
     }
-    if (valid) {
+    if (valid && s == 0) {
       // x_trim of env.py:275-290 (unclipped optimiser output; lef from the formula)
       double q[5], xf[18];
-      for (int k = 0; k < 5; ++k) q[k] = SIM(0, k);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) q[k] = sim[0][k];
       const double c = trim_cost((const double *)tab, a.lofi, q, h, V, a.xcg, a.fi, a.flags, st, xf);
       xf[7] = q[4]; xf[12] = q[0]; xf[13] = q[1]; xf[14] = q[2]; xf[15] = q[3];
 #pragma unroll
@@ -200,8 +258,6 @@ __global__ __launch_bounds__(BLOCK) void k_trim(TrimArgs a) {
       if (a.status) a.status[b] |= st | (iters >= a.maxiter ? F16_ST_QP_MAXITER : 0);
     }
   }
-#undef SIM
-#undef FS
 }
 
 }  // namespace f16
@@ -220,7 +276,7 @@ extern "C" int f16_trim_batch(f16_ctx *ctx, const double *h, const double *v, do
   a.xatol = 1e-10; a.fatol = 1e-10;                 // tol=1e-10
   static const double x0_ref[5] = {5000, -0.09, 8.49, -0.01, 0.01};   // env.py:265-271 (order as passed to minimize)
   for (int k = 0; k < 5; ++k) a.x0[k] = h_x0 ? h_x0[k] : x0_ref[k];
-  const long blocks = (B + 63) / 64;
-  hipLaunchKernelGGL(k_trim<64>, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(64), 0, (hipStream_t)stream, a);
+  const long blocks = (B + 15) / 16;       // 16 conditions (16 lanes each) per 256-lane workgroup, one workgroup per CU
+  hipLaunchKernelGGL(k_trim, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream, a);
   return hip_check(hipGetLastError(), "f16_trim_batch launch");
 }
