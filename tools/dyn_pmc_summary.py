@@ -8,10 +8,10 @@ SQ_ACTIVE_INST_VALU / (4 x SQ_BUSY_CYCLES-equivalent SIMD cycles) printed to std
 import csv, glob, os, sys
 from collections import defaultdict
 
-d, tag = sys.argv[1], sys.argv[2]
+dirs, tag = sys.argv[1:-1], sys.argv[-1]
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 acc = defaultdict(lambda: [0.0, 0])
-for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+for f in [g for d in dirs for g in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)]:
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
         if "k_rollout" not in name:
@@ -31,4 +31,9 @@ for k in kern:
     print("%-28s VALU wave-instr %.3e | active VALU cycles / wave cycles %.3f | wait / wave cycles %.3f | LDS instr %.3e, conflict/active %.3f"
           % (k, g("SQ_INSTS_VALU"), g("SQ_ACTIVE_INST_VALU") / max(g("SQ_WAVE_CYCLES"), 1), g("SQ_WAIT_ANY") / max(g("SQ_WAVE_CYCLES"), 1),
              g("SQ_INSTS_LDS"), g("SQ_LDS_BANK_CONFLICT") / max(g("SQ_ACTIVE_INST_LDS"), 1)))
+    if acc.get((k, "SQ_LDS_IDX_ACTIVE")):
+        fp = g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64")
+        print("%-28s LDS bank-conflict cycles / LDS index-active cycles %.3f | address conflicts / index-active %.3f | fp64 FMA+ADD+MUL wave-instr %.3e = %.1f %% of VALU"
+              % ("", g("SQ_LDS_BANK_CONFLICT") / max(g("SQ_LDS_IDX_ACTIVE"), 1), g("SQ_LDS_ADDR_CONFLICT") / max(g("SQ_LDS_IDX_ACTIVE"), 1), fp,
+                 100 * fp / max(g("SQ_INSTS_VALU"), 1)))
 print("wrote", out)

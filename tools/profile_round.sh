@@ -1,25 +1,29 @@
 #!/bin/bash
 # Round profile on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh
 # Separate rocprofv3 passes, as MI355X_MICROARCH.md prescribes: --kernel-trace --stats alone; each --pmc set alone.
+# Output under gpurun_out/prof_*; tools/*_summary.py (run in the build container) turn it into profiles/<tag>_*.
 set -e
 export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
+step() { echo "== $1 ($(date +%T))"; }
+step "kernel-trace + stats of the default bench command"
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_stats -o st -- python3 bench.py --steps 10 --warmup 2 > $O/bench_under_rocprof.json 2> $O/prof_stats.err
-echo "stats pass done"
-rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/prof_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mpc --no-large > /dev/null 2> $O/prof_fetch.err
-rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/prof_write -o w -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mpc --no-large > /dev/null 2> $O/prof_write.err
-echo "hbm passes done"
+step "HBM traffic: FETCH_SIZE, WRITE_SIZE (separate passes), B = 4096 and B = 262,144 rollouts"
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/prof_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mpc --no-config5 > /dev/null 2> $O/prof_fetch.err
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/prof_write -o w -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mpc --no-config5 > /dev/null 2> $O/prof_write.err
+step "MPC kernels: matrix-core and issue counters (osqp-default settings)"
 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU \
   -d $O/prof_mfma -o m -- python3 tools/gpu_mpc_only.py > $O/prof_mfma.log 2> $O/prof_mfma.err
 rocprofv3 --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 \
   -d $O/prof_lds -o l -- python3 tools/gpu_mpc_only.py > $O/prof_lds.log 2> $O/prof_lds.err
-echo "mpc passes done"
-python3 bench.py > $O/bench.json 2> $O/bench.err
-echo "plain bench done"
-# SQ counters of the dynamics kernels (issue utilisation behind the "VALU-bound when the chip is full" reading)
+step "dynamics kernels: issue counters, then LDS pipe + fp64 instruction mix"
 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT \
-  -d $O/prof_dyn -o d -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mpc > /dev/null 2> $O/prof_dyn.err
-echo "dynamics SQ pass done"
+  -d $O/prof_dyn -o d -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mpc --no-config5 > /dev/null 2> $O/prof_dyn.err
+rocprofv3 --output-format csv --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_SALU \
+  -d $O/prof_dyn2 -o d2 -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mpc --no-config5 > /dev/null 2> $O/prof_dyn2.err
+step "plain bench (the record the profile is compared with)"
+python3 bench.py > $O/bench.json 2> $O/bench.err
+step "done"
