@@ -156,10 +156,11 @@ int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double
                   long B, long ld, int hzn, double dt, const f16_qp_settings *s, void *stream);
 /* Prepared plans.  The reference freezes (Ad,Bd,Cd) at construction (env.py:49-60) yet rebuilds the whole QP on every
  * _calc_MPC_action call (utils.py:21-167 inside env.py:373-424).  A plan computes the model-only part once -- DARE,
- * terminal weight, prediction blocks, P, A'A, the start value of rho and the factorisation of the KKT matrix (kept as
- * matrix-core accumulator tiles, 73.7 KB per aircraft) -- and f16_mpc_plan_solve does what is left per call: the
- * state-dependent vectors and the ADMM iterations.  Results are bit-identical to f16_mpc_batch with the same
- * settings.  hzn <= 32.  (Ad,Bd,Cd) are read during f16_mpc_plan_create only. */
+ * terminal weight, prediction blocks, P; with scaling = 0 also the start value of rho and the inverse of the KKT matrix
+ * (73.7 KB per aircraft) -- and f16_mpc_plan_solve does what is left per call: the state-dependent vectors, the
+ * iterations and, with OSQP's defaults, equilibration + factorisation (OSQP's scaling looks at q, i.e. at the state of the
+ * call).  Results are bit-identical to f16_mpc_batch with the same settings.  hzn <= 32.  (Ad,Bd,Cd) are read during
+ * f16_mpc_plan_create only. */
 typedef struct f16_mpc_plan f16_mpc_plan;
 int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const double *Ad, const double *Bd, const double *Cd,
                         long B, long ld, int hzn, double dt, const f16_qp_settings *s, void *stream);
