@@ -996,14 +996,15 @@ static int mpc_lds_opt_in() {
   return F16_OK;
 }
 
-// Per-call QP workspace, stream-ordered (see f16_ctx.h): [B][np] P | [B][ext] extras.
-static int mpc_work_alloc(f16_ctx *ctx, MpcArgs &a, bool with_ext, void *stream, void **block) {
+// Per-call QP workspace, stream-ordered (see f16_ctx.h): [B][np] P | [B][ext] extras | [B][tiles] A'WA of the fast solver.
+static int mpc_work_alloc(f16_ctx *ctx, MpcArgs &a, bool with_ext, void *stream, void **block, bool with_gram = false) {
   const size_t np = (size_t)(3 * a.N) * (3 * a.N + 1) / 2;
-  const size_t need = (np + (with_ext ? mpc_ext_doubles(a.N) : 0)) * (size_t)a.B * sizeof(double);
+  const size_t need = (np + (with_ext ? mpc_ext_doubles(a.N) : 0) + (with_gram ? MPC_TILE_DOUBLES : 0)) * (size_t)a.B * sizeof(double);
   *block = nullptr;
   if (int rc = hip_check(hipMallocFromPoolAsync(block, need, ctx->pool, (hipStream_t)stream), "hipMallocFromPoolAsync QP workspace")) return rc;
   a.Ppk = (double *)*block;
   a.ext = with_ext ? a.Ppk + np * (size_t)a.B : nullptr;
+  a.gramws = with_gram ? a.Ppk + (np + mpc_ext_doubles(a.N)) * (size_t)a.B : nullptr;
   return F16_OK;
 }
 static int mpc_work_free(void *block, void *stream) {
@@ -1035,7 +1036,7 @@ static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream, int mode, void **k
   if (lds > 160 * 1024) return set_error(F16_EINVAL, "horizon too large for LDS");
   if (int rc = mpc_lds_opt_in()) return rc;
   void *block = nullptr;
-  if (int rc = mpc_work_alloc(ctx, a, mode != 0, stream, &block)) return rc;
+  if (int rc = mpc_work_alloc(ctx, a, mode != 0, stream, &block, mode == 2 && a.s.adaptive_rho)) return rc;
   int rc = F16_OK;
   if (mode == 0) {
     hipLaunchKernelGGL(k_mpc<false>, dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
@@ -1123,7 +1124,7 @@ extern "C" int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const doub
     return set_error(F16_EINVAL, "bad QP settings");
   }
   const size_t np = (size_t)(3 * hzn) * (3 * hzn + 1) / 2;
-  const size_t per = np + mpc_ext_doubles(hzn) + MPC_TILE_DOUBLES;
+  const size_t per = np + mpc_ext_doubles(hzn) + 2 * MPC_TILE_DOUBLES;      // P | extras | inverse (scaling = 0) | A'WA
   if (int rc = hip_check(hipMalloc(&p->buf, per * (size_t)B * sizeof(double)), "hipMalloc MPC plan")) { delete p; return rc; }
   if (int rc = hip_check(hipMalloc(&p->sched, 2 * (size_t)B * sizeof(int32_t)), "hipMalloc MPC plan")) { (void)hipFree(p->buf); delete p; return rc; }
   MpcArgs &a = p->a;
@@ -1131,6 +1132,7 @@ extern "C" int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const doub
   a.Ad = Ad; a.Bd = Bd; a.Cd = Cd; a.B = B; a.ld = ld; a.N = hzn; a.dt = dt; a.s = p->s;
   a.Ppk = p->buf; a.ext = a.Ppk + np * (size_t)B;
   a.tiles = a.ext + mpc_ext_doubles(hzn) * (size_t)B;
+  a.gramws = a.tiles + MPC_TILE_DOUBLES * (size_t)B;
   a.mode = 1;
   int rc = plan_launch_build(p, a, stream);
   // Without equilibration the start value of rho and the KKT factorisation depend on the model only and are cached too.

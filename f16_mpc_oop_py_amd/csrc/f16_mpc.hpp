@@ -36,7 +36,9 @@ struct MpcArgs {
   int32_t *status;
   double *Ppk;                // workspace [B][np] packed P (A'A is never stored: the solvers form the weighted Gram themselves)
   double *ext;                // workspace [B][mpc_ext_doubles(N)]: q | G | pred | A | Q | Qbar | rho, ok | scaling (setup kernel -> solver / debug)
-  double *tiles;              // prepared plans: [B][MPC_TILE_DOUBLES] KKT-inverse tiles in accumulator layout
+  double *tiles;              // prepared plans without equilibration: [B][MPC_TILE_DOUBLES] the re-laid KKT inverse
+  double *gramws;             // [B][MPC_TILE_DOUBLES] A'WA as matrix-core tiles, written by a solve's first factorisation and
+                              // re-read by its rho updates (the Gram product does not depend on rho); may be null (recomputed)
   int mode;                   // 0 one-shot; 1 prepare (build + factor, keep everything, no iterations); 2 solve from a plan
   double *warm;               // plans with warm start: [B][MPC_WARM_DOUBLES] x, z, y of the previous solve (per lane)
   int warm_load;              // start from them (else from zero, as the reference's fresh OSQP object does)

@@ -428,33 +428,72 @@ __device__ __forceinline__ double row_allmax(double v) {
 constexpr int ES9 = 9 * 64;            // E of all nine state rows per horizon step (equilibration), zero padded like wsP
 constexpr int WGN = 6 * FAST_MAXN + 8; // Gram weights of the kept state rows, zero padded to whole k-steps
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS of the solver kernel (143 KB of the 160 KB of a CU: one workgroup per CU in any case -- 512 lanes x 256 registers
+// fill its register file).  Namespace scope, so that the phases of a solve can be SEPARATE FUNCTIONS (real calls):
+// equilibrate once, then factorise / iterate alternately.  Each phase then gets a register allocation of its own; as one
+// inlined kernel the allocator kept values of the factorisation path alive across the iteration loop and spilled the
+// loop's operators (the N = 30 instantiation reloaded 16 of its 36 Toeplitz operands from scratch in every iteration).
+// The iteration's zero-padded vectors sit in ONE block: during a factorisation the same memory carries one tile row of
+// the inverse on its way to the per-lane layout (Mst, 16 x 96 doubles).
+__shared__ __attribute__((aligned(16))) double s_itv[2 * WSP + 2 * XTP];
+static_assert(2 * WSP + 2 * XTP >= 16 * FN, "the relayout buffer must fit in the iteration vectors");
+#define wsP (s_itv)
+#define ysP (s_itv + WSP)
+#define xtP (s_itv + 2 * WSP)
+#define xcP (s_itv + 2 * WSP + XTP)
+#define Mst (s_itv)
+__shared__ __attribute__((aligned(16))) double s_Cs[2 * FN * 4 + 40];      // pivot panels of the sweep
+__shared__ double s_rhs[FN], s_wc[FN], s_wr[FN + 4], s_yc[FN], s_yr[FN + 4], s_red[8 * 9];
+__shared__ double s_sg2[FN], s_cq[FN], s_q[FN], s_cD[FN], s_cinv;          // per variable: sigma D^-2, c q, q, c D; 1 / c
+__shared__ double s_Dv[XTP], s_Es9[ES9], s_Ecv[FN], s_Erv[FN + 4], s_Wg[WGN], s_Wcv[FN], s_Wrv[FN + 4], s_nPm[FN];
+__shared__ __attribute__((aligned(16))) double s_Gl[27 * FAST_MAXN];       // all nine rows of every G_k: equilibration, Gram
+__shared__ double s_px[18 * FT];       // this lane's 18 entries of P (termination test): lane q of row blk holds P[3 blk + c][6 q + cc]
+__shared__ double s_lc[4 * FT];        // per constraint row: lower bound | upper bound | weight W = E^2 | rho-vector factor
 
-// ---- Ruiz equilibration (OSQP scaling.c:scale_data), out of line: its register
-// needs (|P| tiles, eighteen E / six D operands per pass) stay out of the iteration loop's allocation.  Norms of the scaled
-// matrices are formed from the ORIGINAL entries and the running D, E, c:
+struct LaneRole {                      // fixed for the whole launch; recomputed by every phase from threadIdx (cheap)
+  int w, l, lc, lq, blk, q, kind, sub, r9, k3, xe, xec, dup;
+  bool h, g, e, inb, srow, xown;
+};
+__device__ __forceinline__ LaneRole lane_role(int N) {
+  LaneRole r;
+  const int tid = threadIdx.x;
+  r.w = tid >> 6; r.l = tid & 63; r.lc = r.l & 15; r.lq = r.l >> 4; r.blk = tid >> 4; r.q = r.lc;
+  r.h = r.lc & 8; r.g = r.lc & 4; r.e = r.lc & 2;
+  r.inb = r.blk < N;
+  r.kind = 0; r.sub = 0;               // 1 state row rr = sub, 2 command row c = sub, 3 rate row c = sub
+  if (r.inb) {
+    if (r.lc == 0 || r.lc == 2 || r.lc == 4) { r.kind = 1; r.sub = r.lc >> 1; }
+    else if (r.lc == 8 || r.lc == 10 || r.lc == 12) { r.kind = 1; r.sub = 3 + ((r.lc - 8) >> 1); }
+    else if (r.lc == 1 || r.lc == 3 || r.lc == 5) { r.kind = 2; r.sub = (r.lc - 1) >> 1; }
+    else if (r.lc == 9 || r.lc == 11 || r.lc == 13) { r.kind = 3; r.sub = (r.lc - 9) >> 1; }
+  }
+  // x9 row of a state-row owner (kept rows: SROW[sub]; rows without bounds: lanes 6 -> phi, 14 -> theta, 7 -> lf1)
+  r.r9 = r.kind == 1 ? (r.sub < 5 ? r.sub + 2 : 8) : (r.lc == 6 ? 0 : (r.lc == 14 ? 1 : (r.lc == 7 ? 7 : -1)));
+  r.srow = r.inb && r.r9 >= 0;
+  r.k3 = 3 * r.blk + r.sub;            // index of a command / rate row
+  r.xown = r.inb && (r.lc == 0 || r.lc == 4 || r.lc == 8);
+  r.xe = 3 * r.blk + (r.lc >> 2);
+  r.xec = r.xe < FN ? r.xe : FN - 1;   // in-range index for lanes that own no variable
+  r.dup = (r.kind == 1 && r.sub < 3) ? 6 : 0;      // state rows 0..2 are stored twice (stage1_load)
+  return r;
+}
+__device__ __forceinline__ double *w_slot(const LaneRole &r, double *sP, double *sc, double *sr) {
+  return r.kind == 1 ? sP + WROW * r.blk + r.sub : (r.kind == 2 ? sc + r.k3 : sr + r.k3);
+}
+
+// ---- Ruiz equilibration (OSQP scaling.c:scale_data).  Norms of the scaled matrices are formed from the ORIGINAL entries
+// and the running D, E, c:
 //   columns / rows of Pb = c D P D    from |P| held as matrix-core tiles (tile-row waves, DPP row maxima)
 //   columns of Ab = E A D             the stage-1 pattern with (max, x) instead of (+, x) on |G_d| and E
 //   rows of Ab                        the stage-3 pattern likewise on |G_d| and D
-// All nine state rows take part (rows without bounds are rows of A as OSQP sees it).  On entry Dv / Es9 / Ecv / Erv hold
-// D = E = 1 (zero padded); on return they hold the final D, E; De / Eo / cs are this lane's D, E and the cost scaling c.
+// All nine state rows take part (rows without bounds are rows of A as OSQP sees it).  On entry s_Dv / s_Es9 / s_Ecv / s_Erv
+// hold D = E = 1 (zero padded); on return they hold the final D, E; out3 = this lane's D, E and the cost scaling c.
 template <int NTT>
-__device__ __noinline__ void ruiz_equilibrate(const double *Pg, const double *Gl, double *Dv, double *Es9, double *Ecv, double *Erv,
-                                              double *nPm, double *red, int N, int passes, double qe, double *out3) {
+__device__ __noinline__ void ruiz_equilibrate(const double *Pg, int N, int passes, double qe, double *out3) {
   const int n = 3 * N;
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lc = l & 15, lq = l >> 4, blk = tid >> 4, q = lc;
-  const bool inb = blk < N;
-  int kind = 0, sub = 0;
-  if (inb) {
-    if (lc == 0 || lc == 2 || lc == 4) { kind = 1; sub = lc >> 1; }
-    else if (lc == 8 || lc == 10 || lc == 12) { kind = 1; sub = 3 + ((lc - 8) >> 1); }
-    else if (lc == 1 || lc == 3 || lc == 5) { kind = 2; sub = (lc - 1) >> 1; }
-    else if (lc == 9 || lc == 11 || lc == 13) { kind = 3; sub = (lc - 9) >> 1; }
-  }
-  const int r9 = kind == 1 ? (sub < 5 ? sub + 2 : 8) : (lc == 6 ? 0 : (lc == 14 ? 1 : (lc == 7 ? 7 : -1)));
-  const bool srow = inb && r9 >= 0;
-  const int k3 = 3 * blk + sub;
-  const bool xown = inb && (lc == 0 || lc == 4 || lc == 8);
-  const int xe = 3 * blk + (lc >> 2);
+  const LaneRole r = lane_role(N);
+  const int w = r.w, lc = r.lc, lq = r.lq, blk = r.blk, q = r.q;
   double De = 1.0, Eo = 1.0, cs = 1.0;
   d4_t pt[NT];                                               // |P| tiles
   if (w < NTT) {
@@ -471,7 +510,7 @@ __device__ __noinline__ void ruiz_equilibrate(const double *Pg, const double *Gl
     if (w < NTT) {
       double dj[NTT];
 #pragma unroll
-      for (int J = 0; J < NTT; ++J) dj[J] = Dv[XOFF + 16 * J + lc];
+      for (int J = 0; J < NTT; ++J) dj[J] = s_Dv[XOFF + 16 * J + lc];
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         double m = 0.0;
@@ -479,66 +518,66 @@ __device__ __noinline__ void ruiz_equilibrate(const double *Pg, const double *Gl
         for (int J = 0; J < NTT; ++J) m = fmax(m, pt[J][qq] * dj[J]);
         m = row_allmax(m);
         const int i = 16 * w + 4 * qq + lq;
-        if (lc == qq && i < n) nPm[i] = Dv[XOFF + i] * m;
+        if (lc == qq && i < n) s_nPm[i] = s_Dv[XOFF + i] * m;
       }
     }
   };
   p_row_norms();
   __syncthreads();
   const int d0 = 2 * q, d1 = 2 * q + 1;
-  const double *g0 = Gl + (d0 < N ? d0 : 0) * 27, *g1 = Gl + (d1 < N ? d1 : 0) * 27;
+  const double *g0 = s_Gl + (d0 < N ? d0 : 0) * 27, *g1 = s_Gl + (d1 < N ? d1 : 0) * 27;
   const double m0 = d0 < N ? 1.0 : 0.0, m1 = d1 < N ? 1.0 : 0.0;
   for (int pass = 0; pass < passes; ++pass) {
     // column norms of the state block of Ab (before the D of the column) and row norms (before the E of the row):
     // lane q covers the blocks d = 2q, 2q+1
     double colS[3] = {0.0, 0.0, 0.0}, rowS[9];
-    const double *ep = Es9 + 9 * (blk + 2 * q), *dp = Dv + XOFF + 3 * (blk - 2 * q - 1);
+    const double *ep = s_Es9 + 9 * (blk + 2 * q), *dp = s_Dv + XOFF + 3 * (blk - 2 * q - 1);
     double dv[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) dv[k] = dp[k];               // D of step i-2q-1 (3), of step i-2q (3)
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      const double e0 = ep[r] * m0, e1 = ep[9 + r] * m1;
+    for (int rr = 0; rr < 9; ++rr) {
+      const double e0 = ep[rr] * m0, e1 = ep[9 + rr] * m1;
       double m = 0.0;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const double a0 = fabs(g0[r * 3 + c]), a1 = fabs(g1[r * 3 + c]);
+        const double a0 = fabs(g0[rr * 3 + c]), a1 = fabs(g1[rr * 3 + c]);
         colS[c] = fmax(colS[c], fmax(a0 * e0, a1 * e1));
         m = fmax(m, fmax(a0 * m0 * dv[3 + c], a1 * m1 * dv[c]));
       }
-      rowS[r] = row_allmax(m);
+      rowS[rr] = row_allmax(m);
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) colS[c] = row_allmax(colS[c]);
     double Dt = 1.0, Et = 1.0;
-    if (xown) {
+    if (r.xown) {
       const int c = lc >> 2;
       const double cS = c == 0 ? colS[0] : (c == 1 ? colS[1] : colS[2]);
-      const double colA = De * fmax(fmax(cS, Ecv[xe]), fmax(Erv[xe], Erv[xe + 3]));
-      Dt = 1.0 / sqrt(osqp_limit_scaling(fmax(cs * nPm[xe], colA)));
+      const double colA = De * fmax(fmax(cS, s_Ecv[r.xe]), fmax(s_Erv[r.xe], s_Erv[r.xe + 3]));
+      Dt = 1.0 / sqrt(osqp_limit_scaling(fmax(cs * s_nPm[r.xe], colA)));
     }
-    if (srow) {
+    if (r.srow) {
       double rs = rowS[0];
 #pragma unroll
-      for (int r = 1; r < 9; ++r) rs = r9 == r ? rowS[r] : rs;
+      for (int rr = 1; rr < 9; ++rr) rs = r.r9 == rr ? rowS[rr] : rs;
       Et = 1.0 / sqrt(osqp_limit_scaling(Eo * rs));
-    } else if (kind == 2) {
-      Et = 1.0 / sqrt(osqp_limit_scaling(Eo * Dv[XOFF + k3]));
-    } else if (kind == 3) {
-      Et = 1.0 / sqrt(osqp_limit_scaling(Eo * fmax(Dv[XOFF + k3], Dv[XOFF + k3 - 3])));
+    } else if (r.kind == 2) {
+      Et = 1.0 / sqrt(osqp_limit_scaling(Eo * s_Dv[XOFF + r.k3]));
+    } else if (r.kind == 3) {
+      Et = 1.0 / sqrt(osqp_limit_scaling(Eo * fmax(s_Dv[XOFF + r.k3], s_Dv[XOFF + r.k3 - 3])));
     }
     __syncthreads();                                        // every lane has read the old D and E
     De *= Dt; Eo *= Et;
-    if (xown) Dv[XOFF + xe] = De;
-    if (srow) Es9[9 * blk + r9] = Eo;
-    if (kind == 2) Ecv[k3] = Eo;
-    if (kind == 3) Erv[k3] = Eo;
+    if (r.xown) s_Dv[XOFF + r.xe] = De;
+    if (r.srow) s_Es9[9 * blk + r.r9] = Eo;
+    if (r.kind == 2) s_Ecv[r.k3] = Eo;
+    if (r.kind == 3) s_Erv[r.k3] = Eo;
     __syncthreads();
     p_row_norms();                                           // with the new D: cost scaling now, column norms of the next pass
     __syncthreads();
-    double v2[2] = {xown ? cs * nPm[xe] : 0.0, xown ? cs * De * fabs(qe) : 0.0};
+    double v2[2] = {r.xown ? cs * s_nPm[r.xe] : 0.0, r.xown ? cs * De * fabs(qe) : 0.0};
     const bool s2[2] = {true, false};
-    block_reduce<2>(v2, s2, red);
+    block_reduce<2>(v2, s2, s_red);
     cs *= 1.0 / fmax(osqp_limit_scaling(v2[0] / n), osqp_limit_scaling(v2[1]));
   }
   out3[0] = De; out3[1] = Eo; out3[2] = cs;
@@ -550,14 +589,9 @@ __device__ __noinline__ void ruiz_equilibrate(const double *Pg, const double *Gl
 // tile row T and (times w) as the B operand of tile column T --, the command rows (identity) and rate rows (D = I - shift_3)
 // as a diagonal / third-off-diagonal fix-up.  gram: tile row w of this lane (24 values).
 template <int NTT>
-__device__ __forceinline__ void gram_tiles(d4_t *gram, const double *Gl, const double *Wg, const double *Wcv, const double *Wrv, int N) {
+__device__ __forceinline__ void gram_tiles(d4_t (&acc)[NT], int N) {
   const int n = 3 * N;
-  const int tid = threadIdx.x, w = tid >> 6;
-  // (inlined: a real call inside the factorisation loop pins every value that lives across it to the callee-saved half of
-  //  the register file.  Opaque lane indices keep the index arithmetic from being hoisted out of that loop.)
-  int lc = tid & 15, lq = (tid & 63) >> 4;
-  asm volatile("" : "+v"(lc), "+v"(lq));
-  d4_t acc[NT];
+  const int tid = threadIdx.x, w = tid >> 6, lc = tid & 15, lq = (tid & 63) >> 4;
 #pragma unroll
   for (int J = 0; J < NTT; ++J) acc[J] = d4_t{0.0, 0.0, 0.0, 0.0};
   if (w < NTT) {
@@ -577,13 +611,13 @@ __device__ __forceinline__ void gram_tiles(d4_t *gram, const double *Gl, const d
     for (int kk = (6 * ((16 * w) / 3)) >> 2; kk < nk; ++kk) {
       const int rw = 4 * kk + lq, i = rw / 6, rr = rw - 6 * i;
       const int base = 27 * i + 3 * (rr < 5 ? rr + 2 : 8);
-      const double wgt = Wg[rw];                             // 0 beyond row 6N
+      const double wgt = s_Wg[rw];                           // 0 beyond row 6N
       const bool vi = i < N;
-      const double a_op = (vi && i >= jW) ? Gl[base + offW] : 0.0;
+      const double a_op = (vi && i >= jW) ? s_Gl[base + offW] : 0.0;
 #pragma unroll
       for (int J = 0; J < NTT; ++J) {
         if (kk >= ((6 * ((16 * J) / 3)) >> 2)) {             // (uniform)
-          const double b_op = (vi && i >= jT[J]) ? Gl[base + offT[J]] * wgt : 0.0;
+          const double b_op = (vi && i >= jT[J]) ? s_Gl[base + offT[J]] * wgt : 0.0;
           acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op, acc[J], 0, 0, 0);
         }
       }
@@ -594,489 +628,433 @@ __device__ __forceinline__ void gram_tiles(d4_t *gram, const double *Gl, const d
       for (int qq = 0; qq < 4; ++qq) {
         const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
         if (i < n && j < n) {
-          if (i == j) acc[J][qq] += Wcv[i] + Wrv[i] + Wrv[i + 3];
-          else if (i == j + 3) acc[J][qq] -= Wrv[i];
-          else if (j == i + 3) acc[J][qq] -= Wrv[j];
+          if (i == j) acc[J][qq] += s_Wcv[i] + s_Wrv[i] + s_Wrv[i + 3];
+          else if (i == j + 3) acc[J][qq] -= s_Wrv[i];
+          else if (j == i + 3) acc[J][qq] -= s_Wrv[j];
         }
       }
   }
-#pragma unroll
-  for (int J = 0; J < NTT; ++J) gram[J] = acc[J];
 }
+
+// ---- One KKT factorisation: K = c P + sigma D^-2 + rho A'WA as matrix-core tiles (Gram product above; it does not depend
+// on rho, so the first factorisation of a solve parks it in the workspace `gw` and the rho updates read it back), blocked
+// sweep on the matrix cores (mfma_inverse), then the RE-LAYOUT for the iterations: lane q of DPP row blk receives
+// K^-1[3 blk + c][6 q + cc] (c < 3, cc < 6; the layout of the cached P entries) through LDS, one tile row at a time, in
+// the memory of the iteration vectors (dead during a factorisation).  rho <= 0 on entry: the builder's opt-in start value
+// 2 sqrt(tr P / tr A'A) (no equilibration).  mrow: 18 values per lane.  Returns whether every pivot block was positive
+// definite (uniform).
+template <int NTT>
+__device__ __noinline__ bool kkt_factorise(const double *Pg, double *gw, bool have_gram, int N, double cs, double sigma_unused,
+                                           double *rho_io, double *mrow) {
+  (void)sigma_unused;
+  const int n = 3 * N;
+  const LaneRole r = lane_role(N);
+  const int w = r.w, lc = r.lc, lq = r.lq;
+  d4_t acc[NT], pp[NT];
+  if (w < NTT) load_packed_tiles<NTT>(pp, Pg, n, w, lc, lq);       // P goes out first: its round trip hides under the Gram product
+  double *const gwl = gw ? gw + (size_t)(w * NT * 4) * 64 + r.l : nullptr;
+  if (gwl && have_gram) {
+    if (w < NTT) {
+#pragma unroll
+      for (int J = 0; J < NTT; ++J)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) acc[J][qq] = gwl[(J * 4 + qq) * 64];
+    }
+  } else {
+    gram_tiles<NTT>(acc, N);
+    if (gwl && w < NTT) {
+#pragma unroll
+      for (int J = 0; J < NTT; ++J)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) gwl[(J * 4 + qq) * 64] = acc[J][qq];
+    }
+  }
+  double rho = *rho_io;
+  if (!(rho > 0.0)) {   // the builder's opt-in start value (no equilibration): balance the two terms of P + rho A'A
+    double tr[2] = {r.xown ? Pg[tri(r.xe, r.xe)] : 0.0, 0.0};
+    if (w < NTT) {
+#pragma unroll
+      for (int J = 0; J < NTT; ++J)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
+          if (i == j && i < n) tr[1] += acc[J][qq];
+        }
+    }
+    const bool sums[2] = {true, true};
+    block_reduce<2>(tr, sums, s_red);
+    rho = fmin(fmax(RHO_AUTO_SCALE * sqrt(tr[0] / tr[1]), OSQP_RHO_MIN), OSQP_RHO_MAX);
+    *rho_io = rho;
+  }
+  if (w < NTT) {
+#pragma unroll
+    for (int J = 0; J < NTT; ++J)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
+        acc[J][qq] = (i < n && j < n) ? cs * pp[J][qq] + rho * acc[J][qq] + (i == j ? s_Dv[XOFF + i] : 0.0) : (i == j ? 1.0 : 0.0);
+      }
+  } else {
+#pragma unroll
+    for (int J = 0; J < NTT; ++J) acc[J] = d4_t{0.0, 0.0, 0.0, 0.0};
+  }
+  const bool ok = mfma_inverse<NTT>(acc, s_Cs, acc);
+  // re-layout (acc = MINUS the inverse, tile layout)
+  double mr[3][6];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) mr[c][cc] = 0.0;
+  for (int ww = 0; ww < NTT; ++ww) {
+    __syncthreads();
+    if (w == ww) {
+#pragma unroll
+      for (int J = 0; J < NTT; ++J)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) Mst[(4 * qq + lq) * FN + 16 * J + lc] = -acc[J][qq];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int i = 3 * r.blk + c;
+      if ((i >> 4) == ww) {
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) mr[c][cc] = (6 * r.q + cc) < 16 * NTT ? Mst[(i & 15) * FN + 6 * r.q + cc] : 0.0;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) mrow[c * 6 + cc] = mr[c][cc];
+  __syncthreads();                                          // Mst is read: its memory returns to the iteration vectors
+  return ok;
+}
+
+// ---- The iterations between two factorisations.
+struct SolveState {
+  double xs, z, y, dy;                 // this lane's variable (x owners) and constraint row: x, z, y = yb / E, last dy
+  double rho, rp, rd;
+  int it, to_check;
+  int done, converged, infeasible;
+};
+struct IterSettings { double alpha, eps_abs, eps_rel, eps_prim_inf; int max_iter, check_every, rho_every, adaptive_rho; };
 
 // One 512-lane workgroup per aircraft, three barriers per ADMM iteration:
-//   A  stage 1 partials + row reduce -> rhs = sigma D^-2 x - c q + A' E (rho zb - yb)              | barrier
-//   B  stage 2: x~ = Minv rhs straight from the MFMA accumulators of the inverse (tile-row waves) | barrier
-//   C  stage 3 partials + row reduce -> zb~ = E A x~ ; relaxation, projection, dual update, w = E (rho zb - yb) | barrier
+//   A  stage 1 partials + row reduce -> rhs = sigma D^-2 x - c q + A' W (rho z - y)                | barrier
+//   B  stage 2: x~ = K^-1 rhs, three rows x six columns per lane on all eight waves             | barrier
+//   C  stage 3 partials + row reduce -> z~ = A x~ ; relaxation, projection, dual update, w = W (rho z - y) | barrier
 // Lane roles inside DPP row blk (= horizon step): lanes 0,2,4,8,10,12 own the six kept state rows of step blk (that is
-// where reduce6 leaves their z~), lanes 1,3,5 the command rows, 9,11,13 the rate rows, lanes 0,4,8 also own x[3 blk + c];
-// during the equilibration lanes 6, 14, 7 stand in for the three state rows without bounds (phi, theta, lf1).
+// where reduce6 leaves their z~), lanes 1,3,5 the command rows, 9,11,13 the rate rows, lanes 0,4,8 also own x[3 blk + c].
+// Runs until the termination test is met, the problem is certified infeasible, max_iter is reached, or the rho estimate
+// leaves the 5x band (then st->rho holds the new value and the caller re-factorises).  Returns 1 in the last case.
+__device__ __noinline__ int admm_iterate(SolveState *st, const double *mrow_in, const double *Gg, int N, IterSettings o) {
+  const LaneRole r = lane_role(N);
+  const int blk = r.blk, q = r.q, kind = r.kind, k3 = r.k3, xe = r.xe, xec = r.xec, dup = r.dup;
+  const bool h = r.h, g = r.g, e = r.e, xown = r.xown;
+  const int lane = threadIdx.x;
+  double mrow[3][6], Gd[2][6][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) mrow[c][cc] = mrow_in[c * 6 + cc];
+  {   // the lane's two Toeplitz blocks (utils.py:171-197: CC[i,j] = A^(i-j) B, rows S kept, slot order of reduce6_slots)
+    constexpr int SR[6] = {2, 3, 4, 5, 6, 8};
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      const int d = 2 * q + bb;
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) {
+        const int srw = h ? SR[(rr + 3) % 6] : SR[rr];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Gd[bb][rr][c] = d < N ? Gg[d * 27 + srw * 3 + c] : 0.0;
+      }
+    }
+  }
+  double xs = st->xs, z = st->z, y = st->y, dy = st->dy, rho = st->rho, rp = st->rp, rd = st->rd;
+  int it = st->it, to_check = st->to_check;
+  bool done = false, converged = false, infeasible = false, refactor = false;
+  // per-lane constants of the loop: bounds, row weight, this lane's entry of the rho vector
+  const double lo = s_lc[lane], hi = s_lc[FT + lane], Wl = s_lc[2 * FT + lane], rho_o = rho * s_lc[3 * FT + lane], rinv = 1.0 / rho_o;
+  const double sgl = s_sg2[xec], qcl = s_cq[xec];
+  double *const wdst = w_slot(r, wsP, s_wc, s_wr);
+  const double *const wsrc = wsP + WROW * (blk + 2 * q) + (h ? 3 : 0);
+  // the iteration vectors (their memory carried the inverse during the re-layout): zero pads, then w of the current point
+  for (int i = lane; i < 2 * WSP + 2 * XTP; i += FT) s_itv[i] = 0.0;
+  __syncthreads();
+  if (kind) { const double w0 = Wl * (rho_o * z - y); wdst[0] = w0; wdst[dup] = w0; }
+  __syncthreads();
+  while (!done && !refactor) {
+    ++it;
+    // ---- A: rhs = sigma D^-2 x - c q + A' W (rho z - y)
+    {
+      double wv[12], o1[3];
+      stage1_load(wsrc, wv);
+      const double wce = s_wc[xec], wre = s_wr[xec], wrn = s_wr[xec + 3];
+      MPC_PHASE();
+      stage1_fma(Gd, wv, o1);
+      const double t = reduce3(o1[0], o1[1], o1[2], h, g);
+      if (xown) s_rhs[xe] = sgl * xs - qcl + (t + wce + (wre - wrn));
+    }
+    __syncthreads();
+    // ---- B: x~ = K^-1 rhs, three rows x six columns per lane; reduce3 leaves x~[3 blk + c] in lane 4c of the row
+    double xt_own;
+    {
+      double rj[6], p3[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) rj[cc] = s_rhs[6 * q + cc];
+      MPC_PHASE();
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p3[c] = fma(mrow[c][cc], rj[cc], p3[c]);
+      xt_own = reduce3(p3[0], p3[1], p3[2], h, g);
+      if (xown) xtP[XOFF + xe] = xt_own;
+    }
+    __syncthreads();
+    // ---- C: z~ = A x~, relaxation, projection, dual update (unscaled z, y = yb / E)
+    {
+      double xv[6], o3[6];
+      stage3_load(xtP + XOFF + 3 * (blk - 2 * q - 1), xv);
+      const double xk = xtP[XOFF + k3], xkm = xtP[XOFF + k3 - 3];
+      MPC_PHASE();
+      stage3_fma(Gd, xv, o3);
+      const double zs = reduce6_slots(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], g, e);
+      if (xown) xs = o.alpha * xt_own + (1 - o.alpha) * xs;
+      if (kind) {
+        const double zt = kind == 1 ? zs : (kind == 2 ? xk : xk - xkm);
+        const double zr = o.alpha * zt + (1 - o.alpha) * z;
+        const double zn = fmin(fmax(fma(y, rinv, zr), lo), hi);
+        dy = rho_o * (zr - zn);
+        y = y + dy;
+        z = zn;
+      }
+    }
+    const bool check = --to_check == 0 || it >= o.max_iter;      // it % check_every == 0, without the division
+    if (to_check == 0) to_check = o.check_every;
+    if (check) {
+      // ---- residuals (OSQP termination test on the UNSCALED problem): A x, P x, A' W y / c.  x goes to its own zero-padded
+      // buffer (x~ may still be read by slower waves), W y to the state-row layout; one barrier, then everything of the
+      // test in one reduction (the two quantities of the primal-infeasibility certificate ride along)
+      const double cinv = s_cinv;
+      double *const ydst = w_slot(r, ysP, s_yc, s_yr);
+      const double *const ysrc = ysP + WROW * (blk + 2 * q) + (h ? 3 : 0);
+      if (kind) { const double ye = Wl * y; ydst[0] = ye; ydst[dup] = ye; }
+      if (xown) xcP[XOFF + xe] = xs;
+      __syncthreads();
+      double o3[6], o1[3], px3[3] = {0.0, 0.0, 0.0};
+      { double xv[6]; stage3_load(xcP + XOFF + 3 * (blk - 2 * q - 1), xv); stage3_fma(Gd, xv, o3); }
+      const double axs = reduce6_slots(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], g, e);
+      { double wv[12]; stage1_load(ysrc, wv); stage1_fma(Gd, wv, o1); }
+      const double atys = reduce3(o1[0], o1[1], o1[2], h, g);
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) {                          // P x from the cached entries (zeros outside the matrix)
+        const double xv = xcP[XOFF + 6 * q + cc];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) px3[c] = fma(s_px[(cc * 3 + c) * FT + lane], xv, px3[c]);
+      }
+      const double px = reduce3(px3[0], px3[1], px3[2], h, g);
+      const double qu = s_q[xec];
+      double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};              // r1, |Ax|, |z|, r2, |Px|, |A'y|, |q|, |E dyb|, support(dyb)
+      double ax = 0.0, aty = 0.0;
+      if (kind) {
+        ax = kind == 1 ? axs : (kind == 2 ? xcP[XOFF + k3] : xcP[XOFF + k3] - xcP[XOFF + k3 - 3]);
+        v[0] = fabs(ax - z); v[1] = fabs(ax); v[2] = fabs(z);
+        v[7] = Wl * fabs(dy); v[8] = Wl * (hi * fmax(dy, 0.0) + lo * fmin(dy, 0.0));
+      }
+      if (xown) {
+        aty = cinv * (atys + s_yc[xe] + (s_yr[xe] - s_yr[xe + 3]));
+        v[3] = fabs(px + qu + aty); v[4] = fabs(px); v[5] = fabs(aty); v[6] = fabs(qu);
+      }
+      const bool issum[9] = {false, false, false, false, false, false, false, false, true};
+      block_reduce<9>(v, issum, s_red);
+      rp = v[0]; rd = v[3];
+      const double np_ = fmax(v[1], v[2]), nd_ = fmax(fmax(v[4], v[5]), v[6]);
+      if (rp < o.eps_abs + o.eps_rel * np_ && rd < o.eps_abs + o.eps_rel * nd_) { done = true; converged = true; }
+      else {
+        // OSQP primal-infeasibility certificate on dy (auxil.c:is_primal_infeasible)
+        const double ndy = v[7], supp = v[8];
+        if (ndy > o.eps_prim_inf && supp < -o.eps_prim_inf * ndy) {
+          if (kind) { const double de = Wl * dy; ydst[0] = de; ydst[dup] = de; }
+          __syncthreads();
+          { double wv[12]; stage1_load(ysrc, wv); stage1_fma(Gd, wv, o1); }
+          const double t = reduce3(o1[0], o1[1], o1[2], h, g);
+          double wv[1] = {xown ? fabs(t + s_yc[xe] + (s_yr[xe] - s_yr[xe + 3])) : 0.0};
+          const bool km[1] = {false};
+          block_reduce<1>(wv, km, s_red);
+          if (wv[0] < o.eps_prim_inf * ndy) { done = true; infeasible = true; }
+        }
+        if (!done) {
+          if (it >= o.max_iter) done = true;
+          else if (o.adaptive_rho && it % o.rho_every == 0) {
+            // auxil.c:compute_rho_estimate on the SCALED residuals: ||Ab xb - zb||, ||Pb xb + qb + Ab' yb|| and their norms
+            const double cD = s_cD[xec], Er = sqrt(Wl);
+            double sv[7] = {0, 0, 0, 0, 0, 0, 0};
+            if (kind) { sv[0] = Er * fabs(ax - z); sv[1] = Er * fabs(ax); sv[2] = Er * fabs(z); }
+            if (xown) { sv[3] = cD * fabs(px + qu + aty); sv[4] = cD * fabs(px); sv[5] = cD * fabs(aty); sv[6] = cD * fabs(qu); }
+            const bool mx[7] = {false, false, false, false, false, false, false};
+            block_reduce<7>(sv, mx, s_red);
+            const double pr = sv[0] / (fmax(sv[2], sv[1]) + 1e-10), dr = sv[3] / (fmax(fmax(sv[6], sv[5]), sv[4]) + 1e-10);
+            const double nw = fmin(fmax(rho * sqrt(pr / (dr + 1e-10)), OSQP_RHO_MIN), OSQP_RHO_MAX);
+            if (nw > OSQP_ADAPTIVE_RHO_TOLERANCE * rho || nw < rho / OSQP_ADAPTIVE_RHO_TOLERANCE) { rho = nw; refactor = true; }
+          }
+        }
+      }
+    }
+    // w = W (rho z - y) for the next iteration (after a rho update the next call rewrites it with the new rho)
+    if (kind) { const double wn = Wl * (rho_o * z - y); wdst[0] = wn; wdst[dup] = wn; }
+    __syncthreads();
+  }
+  st->xs = xs; st->z = z; st->y = y; st->dy = dy; st->rho = rho; st->rp = rp; st->rd = rd;
+  st->it = it; st->to_check = to_check;
+  st->done = done; st->converged = converged; st->infeasible = infeasible;
+  return refactor ? 1 : 0;
+}
+
+// The solve of one aircraft per workgroup (grid = B): prologue (loads, bounds, constants into LDS), equilibration, then
+// factorise / iterate until done.  mode 0 one-shot; 1 prepare a plan without equilibration (factorise, keep the re-laid
+// inverse and its rho, no iterations); 2 solve from such a plan.
 template <int NTT>
 __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
-  // the iteration's zero-padded vectors in ONE block: between iterations (during a factorisation) the same memory carries
-  // one tile row of the inverse on its way to the per-lane layout (Mst, 16 x 96 doubles)
-  __shared__ __attribute__((aligned(16))) double itv[2 * WSP + 2 * XTP];
-  double *const wsP = itv, *const ysP = itv + WSP, *const xtP = itv + 2 * WSP, *const xcP = itv + 2 * WSP + XTP, *const Mst = itv;
-  static_assert(2 * WSP + 2 * XTP >= 16 * FN, "the relayout buffer must fit in the iteration vectors");
-  __shared__ __attribute__((aligned(16))) double Cs[2 * FN * 4 + 40];
-  __shared__ double rhs[FN], wc[FN], wr[FN + 4], yc[FN], yr[FN + 4], red[8 * 9];
-  __shared__ double xo_sg2[FN], xo_cq[FN], xo_q[FN], xo_cD[FN], sh_cinv;      // constants of the x-owner lanes, by variable; 1/c
-  __shared__ double Dv[XTP], Es9[ES9], Ecv[FN], Erv[FN + 4], Wg[WGN], Wcv[FN], Wrv[FN + 4], nPm[FN];
-  __shared__ __attribute__((aligned(16))) double Gl[27 * FAST_MAXN];
-  extern __shared__ double pxL[];       // [18][FT] this lane's 18 entries of P (termination test) | [6][FT] lane constants
-
   const int N = a.N, n = 3 * N;
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lc = l & 15, lq = l >> 4, blk = tid >> 4, q = lc;
-  const bool h = lc & 8, g = lc & 4, e = lc & 2;
-  const bool inb = blk < N;
-  // ---- lane roles (fixed for the whole launch)
-  int kind = 0, sub = 0;                                       // 1 state row rr=sub, 2 command row c=sub, 3 rate row c=sub
-  if (inb) {
-    if (lc == 0 || lc == 2 || lc == 4) { kind = 1; sub = lc >> 1; }
-    else if (lc == 8 || lc == 10 || lc == 12) { kind = 1; sub = 3 + ((lc - 8) >> 1); }
-    else if (lc == 1 || lc == 3 || lc == 5) { kind = 2; sub = (lc - 1) >> 1; }
-    else if (lc == 9 || lc == 11 || lc == 13) { kind = 3; sub = (lc - 9) >> 1; }
+  const LaneRole r = lane_role(N);
+  const int tid = threadIdx.x, blk = r.blk, q = r.q, kind = r.kind, sub = r.sub, k3 = r.k3, xe = r.xe;
+  const bool inb = r.inb, xown = r.xown, srow = r.srow;
+  // zero what carries zero padding (the iteration vectors are zeroed by every admm_iterate call)
+  for (int i = tid; i < XTP; i += FT) s_Dv[i] = 0.0;
+  for (int i = tid; i < FN + 4; i += FT) { s_wr[i] = 0.0; s_yr[i] = 0.0; s_Erv[i] = 0.0; s_Wrv[i] = 0.0; }
+  for (int i = tid; i < FN; i += FT) { s_rhs[i] = 0.0; s_wc[i] = 0.0; s_yc[i] = 0.0; s_Ecv[i] = 0.0; s_Wcv[i] = 0.0; s_nPm[i] = 0.0;
+                                       s_sg2[i] = 0.0; s_cq[i] = 0.0; s_q[i] = 0.0; s_cD[i] = 0.0; }
+  for (int i = tid; i < ES9; i += FT) s_Es9[i] = 0.0;
+  for (int i = tid; i < WGN; i += FT) s_Wg[i] = 0.0;
+
+  // one aircraft per workgroup.  readfirstlane: the index is uniform, so every per-aircraft pointer below lives in scalar
+  // registers instead of a VGPR pair each
+  const long b = a.order ? (long)__builtin_amdgcn_readfirstlane(a.order[blockIdx.x]) : (long)blockIdx.x;
+  double *const exw = a.ext + (size_t)b * mpc_ext_doubles(N);
+  const double *Pg = a.Ppk + (size_t)b * (n * (n + 1) / 2);
+  const double *Gg = exw + n, *pred = exw + n + 27 * N;
+  double *const exm = exw + mpc_ext_model(N);                 // A | Q | Qbar | rho, ok of a prepared plan
+  for (int i = tid; i < 27 * N; i += FT) s_Gl[i] = Gg[i];
+  const double qe = xown ? exw[xe] : 0.0;
+  // the termination test needs P x: row blk's 16 lanes split the columns six apiece, so a lane touches the SAME 18
+  // entries of P at every test -- fetched once here into per-lane LDS slots
+#pragma unroll
+  for (int cc = 0; cc < 6; ++cc) {
+    const int col = 6 * q + cc;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int row = 3 * blk + c;
+      s_px[(cc * 3 + c) * FT + tid] = (inb && col < n) ? Pg[row >= col ? tri(row, col) : tri(col, row)] : 0.0;
+    }
   }
-  // x9 row of a state-row owner (kept rows: SROW[sub]; rows without bounds: lanes 6 -> phi, 14 -> theta, 7 -> lf1)
-  const int r9 = kind == 1 ? (sub < 5 ? sub + 2 : 8) : (lc == 6 ? 0 : (lc == 14 ? 1 : (lc == 7 ? 7 : -1)));
-  const bool srow = inb && r9 >= 0;
-  const int k3 = 3 * blk + sub;                                // index of a command / rate row
-  const bool xown = inb && (lc == 0 || lc == 4 || lc == 8);
-  const int xe = 3 * blk + (lc >> 2);
-  const int xec = xe < FN ? xe : FN - 1;                        // in-range index for lanes that own no variable
-  double *const wdst = kind == 1 ? wsP + WROW * blk + sub : (kind == 2 ? wc + k3 : wr + k3);
-  const int dup = (kind == 1 && sub < 3) ? 6 : 0;              // state rows 0..2 are stored twice (stage1_load)
-  const double *const wsrc = wsP + WROW * (blk + 2 * q) + (h ? 3 : 0);
-  double *const lcst = pxL + 18 * FT + tid;                   // lane constants (see below)
-  // zero everything once: the pads are never written again
-  for (int i = tid; i < XTP; i += FT) Dv[i] = 0.0;                // (the iteration vectors are zeroed after each factorisation)
-  for (int i = tid; i < FN + 4; i += FT) { wr[i] = 0.0; yr[i] = 0.0; Erv[i] = 0.0; Wrv[i] = 0.0; }
-  for (int i = tid; i < FN; i += FT) { rhs[i] = 0.0; wc[i] = 0.0; yc[i] = 0.0; Ecv[i] = 0.0; Wcv[i] = 0.0; nPm[i] = 0.0;
-                                       xo_sg2[i] = 0.0; xo_cq[i] = 0.0; xo_q[i] = 0.0; xo_cD[i] = 0.0; }
-  for (int i = tid; i < ES9; i += FT) Es9[i] = 0.0;
-  for (int i = tid; i < WGN; i += FT) Wg[i] = 0.0;
-
-  const double sigma = a.s.sigma, alpha = a.s.alpha;
-
-  {
-    // one aircraft per workgroup (grid = B).  readfirstlane: the index is uniform, so every per-aircraft pointer below lives in
-    // scalar registers instead of a VGPR pair each
-    const long b = a.order ? (long)__builtin_amdgcn_readfirstlane(a.order[blockIdx.x]) : (long)blockIdx.x;
-    double *const exw = a.ext + (size_t)b * mpc_ext_doubles(N);
-    const double *ex = exw;
-    const double *Pg = a.Ppk + (size_t)b * (n * (n + 1) / 2);
-    const double *Gg = ex + n, *pred = ex + n + 27 * N;
-    double *const exm = exw + mpc_ext_model(N);                 // A | Q | Qbar | rho, ok of a prepared plan
-#ifdef F16_EXP_STAMPM
-    const unsigned long long tP0 = __builtin_amdgcn_s_memtime();
-#endif
-    for (int i = tid; i < 27 * N; i += FT) Gl[i] = Gg[i];      // all nine rows of every G_k: equilibration + Gram
-    const double qe = xown ? ex[xe] : 0.0;
-    // the termination test needs P x: row blk's 16 lanes split the columns six apiece, so a lane touches the SAME 18
-    // entries of P at every test -- fetched once here, with the other prologue loads, into per-lane LDS slots (a test
-    // used to pay a global round trip: 5.4 iterations' worth of time per test, now 2)
-    double pv[18];
+  double *const tl = a.tiles ? a.tiles + (size_t)b * MPC_TILE_DOUBLES + tid : nullptr;      // [18][FT]: the re-laid inverse of a plan
+  double mrow[18];
+  if (a.mode == 2) {
 #pragma unroll
-    for (int cc = 0; cc < 6; ++cc) {
-      const int col = 6 * q + cc;
+    for (int k = 0; k < 18; ++k) mrow[k] = tl[k * FT];
+  }
+  // ---- equilibration: De = D of this lane's variable (x owners), Eo = E of this lane's constraint row, cs = c
+  // (a cached plan -- modes 1 and 2 -- exists only without equilibration: D = E = c = 1 there)
+  double De = 1.0, Eo = 1.0, cs = 1.0;
+  if (xown) s_Dv[XOFF + xe] = 1.0;
+  if (srow) s_Es9[9 * blk + r.r9] = 1.0;
+  if (kind == 2) s_Ecv[k3] = 1.0;
+  if (kind == 3) s_Erv[k3] = 1.0;
+  __syncthreads();                                            // zeros, G, D = E = 1 are in place
+  if (a.mode == 0 && a.s.scaling > 0) {
+    double o3[3];
+    ruiz_equilibrate<NTT>(Pg, N, a.s.scaling, qe, o3);
+    De = o3[0]; Eo = o3[1]; cs = o3[2];
+  }
+  if (kind == 0) Eo = 1.0;                                     // (lanes that stood in for an unbounded row)
+  // ---- bounds of this lane's constraint row (utils.py:129-152; rows with two infinite bounds are not kept)
+  double lo = 0.0, hi = 0.0;
+  if (kind == 1) {
+    const double pm = pred[blk * 9 + SROW[sub]];
+    lo = SLB[sub] - pm; hi = SUB[sub] - pm;
+  } else if (kind == 2) {
+    lo = ULB[sub]; hi = UUB[sub];
+  } else if (kind == 3) {
+    if (blk == 0) {
+      const double act = a.x ? a.x[(13 + sub) * a.ld + b] : 0.0;      // (no state when a plan is prepared)
+      lo = act + RLB[sub] * a.dt; hi = act + RUB[sub] * a.dt;
+    } else { lo = RLB[sub]; hi = RUB[sub]; }               // reference quirk: not scaled by dt (utils.py:151-152)
+  }
+  // rho vector (osqp auxil.c:set_rho_vec): an equality row (E (u - l) < 1e-4, i.e. after scaling) carries 1e3 rho
+  const double eqf = (kind && Eo * (hi - lo) < OSQP_RHO_TOL) ? OSQP_RHO_EQ_OVER_RHO_INEQ : 1.0;
+  const double Wrow = kind ? Eo * Eo : 0.0;                    // the row weight E^2: all the iterations see of E
+  if (kind == 1) s_Wg[6 * blk + sub] = Wrow * eqf;
+  else if (kind == 2) s_Wcv[k3] = Wrow * eqf;
+  else if (kind == 3) s_Wrv[k3] = Wrow * eqf;
+  s_lc[tid] = lo; s_lc[FT + tid] = hi; s_lc[2 * FT + tid] = Wrow; s_lc[3 * FT + tid] = eqf;
+  if (xown) {
+    const double sg2 = a.s.sigma / (De * De);
+    s_Dv[XOFF + xe] = sg2;                                     // s_Dv now holds sigma D^-2 for the KKT diagonal
+    s_sg2[xe] = sg2; s_cq[xe] = cs * qe; s_q[xe] = qe; s_cD[xe] = cs * De;
+  }
+  if (tid == 0) s_cinv = 1.0 / cs;
+  SolveState st;
+  st.xs = 0.0; st.z = 0.0; st.y = 0.0; st.dy = 0.0; st.rp = INFINITY; st.rd = INFINITY;
+  st.it = 0; st.to_check = a.s.check_every > 0 ? a.s.check_every : 1;
+  st.done = 0; st.converged = 0; st.infeasible = 0;
+  double *const wm = a.warm ? a.warm + (size_t)b * MPC_WARM_DOUBLES + tid : nullptr;
+  if (wm && a.warm_load) {   // warm start: x, z, y of the previous solve of this plan, kept UNscaled (the equilibration of an
+    const double x0 = wm[0], z0 = wm[FT], y0 = wm[2 * FT];      // OSQP-default plan is redone per solve: it depends on q)
+    if (isfinite(x0) && isfinite(z0) && isfinite(y0)) { st.xs = x0; st.z = z0; st.y = kind ? cs * y0 / Wrow : 0.0; }
+  }
+  st.rho = a.mode == 2 ? exm[243] : a.s.rho;
+  bool ok = true;
+  if (a.mode == 2 && !(exm[244] > 0.5)) ok = false;
+  __syncthreads();                                            // weights / sigma D^-2 / lane constants are in place
+  double *const gw = a.gramws ? a.gramws + (size_t)b * MPC_TILE_DOUBLES : nullptr;
+  IterSettings o;
+  o.alpha = a.s.alpha; o.eps_abs = a.s.eps_abs; o.eps_rel = a.s.eps_rel; o.eps_prim_inf = a.s.eps_prim_inf;
+  o.max_iter = a.s.max_iter; o.check_every = a.s.check_every; o.rho_every = a.s.rho_every; o.adaptive_rho = a.s.adaptive_rho;
+  bool have_inverse = a.mode == 2, have_gram = false;
+  bool done = a.s.max_iter < 0;                               // (max_iter == 0: factor only, used for timing)
+  while (!done) {
+    if (!have_inverse) {
+      ok = kkt_factorise<NTT>(Pg, gw, have_gram, N, cs, 0.0, &st.rho, mrow) && ok;
+      have_gram = true;
+      if (a.mode == 1) {                                      // prepare: keep the inverse and its rho, no iterations
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int row = 3 * blk + c;
-        pv[cc * 3 + c] = (inb && col < n) ? Pg[row >= col ? tri(row, col) : tri(col, row)] : 0.0;
+        for (int k = 0; k < 18; ++k) tl[k * FT] = mrow[k];
+        if (tid == 0) { exm[243] = st.rho; exm[244] = ok ? 1.0 : 0.0; }
+        return;
       }
     }
-    auto store_pv = [&]() {
-#pragma unroll
-      for (int k = 0; k < 18; ++k) pxL[k * FT + tid] = pv[k];
-    };
-    // The inverse K^-1 of c P + sigma D^-2 + rho A'WA is computed as matrix-core tiles (tile row w on wave w) and then
-    // RE-LAID for the iterations: lane q of DPP row blk holds K^-1[3 blk + c][6 q + cc] (c < 3, cc < 6) -- the layout of the
-    // cached P entries.  Stage 2 is then 18 FMAs on ALL eight waves and ends in the same reduce3 as stage 1, which leaves
-    // x~[3 blk + c] in the lane that owns that variable (24 FMAs on six waves + a four-value reduction before, and six
-    // more registers per lane: the N = 30 instantiation spilled its Toeplitz blocks inside the iteration loop).
-    double mrow[3][6];
-    double Gd[2][6][3];                                        // this lane's two Toeplitz blocks
-    auto relayout = [&](const d4_t (&acc)[NT]) {               // acc = MINUS the inverse, tile layout
-      // (opaque copies of the lane indices: otherwise the address arithmetic below, invariant for the factorisation loop, is
-      //  hoisted to the top of the kernel and held in registers across the iteration loop -- 87 VGPRs of such values made
-      //  the N = 30 instantiation spill its operators inside the loop)
-      int lc = (threadIdx.x & 15), lq = (threadIdx.x & 63) >> 4, blk = threadIdx.x >> 4;
-      asm volatile("" : "+v"(lc), "+v"(lq), "+v"(blk));
-      const int q = lc;
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int cc = 0; cc < 6; ++cc) mrow[c][cc] = 0.0;
-      for (int ww = 0; ww < NTT; ++ww) {
-        __syncthreads();
-        if (w == ww) {
-#pragma unroll
-          for (int J = 0; J < NTT; ++J)
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) Mst[(4 * qq + lq) * FN + 16 * J + lc] = -acc[J][qq];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const int i = 3 * blk + c;
-          if ((i >> 4) == ww) {
-#pragma unroll
-            for (int cc = 0; cc < 6; ++cc) mrow[c][cc] = (6 * q + cc) < 16 * NTT ? Mst[(i & 15) * FN + 6 * q + cc] : 0.0;
-          }
-        }
-      }
-    };
-    // the lane's two Toeplitz blocks (utils.py:171-197: CC[i,j] = A^(i-j) B, rows S kept, slot order of reduce6_slots)
-    auto load_Gd = [&]() {
-      constexpr int SR[6] = {2, 3, 4, 5, 6, 8};
-      int q = threadIdx.x & 15;
-      asm volatile("" : "+v"(q));
-      const bool h = q & 8;
-#pragma unroll
-      for (int bb = 0; bb < 2; ++bb) {
-        const int d = 2 * q + bb;
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr) {
-          const int srw = h ? SR[(rr + 3) % 6] : SR[rr];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) Gd[bb][rr][c] = d < N ? Gg[d * 27 + srw * 3 + c] : 0.0;
-        }
-      }
-    };
-    double *const tl = a.tiles ? a.tiles + (size_t)b * MPC_TILE_DOUBLES + tid : nullptr;      // [18][FT]: the re-laid inverse
-    if (a.mode == 2) {
-      // a plan's solve starts from HBM-cold data: the inverse (18 loads per lane, 512-byte runs), Toeplitz blocks (36) and
-      // the P entries (18) go out in ONE batch, ahead of everything that waits for a load, instead of three serial round trips
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int cc = 0; cc < 6; ++cc) mrow[c][cc] = tl[(c * 6 + cc) * FT];
-      load_Gd();
+    have_inverse = false;
+    if (!ok || a.s.max_iter <= 0) break;
+    if (!admm_iterate(&st, mrow, Gg, N, o)) done = true;
+  }
+  const bool converged = st.converged != 0, infeasible = st.infeasible != 0;
+  // res.x[0:3] (env.py:424); OSQP hands back NaN for a problem it certifies infeasible
+  if (wm) {                                                  // keep the solution for the next warm start
+    const bool good = converged && !infeasible;
+    wm[0] = good ? st.xs : NAN; wm[FT] = good ? st.z : NAN; wm[2 * FT] = good ? Wrow * st.y / cs : NAN;
+  }
+  if (xown) {
+    if (xe < 3) a.ucmd[xe * a.ld + b] = infeasible ? NAN : st.xs;
+    if (a.useq) a.useq[xe * a.ld + b] = infeasible ? NAN : st.xs;
+  }
+  if (tid == 0) {
+    if (a.iters_out) a.iters_out[b] = st.it;
+    if (a.info) {
+      a.info[0 * a.ld + b] = (double)st.it;
+      a.info[1 * a.ld + b] = st.rp;
+      a.info[2 * a.ld + b] = st.rd;
+      a.info[3 * a.ld + b] = st.rho;
     }
-    // ---- equilibration state: De = D of this lane's variable (x owners), Eo = E of this lane's constraint row, cs = c
-    double De = 1.0, Eo = 1.0, cs = 1.0;
-    // (a cached plan -- modes 1 and 2 -- exists only without equilibration: D = E = c = 1 there)
-    if (xown) Dv[XOFF + xe] = De;
-    if (srow) Es9[9 * blk + r9] = Eo;
-    if (kind == 2) Ecv[k3] = Eo;
-    if (kind == 3) Erv[k3] = Eo;
-    __syncthreads();                                            // zeros, Gl, D / E = 1 (or the plan's) are in place
-
-    if (a.mode != 2 && a.s.scaling > 0) {
-      double o3[3];
-      ruiz_equilibrate<NTT>(Pg, Gl, Dv, Es9, Ecv, Erv, nPm, red, N, a.s.scaling, qe, o3);
-      De = o3[0]; Eo = o3[1]; cs = o3[2];
-    }
-    if (kind == 0) Eo = 1.0;                                     // (lanes that stood in for an unbounded row)
-    // ---- bounds of this lane's constraint row (utils.py:129-152; rows with two infinite bounds are not kept), scaled by E
-    double lo = 0.0, hi = 0.0, z = 0.0, y = 0.0, dy = 0.0, xs = 0.0;
-    if (kind == 1) {
-      const double pm = pred[blk * 9 + SROW[sub]];
-      lo = SLB[sub] - pm; hi = SUB[sub] - pm;
-    } else if (kind == 2) {
-      lo = ULB[sub]; hi = UUB[sub];
-    } else if (kind == 3) {
-      if (blk == 0) {
-        const double act = a.x ? a.x[(13 + sub) * a.ld + b] : 0.0;      // (no state when a plan is prepared)
-        lo = act + RLB[sub] * a.dt; hi = act + RUB[sub] * a.dt;
-      } else { lo = RLB[sub]; hi = RUB[sub]; }               // reference quirk: not scaled by dt (utils.py:151-152)
-    }
-    // rho vector (osqp auxil.c:set_rho_vec): an equality row (E (u - l) < 1e-4, i.e. after scaling) carries 1e3 rho
-    const double eqf = (kind && Eo * (hi - lo) < OSQP_RHO_TOL) ? OSQP_RHO_EQ_OVER_RHO_INEQ : 1.0;
-    const double Wrow = kind ? Eo * Eo : 0.0;                    // the row weight E^2: all the iteration sees of E
-    if (kind == 1) Wg[6 * blk + sub] = Wrow * eqf;
-    else if (kind == 2) Wcv[k3] = Wrow * eqf;
-    else if (kind == 3) Wrv[k3] = Wrow * eqf;
-    const double sg2 = xown ? sigma / (De * De) : 0.0;           // sigma D^-2 (x owners)
-    if (xown) Dv[XOFF + xe] = sg2;                               // Dv now holds sigma D^-2 for the KKT diagonal
-    // lane constants live in LDS (registers are the scarce resource of the iteration loop).  Per constraint row:
-    // [0] lower bound  [1] upper bound  [2] row weight W = E^2  [3] rho-vector factor  (+ [4] this lane's rho-vector
-    // entry, [5] its reciprocal: written per factorisation); per variable (x owners): sigma D^-2, c q, q, c D; 1/c in red.
-    lcst[0] = lo; lcst[FT] = hi; lcst[2 * FT] = Wrow; lcst[3 * FT] = eqf;
-    if (xown) { xo_sg2[xe] = sg2; xo_cq[xe] = cs * qe; xo_q[xe] = qe; xo_cD[xe] = cs * De; }
-    if (tid == 0) sh_cinv = 1.0 / cs;
-    double *const wm = a.warm ? a.warm + (size_t)b * MPC_WARM_DOUBLES + tid : nullptr;
-    if (wm && a.warm_load) {   // warm start: x, z, y of the previous solve of this plan, kept UNscaled (the equilibration of an
-      const double x0 = wm[0], z0 = wm[FT], y0 = wm[2 * FT];      // OSQP-default plan is redone per solve: it depends on q)
-      if (isfinite(x0) && isfinite(z0) && isfinite(y0)) { xs = x0; z = z0; y = kind ? cs * y0 / Wrow : 0.0; }
-    }
-    double rho = a.mode == 2 ? exm[243] : a.s.rho;
-    store_pv();
-    __syncthreads();                                            // Wg / Wcv / Wrv / sigma D^-2 are in place
-
-    // ---- KKT matrix  c P + sigma D^-2 + rho A'WA  as matrix-core tiles (gram_tiles above); formed inside the factorisation
-    // block below so that the 24 Gram values per lane do not live across the iteration loop
-    auto kkt_tiles = [&](d4_t (&acc)[NT], const d4_t (&gram)[NT], double r) {     // acc <- c P + sigma D^-2 + r A'WA (identity on the padding)
-      int lc = (threadIdx.x & 15), lq = (threadIdx.x & 63) >> 4;  // (opaque: see relayout)
-      asm volatile("" : "+v"(lc), "+v"(lq));
-      if (w < NTT) {
-        d4_t pp[NT];
-        load_packed_tiles<NTT>(pp, Pg, n, w, lc, lq);
-#pragma unroll
-        for (int J = 0; J < NTT; ++J)
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
-            acc[J][qq] = (i < n && j < n) ? cs * pp[J][qq] + r * gram[J][qq] + (i == j ? Dv[XOFF + i] : 0.0) : (i == j ? 1.0 : 0.0);
-          }
-      } else {
-#pragma unroll
-        for (int J = 0; J < NTT; ++J) acc[J] = d4_t{0.0, 0.0, 0.0, 0.0};
-      }
-    };
-    int it = 0, to_check = a.s.check_every > 0 ? a.s.check_every : 1;
-    double rp = INFINITY, rd = INFINITY;
-    bool converged = false, infeasible = false, ok = true;
-    bool done = a.s.max_iter < 0;                              // (max_iter == 0: factor only, used for timing)
-    bool from_plan = a.mode == 2;                              // first factorisation comes out of the plan
-    if (from_plan && !(exm[244] > 0.5)) ok = false;
-#ifdef F16_EXP_STAMPM
-    unsigned long long tS[6] = {0, 0, 0, 0, 0, 0}, tP1 = 0, tP2 = 0, t0 = 0, tF[5] = {0, 0, 0, 0, 0};
-#define MSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t1 = __builtin_amdgcn_s_memtime(); tS[i] += t1 - t0; t0 = t1; }
-#else
-#define MSTAMP(i)
-#endif
-    bool plan_loaded = false;
-    if (from_plan) {                                           // (loads issued at the top of the prologue)
-      from_plan = false; plan_loaded = true;
-    }
-    // outer loop: one trip per KKT factorisation (rho changes at most every rho_every iterations).
-    while (!done) {
-      {
-#ifdef F16_EXP_STAMPM
-        __builtin_amdgcn_s_waitcnt(0);
-        tP1 = __builtin_amdgcn_s_memtime();
-#endif
-        if (plan_loaded) {
-          plan_loaded = false;
-        } else {
-          {
-            d4_t gram[NT], acc[NT];
-#ifdef F16_EXP_STAMPM
-#define FSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); tF[i] = __builtin_amdgcn_s_memtime(); }
-#else
-#define FSTAMP(i)
-#endif
-            FSTAMP(0)
-            gram_tiles<NTT>(gram, Gl, Wg, Wcv, Wrv, N);
-            FSTAMP(1)
-            if (!(rho > 0.0)) {   // the builder's opt-in start value (no equilibration): balance the two terms of P + rho A'A
-              int lc_ = (threadIdx.x & 15), lq_ = (threadIdx.x & 63) >> 4;
-              asm volatile("" : "+v"(lc_), "+v"(lq_));
-              double tr[2] = {xown ? Pg[tri(xe, xe)] : 0.0, 0.0};
-              if (w < NTT) {
-#pragma unroll
-                for (int J = 0; J < NTT; ++J)
-#pragma unroll
-                  for (int qq = 0; qq < 4; ++qq) {
-                    const int i = 16 * w + 4 * qq + lq_, j = 16 * J + lc_;
-                    if (i == j && i < n) tr[1] += gram[J][qq];
-                  }
-              }
-              const bool sums[2] = {true, true};
-              block_reduce<2>(tr, sums, red);
-              rho = fmin(fmax(RHO_AUTO_SCALE * sqrt(tr[0] / tr[1]), OSQP_RHO_MIN), OSQP_RHO_MAX);
-            }
-            kkt_tiles(acc, gram, rho);
-            FSTAMP(2)
-            ok = mfma_inverse<NTT>(acc, Cs, acc) && ok;
-            FSTAMP(3)
-            relayout(acc);
-            FSTAMP(4)
-          }
-          if (a.mode == 1) {                                   // prepare: keep the factorisation and its rho, no iterations
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-              for (int cc = 0; cc < 6; ++cc) tl[(c * 6 + cc) * FT] = mrow[c][cc];
-            if (tid == 0) { exm[243] = rho; exm[244] = ok ? 1.0 : 0.0; }
-            done = true;
-          }
-          load_Gd();                                           // after the factorisation: nothing big is live across it
-        }
-#ifdef F16_EXP_STAMPM
-        tP2 = __builtin_amdgcn_s_memtime();
-        t0 = tP2;
-#endif
-      }
-      // the iteration vectors (their memory carried the inverse during the re-layout): zero pads, then w = W (rho z - y) of
-      // the current point (zero at a cold start)
-      __syncthreads();
-      for (int i = tid; i < 2 * WSP + 2 * XTP; i += FT) itv[i] = 0.0;
-      __syncthreads();
-      {
-        const double ro = rho * lcst[3 * FT];                    // this lane's entry of the rho vector
-        lcst[4 * FT] = ro; lcst[5 * FT] = 1.0 / ro;
-        if (kind) { const double w0 = lcst[2 * FT] * (ro * z - y); wdst[0] = w0; wdst[dup] = w0; }
-      }
-      bool refactor = false;
-      if (!ok || a.s.max_iter <= 0) done = true;
-      __syncthreads();
-    while (!done && !refactor) {
-      ++it;
-      // ---- A: rhs = sigma D^-2 x - c q + A' W (rho z - y)
-      {
-        double wv[12], o1[3];
-        stage1_load(wsrc, wv);
-        const double wce = wc[xec], wre = wr[xec], wrn = wr[xec + 3], sgl = xo_sg2[xec], qcl = xo_cq[xec];
-        MPC_PHASE();
-        stage1_fma(Gd, wv, o1);
-        const double t = reduce3(o1[0], o1[1], o1[2], h, g);
-        if (xown) rhs[xe] = sgl * xs - qcl + (t + wce + (wre - wrn));
-      }
-      MSTAMP(0)
-      __syncthreads();
-      MSTAMP(1)
-      // ---- B: x~ = K^-1 rhs, three rows x six columns per lane; reduce3 leaves x~[3 blk + c] in lane 4c of the row
-      double xt_own;
-      {
-        double rj[6], p3[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-        for (int cc = 0; cc < 6; ++cc) rj[cc] = rhs[6 * q + cc];
-        MPC_PHASE();
-#pragma unroll
-        for (int cc = 0; cc < 6; ++cc)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) p3[c] = fma(mrow[c][cc], rj[cc], p3[c]);
-        xt_own = reduce3(p3[0], p3[1], p3[2], h, g);
-        if (xown) xtP[XOFF + xe] = xt_own;
-      }
-      MSTAMP(2)
-      __syncthreads();
-      MSTAMP(3)
-      // ---- C: z~ = A x~, relaxation, projection, dual update (unscaled z, y = yb / E)
-      double wnext = 0.0;
-      {
-        double xv[6], o3[6];
-        stage3_load(xtP + XOFF + 3 * (blk - 2 * q - 1), xv);
-        const double xk = xtP[XOFF + k3], xkm = xtP[XOFF + k3 - 3], lo = lcst[0], hi = lcst[FT];
-        const double Wl = lcst[2 * FT], rho_o = lcst[4 * FT], rinv = lcst[5 * FT];
-        MPC_PHASE();
-        stage3_fma(Gd, xv, o3);
-        const double zs = reduce6_slots(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], g, e);
-        if (xown) xs = alpha * xt_own + (1 - alpha) * xs;
-        if (kind) {
-          const double zt = kind == 1 ? zs : (kind == 2 ? xk : xk - xkm);
-          const double zr = alpha * zt + (1 - alpha) * z;
-          const double zn = fmin(fmax(fma(y, rinv, zr), lo), hi);
-          dy = rho_o * (zr - zn);
-          y = y + dy;
-          z = zn;
-          wnext = Wl * (rho_o * z - y);                          // w = W (rho z - y) for the next iteration
-        }
-      }
-      const bool check = --to_check == 0 || it >= a.s.max_iter;      // it % check_every == 0, without the division
-      if (to_check == 0) to_check = a.s.check_every;
-      if (check) {
-        // ---- residuals (OSQP termination test on the UNSCALED problem): A x, P x, A' W y / c.  x goes to its own zero-padded
-        // buffer (x~ may still be read by slower waves), E yb to the state-row layout; one barrier, then everything of the
-        // test in one reduction (the two quantities of the primal-infeasibility certificate ride along)
-        const double Wt = lcst[2 * FT], cinv = sh_cinv;
-        int blk_ = blk, q_ = q;                                   // (opaque: keep the test's address arithmetic inside the test)
-        asm volatile("" : "+v"(blk_), "+v"(q_));
-        double *const ydst = kind == 1 ? ysP + WROW * blk_ + sub : (kind == 2 ? yc + 3 * blk_ + sub : yr + 3 * blk_ + sub);
-        const double *const ysrc = ysP + WROW * (blk_ + 2 * q_) + ((q_ & 8) ? 3 : 0);
-        if (kind) { const double ye = Wt * y; ydst[0] = ye; ydst[dup] = ye; }
-        if (xown) xcP[XOFF + xe] = xs;
-        __syncthreads();
-        double o3[6], o1[3], px3[3] = {0.0, 0.0, 0.0};
-        { double xv[6]; stage3_load(xcP + XOFF + 3 * (blk_ - 2 * q_ - 1), xv); stage3_fma(Gd, xv, o3); }
-        const double axs = reduce6_slots(o3[0], o3[1], o3[2], o3[3], o3[4], o3[5], g, e);
-        { double wv[12]; stage1_load(ysrc, wv); stage1_fma(Gd, wv, o1); }
-        const double atys = reduce3(o1[0], o1[1], o1[2], h, g);
-#pragma unroll
-        for (int cc = 0; cc < 6; ++cc) {                          // P x from the cached entries (zeros outside the matrix)
-          const double xv = xcP[XOFF + 6 * q_ + cc];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) px3[c] = fma(pxL[(cc * 3 + c) * FT + 16 * blk_ + q_], xv, px3[c]);
-        }
-        const double px = reduce3(px3[0], px3[1], px3[2], h, g);
-        const double qu = xo_q[xec];
-        double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};              // r1, |Ax|, |z|, r2, |Px|, |A'y|, |q|, |E dyb|, support(dyb)
-        double ax = 0.0, aty = 0.0;
-        if (kind) {
-          ax = kind == 1 ? axs : (kind == 2 ? xcP[XOFF + k3] : xcP[XOFF + k3] - xcP[XOFF + k3 - 3]);
-          v[0] = fabs(ax - z); v[1] = fabs(ax); v[2] = fabs(z);
-          v[7] = Wt * fabs(dy); v[8] = Wt * (lcst[FT] * fmax(dy, 0.0) + lcst[0] * fmin(dy, 0.0));
-        }
-        if (xown) {
-          aty = cinv * (atys + yc[xe] + (yr[xe] - yr[xe + 3]));
-          v[3] = fabs(px + qu + aty); v[4] = fabs(px); v[5] = fabs(aty); v[6] = fabs(qu);
-        }
-        const bool issum[9] = {false, false, false, false, false, false, false, false, true};
-        block_reduce<9>(v, issum, red);
-        rp = v[0]; rd = v[3];
-        const double np_ = fmax(v[1], v[2]), nd_ = fmax(fmax(v[4], v[5]), v[6]);
-        if (rp < a.s.eps_abs + a.s.eps_rel * np_ && rd < a.s.eps_abs + a.s.eps_rel * nd_) { done = true; converged = true; }
-        else {
-          // OSQP primal-infeasibility certificate on dy (auxil.c:is_primal_infeasible)
-          const double ndy = v[7], supp = v[8];
-          if (ndy > a.s.eps_prim_inf && supp < -a.s.eps_prim_inf * ndy) {
-            if (kind) { const double de = Wt * dy; ydst[0] = de; ydst[dup] = de; }
-            __syncthreads();
-            { double wv[12]; stage1_load(ysrc, wv); stage1_fma(Gd, wv, o1); }
-            const double t = reduce3(o1[0], o1[1], o1[2], h, g);
-            double wv[1] = {xown ? fabs(t + yc[xe] + (yr[xe] - yr[xe + 3])) : 0.0};
-            const bool km[1] = {false};
-            block_reduce<1>(wv, km, red);
-            if (wv[0] < a.s.eps_prim_inf * ndy) { done = true; infeasible = true; }
-          }
-          if (!done) {
-            if (it >= a.s.max_iter) done = true;
-            else if (a.s.adaptive_rho && it % a.s.rho_every == 0) {
-              // auxil.c:compute_rho_estimate on the SCALED residuals: ||Ab xb - zb||, ||Pb xb + qb + Ab' yb|| and their norms
-              const double cD = xo_cD[xec], Er = sqrt(Wt);
-              double s[7] = {0, 0, 0, 0, 0, 0, 0};
-              if (kind) { s[0] = Er * fabs(ax - z); s[1] = Er * fabs(ax); s[2] = Er * fabs(z); }
-              if (xown) { s[3] = cD * fabs(px + qu + aty); s[4] = cD * fabs(px); s[5] = cD * fabs(aty); s[6] = cD * fabs(qu); }
-              const bool mx[7] = {false, false, false, false, false, false, false};
-              block_reduce<7>(s, mx, red);
-              const double pr = s[0] / (fmax(s[2], s[1]) + 1e-10), dr = s[3] / (fmax(fmax(s[6], s[5]), s[4]) + 1e-10);
-              const double nw = fmin(fmax(rho * sqrt(pr / (dr + 1e-10)), OSQP_RHO_MIN), OSQP_RHO_MAX);
-              if (nw > OSQP_ADAPTIVE_RHO_TOLERANCE * rho || nw < rho / OSQP_ADAPTIVE_RHO_TOLERANCE) { rho = nw; refactor = true; }
-            }
-          }
-        }
-      }
-      if (kind) {
-        wdst[0] = wnext; wdst[dup] = wnext;                    // (after a rho update the next factorisation rewrites it)
-      }
-      MSTAMP(4)
-      __syncthreads();
-      MSTAMP(5)
-      }
-    }
-
-    // res.x[0:3] (env.py:424); OSQP hands back NaN for a problem it certifies infeasible
-    if (a.mode == 1) return;                                   // a plan has no solution yet
-    if (wm) {                                                  // keep the solution for the next warm start
-      const bool good = converged && !infeasible;
-      wm[0] = good ? xs : NAN; wm[FT] = good ? z : NAN; wm[2 * FT] = good ? lcst[2 * FT] * y * sh_cinv : NAN;
-    }
-    if (xown) {
-      if (xe < 3) a.ucmd[xe * a.ld + b] = infeasible ? NAN : xs;
-      if (a.useq) a.useq[xe * a.ld + b] = infeasible ? NAN : xs;
-    }
-    if (tid == 0) {
-      if (a.iters_out) a.iters_out[b] = it;
-      if (a.info) {
-        a.info[0 * a.ld + b] = (double)it;
-        a.info[1 * a.ld + b] = rp;
-        a.info[2 * a.ld + b] = rd;
-        a.info[3 * a.ld + b] = rho;
-      }
-      if (a.status && infeasible) a.status[b] |= F16_ST_QP_INFEASIBLE;
-      else if (a.status && a.s.max_iter > 0 && (!converged || !ok)) a.status[b] |= F16_ST_QP_MAXITER;
-    }
-#ifdef F16_EXP_STAMPM
-    __syncthreads();      // diagnostic build: aircraft 0's u_seq column is replaced by the stamps
-    if ((tid & 63) == 0 && a.useq && b == 0) for (int i = 0; i < 6; ++i) a.useq[(6 * (tid >> 6) + i) * a.ld] = (double)tS[i] / it;
-    if (tid == 0 && a.useq && b == 0) { a.useq[48 * a.ld] = (double)(tP1 - tP0); a.useq[49 * a.ld] = (double)(tP2 - tP1);
-      for (int i = 0; i < 4; ++i) a.useq[(66 + i) * a.ld] = (double)(tF[i + 1] - tF[i]); }
-    if (tid < 16 && a.useq && b == 0) a.useq[(50 + tid) * a.ld] = g_inv_stamp[tid];
-#endif
+    if (a.status && infeasible) a.status[b] |= F16_ST_QP_INFEASIBLE;
+    else if (a.status && a.s.max_iter > 0 && (!converged || !ok)) a.status[b] |= F16_ST_QP_MAXITER;
   }
 }
+#undef wsP
+#undef ysP
+#undef xtP
+#undef xcP
+#undef Mst
 
 // Dispatch order of a plan's next solve: aircraft sorted by the iteration count of the previous solve, longest first
 // (counting sort over the termination-test buckets; one workgroup).  The hardware hands workgroups to CUs in index
@@ -1109,24 +1087,9 @@ int mpc_fast_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
   if (a.B > 0x7fffffffL) return set_error(F16_EINVAL, "batch too large for one launch");
   const unsigned grid = (unsigned)a.B;
   const int nt = (3 * a.N + 15) / 16;       // 16x16 tiles per side of the KKT matrix, instantiated for 2 / 4 / 6
-  constexpr size_t dyn = 24 * FT * sizeof(double);      // per-lane P entries for the termination test + lane constants (98 KB)
-  {   // static + dynamic LDS exceed 64 KB: opt in, once per device (not per launch: a plan's solve may run under capture)
-    static std::mutex mu;
-    static bool ready[64] = {};
-    int dev = 0;
-    if (int rc = hip_check(hipGetDevice(&dev), "hipGetDevice")) return rc;
-    std::lock_guard<std::mutex> lk(mu);
-    if (dev >= 0 && dev < 64 && !ready[dev]) {
-      hipError_t e = hipFuncSetAttribute((const void *)k_mpc_fast<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_mpc_fast<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_mpc_fast<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-      if (int rc = hip_check(e, "hipFuncSetAttribute(k_mpc_fast)")) return rc;
-      ready[dev] = true;
-    }
-  }
-  if (nt <= 2) hipLaunchKernelGGL(k_mpc_fast<2>, dim3(grid), dim3(FT), dyn, (hipStream_t)stream, a);
-  else if (nt <= 4) hipLaunchKernelGGL(k_mpc_fast<4>, dim3(grid), dim3(FT), dyn, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(k_mpc_fast<6>, dim3(grid), dim3(FT), dyn, (hipStream_t)stream, a);
+  if (nt <= 2) hipLaunchKernelGGL(k_mpc_fast<2>, dim3(grid), dim3(FT), 0, (hipStream_t)stream, a);
+  else if (nt <= 4) hipLaunchKernelGGL(k_mpc_fast<4>, dim3(grid), dim3(FT), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_mpc_fast<6>, dim3(grid), dim3(FT), 0, (hipStream_t)stream, a);
   return hip_check(hipGetLastError(), "f16_mpc_batch solve launch");
 }
 
