@@ -73,6 +73,8 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], const bool (&is_su
 typedef double d4_t __attribute__((ext_vector_type(4)));
 #ifdef F16_EXP_STAMPM
 __device__ double g_inv_stamp[16];      // diagnostic build: per-wave work / barrier-wait cycles of the factorisation
+__device__ double g_it_stamp[8 * 6];    // per wave: cycles in phase A, barrier, B, barrier, C (+ test), barrier, summed over iterations
+__device__ double g_f_stamp[6];         // last factorisation of workgroup 0: Gram, assembly, sweep, re-layout; equilibration; iterations stamped
 #endif
 constexpr int NT = FN / 16;   // 6 tile rows / columns
 
@@ -651,6 +653,13 @@ __device__ __noinline__ bool kkt_factorise(const double *Pg, double *gw, bool ha
   const LaneRole r = lane_role(N);
   const int w = r.w, lc = r.lc, lq = r.lq;
   d4_t acc[NT], pp[NT];
+#ifdef F16_EXP_STAMPM
+  unsigned long long tF[5];
+#define FSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); tF[i] = __builtin_amdgcn_s_memtime(); }
+#else
+#define FSTAMP(i)
+#endif
+  FSTAMP(0)
   if (w < NTT) load_packed_tiles<NTT>(pp, Pg, n, w, lc, lq);       // P goes out first: its round trip hides under the Gram product
   double *const gwl = gw ? gw + (size_t)(w * NT * 4) * 64 + r.l : nullptr;
   if (gwl && have_gram) {
@@ -669,6 +678,7 @@ __device__ __noinline__ bool kkt_factorise(const double *Pg, double *gw, bool ha
         for (int qq = 0; qq < 4; ++qq) gwl[(J * 4 + qq) * 64] = acc[J][qq];
     }
   }
+  FSTAMP(1)
   double rho = *rho_io;
   if (!(rho > 0.0)) {   // the builder's opt-in start value (no equilibration): balance the two terms of P + rho A'A
     double tr[2] = {r.xown ? Pg[tri(r.xe, r.xe)] : 0.0, 0.0};
@@ -698,7 +708,9 @@ __device__ __noinline__ bool kkt_factorise(const double *Pg, double *gw, bool ha
 #pragma unroll
     for (int J = 0; J < NTT; ++J) acc[J] = d4_t{0.0, 0.0, 0.0, 0.0};
   }
+  FSTAMP(2)
   const bool ok = mfma_inverse<NTT>(acc, s_Cs, acc);
+  FSTAMP(3)
   // re-layout (acc = MINUS the inverse, tile layout)
   double mr[3][6];
 #pragma unroll
@@ -728,6 +740,10 @@ __device__ __noinline__ bool kkt_factorise(const double *Pg, double *gw, bool ha
 #pragma unroll
     for (int cc = 0; cc < 6; ++cc) mrow[c * 6 + cc] = mr[c][cc];
   __syncthreads();                                          // Mst is read: its memory returns to the iteration vectors
+  FSTAMP(4)
+#ifdef F16_EXP_STAMPM
+  if (blockIdx.x == 0 && threadIdx.x == 0) for (int i = 0; i < 4; ++i) g_f_stamp[i] = (double)(tF[i + 1] - tF[i]);
+#endif
   return ok;
 }
 
@@ -784,6 +800,13 @@ __device__ __noinline__ int admm_iterate(SolveState *st, const double *mrow_in, 
   __syncthreads();
   if (kind) { const double w0 = Wl * (rho_o * z - y); wdst[0] = w0; wdst[dup] = w0; }
   __syncthreads();
+#ifdef F16_EXP_STAMPM
+  unsigned long long tS[6] = {0, 0, 0, 0, 0, 0}, t0 = __builtin_amdgcn_s_memtime();
+  const int it_in = it;
+#define MSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); unsigned long long t1 = __builtin_amdgcn_s_memtime(); tS[i] += t1 - t0; t0 = t1; }
+#else
+#define MSTAMP(i)
+#endif
   while (!done && !refactor) {
     ++it;
     // ---- A: rhs = sigma D^-2 x - c q + A' W (rho z - y)
@@ -796,7 +819,9 @@ __device__ __noinline__ int admm_iterate(SolveState *st, const double *mrow_in, 
       const double t = reduce3(o1[0], o1[1], o1[2], h, g);
       if (xown) s_rhs[xe] = sgl * xs - qcl + (t + wce + (wre - wrn));
     }
+    MSTAMP(0)
     __syncthreads();
+    MSTAMP(1)
     // ---- B: x~ = K^-1 rhs, three rows x six columns per lane; reduce3 leaves x~[3 blk + c] in lane 4c of the row
     double xt_own;
     {
@@ -811,7 +836,9 @@ __device__ __noinline__ int admm_iterate(SolveState *st, const double *mrow_in, 
       xt_own = reduce3(p3[0], p3[1], p3[2], h, g);
       if (xown) xtP[XOFF + xe] = xt_own;
     }
+    MSTAMP(2)
     __syncthreads();
+    MSTAMP(3)
     // ---- C: z~ = A x~, relaxation, projection, dual update (unscaled z, y = yb / E)
     {
       double xv[6], o3[6];
@@ -903,8 +930,16 @@ __device__ __noinline__ int admm_iterate(SolveState *st, const double *mrow_in, 
     }
     // w = W (rho z - y) for the next iteration (after a rho update the next call rewrites it with the new rho)
     if (kind) { const double wn = Wl * (rho_o * z - y); wdst[0] = wn; wdst[dup] = wn; }
+    MSTAMP(4)
     __syncthreads();
+    MSTAMP(5)
   }
+#ifdef F16_EXP_STAMPM
+  if (blockIdx.x == 0 && (lane & 63) == 0) {
+    for (int i = 0; i < 6; ++i) g_it_stamp[6 * (lane >> 6) + i] += (double)tS[i];
+    if (lane == 0) g_f_stamp[5] += (double)(it - it_in);
+  }
+#endif
   st->xs = xs; st->z = z; st->y = y; st->dy = dy; st->rho = rho; st->rp = rp; st->rd = rd;
   st->it = it; st->to_check = to_check;
   st->done = done; st->converged = converged; st->infeasible = infeasible;
@@ -962,11 +997,18 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
   if (kind == 2) s_Ecv[k3] = 1.0;
   if (kind == 3) s_Erv[k3] = 1.0;
   __syncthreads();                                            // zeros, G, D = E = 1 are in place
+#ifdef F16_EXP_STAMPM
+  if (blockIdx.x == 0) { if (tid < 48) g_it_stamp[tid] = 0.0; if (tid < 6) g_f_stamp[tid] = 0.0; }
+  const unsigned long long tE0 = __builtin_amdgcn_s_memtime();
+#endif
   if (a.mode == 0 && a.s.scaling > 0) {
     double o3[3];
     ruiz_equilibrate<NTT>(Pg, N, a.s.scaling, qe, o3);
     De = o3[0]; Eo = o3[1]; cs = o3[2];
   }
+#ifdef F16_EXP_STAMPM
+  if (blockIdx.x == 0 && tid == 0) g_f_stamp[4] = (double)(__builtin_amdgcn_s_memtime() - tE0);
+#endif
   if (kind == 0) Eo = 1.0;                                     // (lanes that stood in for an unbounded row)
   // ---- bounds of this lane's constraint row (utils.py:129-152; rows with two infinite bounds are not kept)
   double lo = 0.0, hi = 0.0;
@@ -1049,6 +1091,14 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
     if (a.status && infeasible) a.status[b] |= F16_ST_QP_INFEASIBLE;
     else if (a.status && a.s.max_iter > 0 && (!converged || !ok)) a.status[b] |= F16_ST_QP_MAXITER;
   }
+#ifdef F16_EXP_STAMPM
+  __syncthreads();      // diagnostic build: the u_seq column of the aircraft solved by workgroup 0 is replaced by the stamps
+  if (blockIdx.x == 0 && a.useq) {
+    if (tid < 48) a.useq[tid * a.ld + b] = g_it_stamp[tid] / fmax(g_f_stamp[5], 1.0);
+    if (tid < 6) a.useq[(66 + tid) * a.ld + b] = g_f_stamp[tid];
+    if (tid < 16) a.useq[(50 + tid) * a.ld + b] = g_inv_stamp[tid];
+  }
+#endif
 }
 #undef wsP
 #undef ysP

@@ -19,7 +19,7 @@ def t(fn, n=3):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-print("linearise ms", t(lambda: env.linearise()))
+print("linearise ms", t(lambda: env._linearise_na()))
 print("c2d ms", t(lambda: env.discretise()))
 print("lqr gain chain ms", t(lambda: env._calc_LQR_gain()))
 env.build_ssr()
