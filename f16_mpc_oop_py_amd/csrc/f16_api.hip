@@ -43,10 +43,14 @@ extern "C" int f16_create(f16_ctx **out, int device) {
   if ((rc = hip_check(hipSetDevice(device), "hipSetDevice"))) return rc;
   std::vector<double> img(TABLE_IMAGE_DOUBLES), lofi(LOFI_IMAGE_DOUBLES);
   if (build_table_images(img.data(), lofi.data())) return set_error(F16_EINVAL, "table data violates a layout assumption");
+  std::vector<int32_t> img32(i32::IMAGE_INTS);
+  build_table_image_i32(img32.data());
   f16_ctx *c = new f16_ctx();
   c->device = device;
   if ((rc = hip_check(hipMalloc(&c->d_tab, sizeof(double) * TABLE_IMAGE_DOUBLES), "hipMalloc tables")) ||
       (rc = hip_check(hipMalloc(&c->d_lofi, sizeof(double) * LOFI_IMAGE_DOUBLES), "hipMalloc lofi")) ||
+      (rc = hip_check(hipMalloc(&c->d_tab32, sizeof(int32_t) * i32::IMAGE_INTS), "hipMalloc tables (int)")) ||
+      (rc = hip_check(hipMemcpy(c->d_tab32, img32.data(), sizeof(int32_t) * i32::IMAGE_INTS, hipMemcpyHostToDevice), "upload tables (int)")) ||
       (rc = hip_check(hipMalloc(&c->d_one, sizeof(double) * 36), "hipMalloc scratch")) ||
       (rc = hip_check(hipHostMalloc(&c->h_one, sizeof(double) * 36), "hipHostMalloc scratch")) ||
       (rc = hip_check(hipMemcpy(c->d_tab, img.data(), sizeof(double) * TABLE_IMAGE_DOUBLES, hipMemcpyHostToDevice), "upload tables")) ||
@@ -72,6 +76,7 @@ extern "C" void f16_destroy(f16_ctx *c) {
   if (!c) return;
   if (c->d_tab) (void)hipFree(c->d_tab);
   if (c->d_lofi) (void)hipFree(c->d_lofi);
+  if (c->d_tab32) (void)hipFree(c->d_tab32);
   if (c->d_one) (void)hipFree(c->d_one);
   (void)hipDeviceSynchronize();       // in-flight calls may still own pool blocks / schedule buffers
   for (int i = 0; i < c->n_sched; ++i) if (c->sched[i].buf) (void)hipFree(c->sched[i].buf);
@@ -83,6 +88,12 @@ extern "C" void f16_destroy(f16_ctx *c) {
 extern "C" int f16_debug_read_tables(f16_ctx *ctx, double *h_out) {
   if (!ctx || !h_out) return set_error(F16_EINVAL, "NULL argument");
   return hip_check(hipMemcpy(h_out, ctx->d_tab, sizeof(double) * TABLE_IMAGE_DOUBLES, hipMemcpyDeviceToHost), "read tables");
+}
+
+extern "C" size_t f16_table_image_i32_ints(void) { return (size_t)i32::IMAGE_INTS; }
+extern "C" int f16_debug_read_tables_i32(f16_ctx *ctx, int32_t *h_out) {
+  if (!ctx || !h_out) return set_error(F16_EINVAL, "bad argument to f16_debug_read_tables_i32");
+  return hip_check(hipMemcpy(h_out, ctx->d_tab32, sizeof(int32_t) * i32::IMAGE_INTS, hipMemcpyDeviceToHost), "read tables (int)");
 }
 
 // ------------------------------------------------------------------ drop-in symbols

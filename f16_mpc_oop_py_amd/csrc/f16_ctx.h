@@ -7,6 +7,7 @@ struct f16_ctx {
   int device;
   double *d_tab;    // [TABLE_IMAGE_DOUBLES] hifi node-major image
   double *d_lofi;   // [LOFI_IMAGE_DOUBLES]
+  int *d_tab32;     // [i32::IMAGE_INTS] hifi image as scaled integers (large-batch rollout)
   // single-aircraft scratch for the drop-in Nlplant symbol
   double *d_one;    // [18 + 18]
   double *h_one;    // pinned mirror

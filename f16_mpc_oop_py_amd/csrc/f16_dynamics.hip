@@ -23,6 +23,7 @@ namespace f16 {
 
 struct DynArgs {
   const double *tab;    // hifi image, global
+  const int *tab32;     // hifi image as scaled integers (f16_tables.h, namespace i32), global
   const double *lofi;   // lofi image, global
   const double *x;      // [18][ld] (or x_full for xdot_na)
   const double *u;      // [4][ld]  (x9 for xdot_na)
@@ -82,13 +83,10 @@ __global__ __launch_bounds__(BLOCK) void k_nlplant(DynArgs a) {
   }
 }
 
-template <int BLOCK, int FI>
-__global__ __launch_bounds__(BLOCK) void k_rollout(DynArgs a) {
-  __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
-  // the four inputs of a lane are constant over the rollout and used once per step: kept in lane-indexed (conflict-free) LDS
-  // slots rather than in eight registers that the 512-lane instantiation (256 registers per lane) spilled and reloaded per step
-  __shared__ double us[4][BLOCK];
-  if (a.fi == 1) stage_tables(tab, a.tab);
+// One lane = one aircraft, the whole rollout in registers.  TP = the table image the lookups read (plant header: fp64
+// values or scaled integers).
+template <int BLOCK, int FI, typename TP>
+__device__ __forceinline__ void rollout_lanes(const DynArgs &a, TP T, double (*us)[BLOCK]) {
   for (long b = (long)blockIdx.x * BLOCK + threadIdx.x; b < a.B; b += (long)gridDim.x * BLOCK) {
     double x[18];
 #pragma unroll
@@ -105,7 +103,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DynArgs a) {
         double xd[18], u[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) u[k] = us[k][threadIdx.x];
-        calc_xdot<FI>((const double *)tab, a.lofi, x, u, xd, a.xcg, a.fi, a.flags, st);
+        calc_xdot<FI>(T, a.lofi, x, u, xd, a.xcg, a.fi, a.flags, st);
 #pragma unroll
         for (int k = 0; k < 18; ++k) x[k] += xd[k] * a.dt;   // env.py:126
       }
@@ -126,6 +124,31 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DynArgs a) {
   }
 }
 
+template <int BLOCK, int FI>
+__global__ __launch_bounds__(BLOCK) void k_rollout(DynArgs a) {
+  __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
+  // the four inputs of a lane are constant over the rollout and used once per step: kept in lane-indexed (conflict-free) LDS
+  // slots rather than in eight registers that the 512-lane instantiation (256 registers per lane) spilled and reloaded per step
+  __shared__ double us[4][BLOCK];
+  if (a.fi == 1) stage_tables(tab, a.tab);
+  rollout_lanes<BLOCK, FI>(a, (const double *)tab, us);
+}
+
+// The same rollout on the scaled-integer table image (hifi, default numerics; large batches: the LDS pipe -- 1.5 KB of
+// table vertices per aircraft-step as doubles, more than half of its cycles bank-conflict replays of the per-lane gathers --
+// is one of the two ceilings of k_rollout there).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_rollout_i(DynArgs a) {
+  __shared__ __attribute__((aligned(16))) int tab[i32::IMAGE_INTS];
+  __shared__ double us[4][BLOCK];
+  {
+    const int4 *src = reinterpret_cast<const int4 *>(a.tab32);
+    int4 *dst = reinterpret_cast<int4 *>(tab);
+    for (int i = threadIdx.x; i < i32::IMAGE_INTS / 4; i += BLOCK) dst[i] = src[i];
+    __syncthreads();
+  }
+  rollout_lanes<BLOCK, 1>(a, TabI32{tab}, us);
+}
 
 // Four-wavefront rollout (latency regime, hifi): one workgroup = 64 aircraft on the four SIMDs of a CU; the state is
 // split by owner (every wave integrates and range-checks what it owns) and the table lookups -- the LDS-latency-bound
@@ -655,6 +678,15 @@ extern "C" int f16_rollout(f16_ctx *ctx, double *x, const double *u, double *tra
     return hip_check(hipGetLastError(), "f16_rollout launch");
   }
   Geometry g = geometry(B, fi_flag);
+#ifdef F16_FAST_DIV
+  // throughput regime, default numerics: lookups on the scaled-integer image
+  static const int use_i32 = [] { const char *e = getenv("F16_ROLLOUT_I32"); return e ? atoi(e) : 1; }();
+  if (fi_flag == 1 && use_i32 && g.block == 512) {
+    a.tab32 = ctx->d_tab32;
+    hipLaunchKernelGGL(k_rollout_i<512>, dim3(g.grid), dim3(512), 0, (hipStream_t)stream, a);
+    return hip_check(hipGetLastError(), "f16_rollout launch");
+  }
+#endif
   LAUNCH_BY_BLOCK_FI(k_rollout, g, (hipStream_t)stream, a);
   return hip_check(hipGetLastError(), "f16_rollout launch");
 }

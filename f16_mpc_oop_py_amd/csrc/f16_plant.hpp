@@ -198,8 +198,41 @@ F16_DEV int beta_guess(double beta) {
 // to scratch).  Same terms, same differences-first order.  Measured at B = 262,144: 14.2 -> 15.8 G steps/s with 256-lane
 // workgroups, 5.7 -> 17.1 with 512-lane ones (two waves per SIMD).
 struct TotalsOut { double Cx, Cz, Cm, Cy, Cn, Cl; };
+
+// Two table images serve the one-lane plant (f16_tables.h): fp64 values (TP = const double *) and scaled integers
+// (TP = TabI32: half the LDS bytes per vertex, one exact int -> double conversion per vertex).  Lay<TP> gives the group
+// offsets / node strides of the image and a view whose operator[] yields a double; with the integer image the lookups
+// run on k = 1e5 x value and the six totals -- linear in the table values once eta_el is scaled -- are scaled at the end.
+struct TabI32 { const int *base; };
+struct I32View {
+  const int *p;
+  F16_DEV I32View operator+(int o) const { return I32View{p + o}; }
+  F16_DEV double operator[](int i) const { return (double)p[i]; }
+};
+template <typename TP> struct Lay {
+  static constexpr int G3A = OFF_G3A, SG3A = S_G3A, G3B = OFF_G3B, SG3B = S_G3B, G2A = OFF_G2A, SG2A = S_G2A, G2B = OFF_G2B,
+                       SG2B = S_G2B, G1A = OFF_G1A, SG1A = S_G1A, G1B = OFF_G1B, SG1B = S_G1B, ETA = OFF_ETA;
+  static constexpr bool SCALED = false;
+  static F16_DEV TP tab(TP T) { return T; }
+  static F16_DEV TP bp(TP T) { return T; }
+};
+template <> struct Lay<TabI32> {
+  static constexpr int G3A = i32::OFF_G3A, SG3A = i32::S_G3A, G3B = i32::OFF_G3B, SG3B = i32::S_G3B, G2A = i32::OFF_G2A,
+                       SG2A = i32::S_G2A, G2B = i32::OFF_G2B, SG2B = i32::S_G2B, G1A = i32::OFF_G1A, SG1A = i32::S_G1A,
+                       G1B = i32::OFF_G1B, SG1B = i32::S_G1B, ETA = i32::OFF_ETA;
+  static constexpr bool SCALED = true;
+  static F16_DEV I32View tab(TabI32 T) { return I32View{T.base}; }
+  static F16_DEV const double *bp(TabI32 T) { return reinterpret_cast<const double *>(T.base); }
+};
+
 template <typename TP>
-F16_DEV void aero_totals_phased(TP T, const double *xu, double xcg, unsigned flags, TotalsOut &t, int &status) {
+F16_DEV void aero_totals_phased(TP T0, const double *xu, double xcg, unsigned flags, TotalsOut &t, int &status) {
+  using L = Lay<TP>;
+  const auto T = L::tab(T0);
+  const auto BP = L::bp(T0);
+  constexpr int S_G3A = L::SG3A, S_G3B = L::SG3B, S_G2A = L::SG2A, S_G2B = L::SG2B, S_G1A = L::SG1A, S_G1B = L::SG1B;
+  constexpr int OFF_G3A = L::G3A, OFF_G3B = L::G3B, OFF_G2A = L::G2A, OFF_G2B = L::G2B, OFF_G1A = L::G1A, OFF_G1B = L::G1B,
+                OFF_ETA = L::ETA;
   const double B = 30.0, cbar = 11.32, xcgr = 0.35, r2d = 180.0 / 3.141592653589793;
   double vt = xu[6];
   if (vt <= 0.01) vt = 0.01;
@@ -207,11 +240,11 @@ F16_DEV void aero_totals_phased(TP T, const double *xu, double xcg, unsigned fla
   const double dail = F16_DIVC(xu[14], 21.5), drud = F16_DIVC(xu[15], 30.0), dlef = 1 - F16_DIVC(xu[16], 25.0);
   const double r2vt = f16_rcp(2 * vt), kq = cbar * r2vt, kb = B * r2vt;
   // (1) breakpoints
-  const BrRaw ra = br_load(T + OFF_BP_A1, N_A1, alpha_guess(alpha));
-  const BrRaw rb = br_load(T + OFF_BP_B1, N_B1, beta_guess(beta));
-  const BrRaw r1 = br_load(T + OFF_BP_D1, N_D1, (el >= -10.0) + (el >= 0.0) + (el >= 10.0));
-  const BrRaw r2 = br_load(T + OFF_BP_D2, N_D2, (int)(el >= 0.0));
-  const double a45 = T[OFF_BP_A1 + N_A2 - 1];
+  const BrRaw ra = br_load(BP + OFF_BP_A1, N_A1, alpha_guess(alpha));
+  const BrRaw rb = br_load(BP + OFF_BP_B1, N_B1, beta_guess(beta));
+  const BrRaw r1 = br_load(BP + OFF_BP_D1, N_D1, (el >= -10.0) + (el >= 0.0) + (el >= 10.0));
+  const BrRaw r2 = br_load(BP + OFF_BP_D2, N_D2, (int)(el >= 0.0));
+  const double a45 = BP[OFF_BP_A1 + N_A2 - 1];
   F16_PHASE();
   bool offa, offb, off1, off2;
   const BrCell ca = br_cell(ra, N_A1, alpha, offa), cb = br_cell(rb, N_B1, beta, offb);
@@ -228,11 +261,11 @@ F16_DEV void aero_totals_phased(TP T, const double *xu, double xcg, unsigned fla
   if (hi_a) { a2.j = N_A2 - 2; a2.l = 1.0; a2.m = 0.0; }
   // (each weight set is formed inside the phase that uses it -- W1 twice, W2 in phase 4 only -- to keep live ranges short:
   //  the 512-lane workgroup has 256 registers per lane)
-  TP g = T + OFF_G1A + ca.j * S_G1A, h = T + OFF_G1B + j2 * S_G1B;
+  const auto g = T + OFF_G1A + ca.j * S_G1A, h = T + OFF_G1B + j2 * S_G1B;
   // (2) longitudinal: G3A (3-D + el = 0 plane), G2B lef, pitch damping, eta_el
   {
     constexpr int SA = S_G3A, SB = S_G3A * N_A1, SD = S_G3A * N_A1 * N_B1;
-    TP p = T + OFF_G3A + n1 * SA;
+    const auto p = T + OFF_G3A + n1 * SA;
     Q4 qlo[3], qhi[3], q0[3], ql[3];
     double g0[3], g1[3], h0[3], h1[3];
 #pragma unroll
@@ -256,21 +289,21 @@ F16_DEV void aero_totals_phased(TP T, const double *xu, double xcg, unsigned fla
     // same order of additions as C/nlplant.c:333-347
     t.Cx = Cf[0] + dC[0] * dlef + dQ[0] * Q;
     t.Cz = Cf[1] + dC[1] * dlef + dQ[1] * Q;
-    t.Cm = Cf[2] * lerp(e0, e1, d1) + t.Cz * (xcgr - xcg) + dC[2] * dlef + dQ[2] * Q + lerp(m0, m1, a1);
+    t.Cm = Cf[2] * (L::SCALED ? i32::SCALE * lerp(e0, e1, d1) : lerp(e0, e1, d1)) + t.Cz * (xcgr - xcg) + dC[2] * dlef + dQ[2] * Q + lerp(m0, m1, a1);
   }
   F16_PHASE();
   // (3) lateral, first half: G3B (3-D + plane), G2A
   double base[3], base0[3], dr30[3], da20[3];
   {
     constexpr int SA3 = S_G3B, SB3 = S_G3B * N_A1, SD3 = S_G3B * N_A1 * N_B1;
-    TP p3 = T + OFF_G3B + n1 * SA3;
+    const auto p3 = T + OFF_G3B + n1 * SA3;
     Q4 qlo[2], qhi[2], q0[2], qa[7];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       qlo[k] = ld4(p3 + k + c2.j * SD3, SA3, SB3); qhi[k] = ld4(p3 + k + (c2.j + 1) * SD3, SA3, SB3);
       q0[k] = ld4(p3 + k + D2_ZERO_NODE * SD3, SA3, SB3);
     }
-    TP pa = T + OFF_G2A + n1 * S_G2A;
+    const auto pa = T + OFF_G2A + n1 * S_G2A;
 #pragma unroll
     for (int k = 0; k < 7; ++k) qa[k] = ld4(pa + k, S_G2A, S_G2A * N_A1);
     F16_PHASE();
@@ -291,7 +324,7 @@ F16_DEV void aero_totals_phased(TP T, const double *xu, double xcg, unsigned fla
   F16_PHASE();
   // (4) lateral, second half: G2B lef tables, yaw / roll damping, sideslip corrections
   {
-    TP pb = T + OFF_G2B + n2 * S_G2B;
+    const auto pb = T + OFF_G2B + n2 * S_G2B;
     Q4 ql[3], qal[3];
     double r0[3], r1v[3], p0[3], p1[3], hr0[3], hr1[3], hp0[3], hp1[3];
 #pragma unroll
@@ -322,6 +355,7 @@ F16_DEV void aero_totals_phased(TP T, const double *xu, double xcg, unsigned fla
            lerp(nb0, nb1, a1) * beta;
     t.Cl = base[2] + dl[2] * dlef + dA[2] * dail + dr30[2] * drud + dR[2] * R + dP[2] * P + lerp(lb0, lb1, a1) * beta;
   }
+  if (L::SCALED) { t.Cx *= i32::SCALE; t.Cz *= i32::SCALE; t.Cm *= i32::SCALE; t.Cy *= i32::SCALE; t.Cn *= i32::SCALE; t.Cl *= i32::SCALE; }
 }
 
 // The same totals as sums of four partial triples, so that four wavefronts can each look up one table family

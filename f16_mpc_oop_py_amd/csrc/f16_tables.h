@@ -46,6 +46,26 @@ constexpr int TABLE_IMAGE_DOUBLES = OFF_ETA + 8;                // 14116 (16-byt
 static_assert(TABLE_IMAGE_DOUBLES % 2 == 0, "image is copied with 16-byte loads");
 static_assert(TABLE_IMAGE_DOUBLES * 8 <= 160 * 1024, "must fit one CU's LDS");
 
+// The same groups as SCALED INTEGERS (int32, value = k / 1e5 exactly -- the reference's data files carry five decimals),
+// for the large-batch rollout kernels: half the LDS bytes per vertex gather (the LDS pipe is one of their two ceilings),
+// node payloads padded to whole 16-byte reads.  The breakpoints stay doubles at the front of the image (same OFF_BP_*
+// offsets, in doubles); table offsets / strides below are in ints.  Interpolating k instead of k / 1e5 and scaling the
+// six totals once is linear algebra on the same numbers, <= a few ulp from the fp64-image path (default build only).
+namespace i32 {
+constexpr int BP_DOUBLES = 48;
+constexpr int OFF_G3A = 2 * BP_DOUBLES, S_G3A = 4;
+constexpr int OFF_G3B = OFF_G3A + S_G3A * N_A1 * N_B1 * N_D1, S_G3B = 2;
+constexpr int OFF_G2A = OFF_G3B + S_G3B * N_A1 * N_B1 * N_D2, S_G2A = 8;
+constexpr int OFF_G2B = OFF_G2A + S_G2A * N_A1 * N_B1, S_G2B = 12;
+constexpr int OFF_G1A = OFF_G2B + S_G2B * N_A2 * N_B1, S_G1A = 12;
+constexpr int OFF_G1B = OFF_G1A + S_G1A * N_A1, S_G1B = 12;
+constexpr int OFF_ETA = OFF_G1B + S_G1B * N_A2;
+constexpr int IMAGE_INTS = OFF_ETA + 8;                          // 16,624 ints = 66,496 B
+constexpr double SCALE = 1e-5;
+static_assert(OFF_G3B % 4 == 0 && OFF_G2A % 4 == 0 && OFF_G2B % 4 == 0 && OFF_G1A % 4 == 0 && OFF_G1B % 4 == 0 &&
+              OFF_ETA % 4 == 0 && IMAGE_INTS % 4 == 0, "node payloads are read with 16-byte loads");
+}  // namespace i32
+
 // el = 0 is node 2 of DH1 and node 1 of DH2 (checked at image build time): the reference's
 // `_Cx(alpha,beta,0)`-style calls (hifi_F16_AeroData.c:1892-1925) are plain 2-D lookups on that plane.
 constexpr int D1_ZERO_NODE = 2, D2_ZERO_NODE = 1;
@@ -58,5 +78,7 @@ constexpr int LOFI_IMAGE_DOUBLES = 744;
 // Builds both images on the host (IEEE division int/scale == the reference's strtod, see
 // tools/pack_tables.py).  Returns 0, or -1 when a structural assumption on the data fails.
 int build_table_images(double *hifi /*[TABLE_IMAGE_DOUBLES]*/, double *lofi /*[LOFI_IMAGE_DOUBLES]*/);
+// The scaled-integer image (call after build_table_images succeeded: same structural assumptions).
+void build_table_image_i32(int32_t *img /*[i32::IMAGE_INTS]*/);
 
 }  // namespace f16

@@ -150,6 +150,8 @@ def load():
     L.f16_last_error.restype = ctypes.c_char_p
     L.f16_table_image_doubles.restype = ctypes.c_size_t
     L.f16_debug_read_tables.argtypes = [vp, vp]
+    L.f16_table_image_i32_ints.restype = ctypes.c_size_t
+    L.f16_debug_read_tables_i32.argtypes = [vp, vp]
     L.Nlplant.argtypes = [vp, vp, i]
     L.Nlplant.restype = None
     L.atmos.argtypes = [d, d, vp]

@@ -61,6 +61,10 @@ const char *f16_last_error(void);
 size_t f16_table_image_doubles(void);
 /* copy the device table image back to host (tests): n = f16_table_image_doubles() */
 int f16_debug_read_tables(f16_ctx *ctx, double *h_out);
+/* the same tables as the scaled-integer image the large-batch rollout reads (value = k / 1e5; breakpoints as doubles in
+ * front, csrc/f16_tables.h namespace i32): n_ints = f16_table_image_i32_ints() */
+size_t f16_table_image_i32_ints(void);
+int f16_debug_read_tables_i32(f16_ctx *ctx, int32_t *h_out);
 
 /* Tests: ONE of the reference's 43 hifi table functions (C/hifi_F16_AeroData.c:109-1861: `_Cx(alpha,beta,el)`,
  * `_CXq(alpha)`, ... each a lazy file read + interpn(), C/mexndinterp.c:97-265) evaluated on the device by the bracket /

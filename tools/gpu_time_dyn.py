@@ -36,6 +36,9 @@ for fi in (1, 0):
     env = F16Batch(x0, u0, fi_flag=fi)
     ms = timeit(env, traj)
     print(f"B={B} T={T} fi={fi} traj=yes  {ms:.3f} ms  {B*T/ms/1e3:.1f} M steps/s  ({ms/T*1e3:.2f} us/step)")
+    if traj is not None:
+        w = torch.arange(1, 19, dtype=torch.float64, device="cuda")[None, :, None]
+        print("   traj checksum %.17g  last-sample checksum %.17g" % (float((traj * w).sum()), float((traj[-1] * w[0]).sum())))
     ms = timeit(env, None)
     print(f"B={B} T={T} fi={fi} traj=no   {ms:.3f} ms  {B*T/ms/1e3:.1f} M steps/s")
 if os.environ.get("PARITY"):
