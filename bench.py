@@ -278,7 +278,7 @@ def bench_large(args, dev, rank):
     assert int(env.status.max()) == 0 and bool(torch.isfinite(traj[-1]).all())
     ms = float(np.mean(ts))
     gbs = B * T * BYTES_PER_STORED_STEP / (ms * 1e-3) / 1e9
-    res = {"bound": "hbm", "kernel": "k_rollout<512>" if B >= 131072 else "k_rollout<256>", "batch_per_gpu": B, "euler_steps": T, "kernel_ms": ms,
+    res = {"bound": "hbm", "kernel": "k_rollout_i<512>" if B >= 131072 else "k_rollout<256>", "batch_per_gpu": B, "euler_steps": T, "kernel_ms": ms,
            "steps_per_s": B * T / (ms * 1e-3), "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": B * T * BYTES_PER_STORED_STEP, "traffic": None,
            "note": "two waves per SIMD on all 256 CUs; fp64/VALU issue-bound"}

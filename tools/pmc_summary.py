@@ -63,18 +63,18 @@ rec = {"kernel": kname, "batch": batch, "euler_steps": euler,
 json.dump(rec, open(os.path.join(out, "traffic_k_rollout.json"), "w"), indent=1)
 print(json.dumps(rec, indent=1))
 
-# the large-batch leg of the same command (bench.py: roofline_large_batch): k_rollout<512, -1>, B = 262,144, 200 steps
+# the large-batch leg of the same command (bench.py: roofline_large_batch): k_rollout_i<512>, B = 262,144, 200 steps
 LB, LT = 262144, 200
-fl, ml = counter(fetch_dir, "FETCH_SIZE", "k_rolloutILi512")
+fl, ml = counter(fetch_dir, "FETCH_SIZE", "k_rollout_i")
 if not fl:
     fl, ml = counter(fetch_dir, "FETCH_SIZE", "k_rollout<512")
-wl, _ = counter(write_dir, "WRITE_SIZE", "k_rolloutILi512")
+wl, _ = counter(write_dir, "WRITE_SIZE", "k_rollout_i")
 if not wl:
     wl, _ = counter(write_dir, "WRITE_SIZE", "k_rollout<512")
 if fl and wl:
     fk, wk = sum(fl) / len(fl), sum(wl) / len(wl)
-    kl = [r for r in rows if "k_rollout<512" in r["Name"] or "k_rolloutILi512" in r["Name"]]
-    rec = {"kernel": "f16::k_rollout<512, -1>", "batch": LB, "euler_steps": LT, "launches": len(fl),
+    kl = [r for r in rows if "k_rollout_i" in r["Name"] or "k_rollout<512" in r["Name"] or "k_rolloutILi512" in r["Name"]]
+    rec = {"kernel": "f16::k_rollout_i<512>", "batch": LB, "euler_steps": LT, "launches": len(fl),
            "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "fetch_correction": 2.0,
            "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024), "algorithmic_bytes_per_launch": LB * LT * 144,
            "ratio_to_algorithmic": (2.0 * fk + wk) * 1024 / (LB * LT * 144),
@@ -83,7 +83,7 @@ if fl and wl:
            "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py ({tag})"}
     with open(os.path.join(out, f"{tag}_pmc_k_rollout.csv"), "a") as f:
         for nm, v in (("FETCH_SIZE", fl), ("WRITE_SIZE", wl)):
-            f.write(f"f16::k_rollout<512; -1>,{nm},{len(v)},{sum(v)/len(v):.3f},{min(v):.3f},{max(v):.3f},{ml['VGPR_Count']},"
+            f.write(f"f16::k_rollout_i<512>,{nm},{len(v)},{sum(v)/len(v):.3f},{min(v):.3f},{max(v):.3f},{ml['VGPR_Count']},"
                     f"{ml['LDS_Block_Size']},{ml['Workgroup_Size']}\n")
     json.dump(rec, open(os.path.join(out, "traffic_k_rollout_large.json"), "w"), indent=1)
     print(json.dumps(rec, indent=1))
