@@ -142,76 +142,86 @@ __device__ __forceinline__ void publish_dinv(double *pan, int k0, int l) {
 
 // One block step of the sweep: pivots 16 Kt + 4 KQ .. +3 (accumulator register KQ of tile row Kt).  cb: this step's
 // panel (pivot rows, D^-1); cbn: where the NEXT step's panel is published.
+#define F16_LDS_PHASE() __builtin_amdgcn_sched_barrier(0x7)   /* LDS / memory ops stay put, ALU may float */
+
+// Which tiles of the NTT x NTT tile matrix a wavefront holds (wave-uniform): tile row tr, tile columns [j0, j1).  Up to
+// four tile rows: wave w owns row w.  Six tile rows (N = 22..32) on eight waves / four SIMDs: waves 0-3 own rows 0-3,
+// rows 4 and 5 are split in halves over waves 4-7, so that every SIMD carries one and a half tile rows (with six
+// whole-row waves, SIMDs 0 and 1 carried two rows each, SIMDs 2 and 3 one, and waves 6, 7 idled through every
+// factorisation).
+struct TileOwn { int tr, j0, j1; };
+template <int NTT>
+__device__ __forceinline__ TileOwn tile_own() {
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  TileOwn o;
+#ifdef F16_MPC_SPLIT_ROWS
+  if (NTT == 6 && w >= 4) { o.tr = 4 + ((w - 4) >> 1); o.j0 = 3 * ((w - 4) & 1); o.j1 = o.j0 + 3; }
+  else
+#endif
+  { o.tr = w; o.j0 = 0; o.j1 = w < NTT ? NTT : 0; }
+  return o;
+}
+#define F16_OWNS(J) ((J) >= own.j0 && (J) < own.j1)
+
 template <int NTT, int KQ>
-__device__ __forceinline__ void inverse_step(d4_t (&acc)[NT], const double *cb, double *cbn, int Kt, int w, int lc, int lq,
-                                             bool &ok) {
+__device__ __forceinline__ void inverse_step(d4_t (&acc)[NT], const double *cb, double *cbn, int Kt, const TileOwn own, int lc,
+                                             int lq, double ndel, bool &ok) {
+  const int w = own.tr;                                  // tile row of this wave
   const bool pl = (lc >> 2) == KQ;                       // this lane's column (within a tile) is a pivot column
-  // rows of D^-1 (symmetric: row = column): row l/16 for the A operand and the pivot rows, row l%4 for the pivot columns
-  double dA[4], dC[4];
+  const bool owner = w == Kt;                            // this wave holds (its columns of) the pivot rows (wave-uniform)
+  // ---- every LDS read of the step first, and as few as possible: the panel reads of all waves go through the one LDS
+  // pipe of the CU right after the barrier (64 lanes x 16 B = 8 clocks per instruction whatever the addresses), and with
+  // the lane-level fix-ups of the first versions (28-40 wide reads per lane) that was ~1 k clocks of a ~3 k-clock step.
+  double2 a0, a1, ca0, ca1;
+  double b_op[NTT], okf, dpiv;
   {
-    const double2 *ra = reinterpret_cast<const double2 *>(cb + PAN_DI + 4 * lq);
-    const double2 *rc = reinterpret_cast<const double2 *>(cb + PAN_DI + 4 * (lc & 3));
-    const double2 a0 = ra[0], a1 = ra[1], c0 = rc[0], c1 = rc[1];
-    dA[0] = a0.x; dA[1] = a0.y; dA[2] = a1.x; dA[3] = a1.y;
-    dC[0] = c0.x; dC[1] = c0.y; dC[2] = c1.x; dC[3] = c1.y;
-  }
-  ok = ok && cb[PAN_OK] > 0.5;
-  double2 ca0, ca1;
-  {
+    const double2 *ra = reinterpret_cast<const double2 *>(cb + PAN_DI + 4 * lq);       // row l/16 of D^-1 (= its column)
+    a0 = ra[0]; a1 = ra[1];
+    okf = cb[PAN_OK];
+    dpiv = cb[PAN_DI + 4 * lq + (lc & 3)];
     const double2 *src = reinterpret_cast<const double2 *>(cb + (16 * w + lc) * 4);
     ca0 = src[0]; ca1 = src[1];
+#pragma unroll
+    for (int J = 0; J < NTT; ++J) b_op[J] = F16_OWNS(J) ? cb[(16 * J + lc) * 4 + lq] : 0.0;
   }
-  double b_op[NTT];
+  F16_LDS_PHASE();
+  ok = ok && okf > 0.5;
+  // ---- ONE matrix-core product per tile does the whole block step.  With X = C D^-1 (C = the pivot columns = the panel):
+  //   A operand  -X[i][k] on ordinary rows, +D^-1[r][k] on the four pivot rows (owner wave)
+  //   B operand  C[j][k] on ordinary columns, -delta(k, kk) on the four pivot columns
+  //   accumulator zeroed beforehand on pivot rows and pivot columns
+  // gives  M[i][j] -= X[i] . C[j]  |  M[i][kk] = X[i][kk]  |  M[r][j] = (D^-1 C')[r][j] = X[j][r]  |  M[r][kk] = -D^-1[r][kk]
+  // -- the rank-4 update, the new pivot columns, the new pivot rows and the pivot block, with no lane-level fix-up reads.
+  double a_op = -(ca0.x * a0.x + ca0.y * a0.y + ca1.x * a1.x + ca1.y * a1.y);
+  if (owner && pl) a_op = dpiv;
 #pragma unroll
-  for (int J = 0; J < NTT; ++J) {
-    b_op[J] = cb[(16 * J + lc) * 4 + lq];
-    if (J == Kt && pl) b_op[J] = 0.0;
-  }
-  // ---- A operand: -(C D^-1)[16w + lc][lq], zero on pivot rows
-  double a_op = -(ca0.x * dA[0] + ca0.y * dA[1] + ca1.x * dA[2] + ca1.y * dA[3]);
-  if (w == Kt && pl) a_op = 0.0;
+  for (int J = 0; J < NTT; ++J)
+    if (J == Kt && F16_OWNS(J)) {
+      b_op[J] = pl ? ndel : b_op[J];
 #pragma unroll
-  for (int J = 0; J < NTT; ++J) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op[J], acc[J], 0, 0, 0);
-  // ---- pivot columns of this tile row: M[i][pivot kk] = (C D^-1)[i][kk] for rows outside the pivot block
-  {
-    double cd[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const double2 *src = reinterpret_cast<const double2 *>(cb + (16 * w + 4 * q + lq) * 4);
-      const double2 u = src[0], v = src[1];
-      cd[q] = u.x * dC[0] + u.y * dC[1] + v.x * dC[2] + v.y * dC[3];
+      for (int q = 0; q < 4; ++q) acc[J][q] = pl ? 0.0 : acc[J][q];
     }
+  if (owner) {
 #pragma unroll
-    for (int J = 0; J < NTT; ++J)
-      if (J == Kt) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (q != KQ) acc[J][q] = pl ? cd[q] : acc[J][q];
-        if (w != Kt) acc[J][KQ] = pl ? cd[KQ] : acc[J][KQ];
-      }
+    for (int J = 0; J < NTT; ++J) acc[J][KQ] = 0.0;
   }
-  // ---- pivot rows (owner wave, register KQ): M[pivot lq][j] = (C D^-1)[j][lq], -D^-1 on the pivot block itself
-  if (w == Kt) {
-    const double mdi = -cb[PAN_DI + 4 * lq + (lc & 3)];
 #pragma unroll
-    for (int J = 0; J < NTT; ++J) {
-      const double2 *src = reinterpret_cast<const double2 *>(cb + (16 * J + lc) * 4);
-      const double2 u = src[0], v = src[1];
-      const double cdv = u.x * dA[0] + u.y * dA[1] + v.x * dA[2] + v.y * dA[3];
-      acc[J][KQ] = (J == Kt && pl) ? mdi : cdv;
-    }
-  }
-  // ---- publish the next pivot rows and the inverse of their pivot block
+  for (int J = 0; J < NTT; ++J)
+    if (F16_OWNS(J)) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op[J], acc[J], 0, 0, 0);
+  // ---- publish the next pivot rows (every wave of that tile row its own columns) and the inverse of their pivot block
+  // (the wave that holds the diagonal tile: it reads back its own writes)
   if (KQ < 3) {
-    if (w == Kt) {
+    if (owner) {
 #pragma unroll
-      for (int J = 0; J < NTT; ++J) cbn[(16 * J + lc) * 4 + lq] = acc[J][(KQ + 1) & 3];
-      publish_dinv(cbn, 16 * Kt + 4 * (KQ + 1), 16 * lq + lc);
+      for (int J = 0; J < NTT; ++J)
+        if (F16_OWNS(J)) cbn[(16 * J + lc) * 4 + lq] = acc[J][(KQ + 1) & 3];
+      if (F16_OWNS(Kt)) publish_dinv(cbn, 16 * Kt + 4 * (KQ + 1), 16 * lq + lc);
     }
   } else if (w == Kt + 1 && Kt + 1 < NTT) {
 #pragma unroll
-    for (int J = 0; J < NTT; ++J) cbn[(16 * J + lc) * 4 + lq] = acc[J][0];
-    publish_dinv(cbn, 16 * (Kt + 1), 16 * lq + lc);
+    for (int J = 0; J < NTT; ++J)
+      if (F16_OWNS(J)) cbn[(16 * J + lc) * 4 + lq] = acc[J][0];
+    if (F16_OWNS(Kt + 1)) publish_dinv(cbn, 16 * (Kt + 1), 16 * lq + lc);
   }
 }
 
@@ -225,18 +235,20 @@ __device__ __forceinline__ void inverse_step(d4_t (&acc)[NT], const double *cb, 
 #endif
 template <int NTT>
 __device__ F16_INV_ATTR bool mfma_inverse(d4_t *acc_out, double *Cs, const d4_t *acc_in) {
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int tid = threadIdx.x, l = tid & 63;
+  const TileOwn own = tile_own<NTT>();
   int lc = l & 15, lq = l >> 4;
   // opaque to the optimiser: otherwise the tile index arithmetic below (loop-invariant for the caller's factorisation
   // loop) is hoisted to the top of the kernel, does not fit in registers there and comes back through scratch memory
   asm volatile("" : "+v"(lc), "+v"(lq));
   bool ok = true;
+  const double ndel = (lq == (lc & 3)) ? -1.0 : 0.0;     // B operand on a pivot column: -delta(k, kk)
   d4_t acc[NT];
 #pragma unroll
   for (int J = 0; J < NTT; ++J) acc[J] = acc_in[J];
   double *c0 = Cs, *c1 = Cs + PAN_SIZE;
   __syncthreads();                        // previous users of Cs are done
-  if (w == 0) {
+  if (own.tr == 0 && own.j1 > 0) {
 #pragma unroll
     for (int J = 0; J < NTT; ++J) c0[(16 * J + lc) * 4 + lq] = acc[J][0];
     publish_dinv(c0, 0, l);
@@ -247,26 +259,27 @@ __device__ F16_INV_ATTR bool mfma_inverse(d4_t *acc_out, double *Cs, const d4_t 
 #else
 #define ISTAMP(acc_)
 #endif
+#pragma unroll
   for (int Kt = 0; Kt < NTT; ++Kt) {
     __syncthreads();
     ISTAMP(tb)
-    if (w < NTT) inverse_step<NTT, 0>(acc, c0, c1, Kt, w, lc, lq, ok);
+    if (own.j1 > 0) inverse_step<NTT, 0>(acc, c0, c1, Kt, own, lc, lq, ndel, ok);
     ISTAMP(tw)
     __syncthreads();
     ISTAMP(tb)
-    if (w < NTT) inverse_step<NTT, 1>(acc, c1, c0, Kt, w, lc, lq, ok);
+    if (own.j1 > 0) inverse_step<NTT, 1>(acc, c1, c0, Kt, own, lc, lq, ndel, ok);
     ISTAMP(tw)
     __syncthreads();
     ISTAMP(tb)
-    if (w < NTT) inverse_step<NTT, 2>(acc, c0, c1, Kt, w, lc, lq, ok);
+    if (own.j1 > 0) inverse_step<NTT, 2>(acc, c0, c1, Kt, own, lc, lq, ndel, ok);
     ISTAMP(tw)
     __syncthreads();
     ISTAMP(tb)
-    if (w < NTT) inverse_step<NTT, 3>(acc, c1, c0, Kt, w, lc, lq, ok);
+    if (own.j1 > 0) inverse_step<NTT, 3>(acc, c1, c0, Kt, own, lc, lq, ndel, ok);
     ISTAMP(tw)
   }
 #ifdef F16_EXP_STAMPM
-  if (blockIdx.x == 0 && l == 0) { g_inv_stamp[2 * w] = (double)tw; g_inv_stamp[2 * w + 1] = (double)tb; }
+  if (blockIdx.x == 0 && l == 0) { g_inv_stamp[2 * (tid >> 6)] = (double)tw; g_inv_stamp[2 * (tid >> 6) + 1] = (double)tb; }
 #endif
 #pragma unroll
   for (int J = 0; J < NTT; ++J) acc_out[J] = acc[J];
@@ -275,9 +288,11 @@ __device__ F16_INV_ATTR bool mfma_inverse(d4_t *acc_out, double *Cs, const d4_t 
 
 // tiles of a packed (lower triangle, row-major) symmetric matrix: element (16w + 4q + l/16, 16J + l%16), identity padding
 template <int NTT>
-__device__ __forceinline__ void load_packed_tiles(d4_t (&acc)[NT], const double *Pg, int n, int w, int lc, int lq) {
+__device__ __forceinline__ void load_packed_tiles(d4_t (&acc)[NT], const double *Pg, int n, int w, int lc, int lq, int j0 = 0,
+                                                  int j1 = NTT) {
 #pragma unroll
   for (int J = 0; J < NTT; ++J) {
+    if (J < j0 || J >= j1) continue;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = 16 * w + 4 * q + lq, j = 16 * J + lc;
@@ -293,19 +308,23 @@ __device__ __forceinline__ void load_packed_tiles(d4_t (&acc)[NT], const double 
 __global__ __launch_bounds__(FT) void k_dbg_inverse(const double *pk, double *out, int n, long B) {
   __shared__ __attribute__((aligned(16))) double cv[2 * FN * 4 + 40];
   const int np = n * (n + 1) / 2, nt = (n + 15) >> 4;
-  const int w = threadIdx.x >> 6, lc = threadIdx.x & 15, lq = (threadIdx.x & 63) >> 4;
+  const int lc = threadIdx.x & 15, lq = (threadIdx.x & 63) >> 4;
+  const TileOwn own = tile_own<NT>();
+  const int w = own.tr;
   for (long b = blockIdx.x; b < B; b += gridDim.x) {
     const double *Pg = pk + (size_t)b * np;
     double *o = out + (size_t)b * n * n;
     d4_t acc[NT], m0[NT];
-    load_packed_tiles<NT>(m0, Pg, n, w, lc, lq);
+#pragma unroll
+    for (int J = 0; J < NT; ++J) m0[J] = d4_t{0.0, 0.0, 0.0, 0.0};
+    load_packed_tiles<NT>(m0, Pg, n, w, lc, lq, own.j0, own.j1);
     const bool ok = mfma_inverse<NT>(acc, cv, m0);
 #pragma unroll
     for (int J = 0; J < NT; ++J)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = 16 * w + 4 * q + lq, j = 16 * J + lc;
-        if (w < nt && J < nt && i < n && j < n) o[i * n + j] = ok ? -acc[J][q] : NAN;
+        if (F16_OWNS(J) && w < nt && J < nt && i < n && j < n) o[i * n + j] = ok ? -acc[J][q] : NAN;
       }
     __syncthreads();
   }
@@ -593,10 +612,12 @@ __device__ __noinline__ void ruiz_equilibrate(const double *Pg, int N, int passe
 template <int NTT>
 __device__ __forceinline__ void gram_tiles(d4_t (&acc)[NT], int N) {
   const int n = 3 * N;
-  const int tid = threadIdx.x, w = tid >> 6, lc = tid & 15, lq = (tid & 63) >> 4;
+  const int tid = threadIdx.x, lc = tid & 15, lq = (tid & 63) >> 4;
+  const TileOwn own = tile_own<NTT>();
+  const int w = own.tr;
 #pragma unroll
   for (int J = 0; J < NTT; ++J) acc[J] = d4_t{0.0, 0.0, 0.0, 0.0};
-  if (w < NTT) {
+  if (own.j1 > 0) {
     int offT[NTT], jT[NTT];
 #pragma unroll
     for (int T = 0; T < NTT; ++T) {
@@ -618,7 +639,7 @@ __device__ __forceinline__ void gram_tiles(d4_t (&acc)[NT], int N) {
       const double a_op = (vi && i >= jW) ? s_Gl[base + offW] : 0.0;
 #pragma unroll
       for (int J = 0; J < NTT; ++J) {
-        if (kk >= ((6 * ((16 * J) / 3)) >> 2)) {             // (uniform)
+        if (F16_OWNS(J) && kk >= ((6 * ((16 * J) / 3)) >> 2)) {   // (uniform)
           const double b_op = (vi && i >= jT[J]) ? s_Gl[base + offT[J]] * wgt : 0.0;
           acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op, acc[J], 0, 0, 0);
         }
@@ -629,7 +650,7 @@ __device__ __forceinline__ void gram_tiles(d4_t (&acc)[NT], int N) {
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
-        if (i < n && j < n) {
+        if (F16_OWNS(J) && i < n && j < n) {
           if (i == j) acc[J][qq] += s_Wcv[i] + s_Wrv[i] + s_Wrv[i + 3];
           else if (i == j + 3) acc[J][qq] -= s_Wrv[i];
           else if (j == i + 3) acc[J][qq] -= s_Wrv[j];
@@ -651,7 +672,10 @@ __device__ __noinline__ bool kkt_factorise(const double *Pg, double *gw, bool ha
   (void)sigma_unused;
   const int n = 3 * N;
   const LaneRole r = lane_role(N);
-  const int w = r.w, lc = r.lc, lq = r.lq;
+  const int lc = r.lc, lq = r.lq;
+  const TileOwn own = tile_own<NTT>();
+  const int w = own.tr;                                  // this wave's tile row; it holds tile columns [own.j0, own.j1)
+  const bool has_tiles = own.j1 > 0;
   d4_t acc[NT], pp[NT];
 #ifdef F16_EXP_STAMPM
   unsigned long long tF[5];
@@ -660,54 +684,49 @@ __device__ __noinline__ bool kkt_factorise(const double *Pg, double *gw, bool ha
 #define FSTAMP(i)
 #endif
   FSTAMP(0)
-  if (w < NTT) load_packed_tiles<NTT>(pp, Pg, n, w, lc, lq);       // P goes out first: its round trip hides under the Gram product
-  double *const gwl = gw ? gw + (size_t)(w * NT * 4) * 64 + r.l : nullptr;
+#pragma unroll
+  for (int J = 0; J < NTT; ++J) pp[J] = d4_t{0.0, 0.0, 0.0, 0.0};
+  if (has_tiles) load_packed_tiles<NTT>(pp, Pg, n, w, lc, lq, own.j0, own.j1);   // P goes out first: its round trip hides under the Gram product
+  double *const gwl = gw ? gw + (size_t)(w * NT * 4) * 64 + r.l : nullptr;      // tile (w, J), register qq at [(w NT + J) 4 + qq][lane]
   if (gwl && have_gram) {
-    if (w < NTT) {
 #pragma unroll
-      for (int J = 0; J < NTT; ++J)
+    for (int J = 0; J < NTT; ++J)
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) acc[J][qq] = gwl[(J * 4 + qq) * 64];
-    }
+      for (int qq = 0; qq < 4; ++qq) acc[J][qq] = F16_OWNS(J) ? gwl[(J * 4 + qq) * 64] : 0.0;
   } else {
     gram_tiles<NTT>(acc, N);
-    if (gwl && w < NTT) {
+    if (gwl) {
 #pragma unroll
       for (int J = 0; J < NTT; ++J)
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) gwl[(J * 4 + qq) * 64] = acc[J][qq];
+        for (int qq = 0; qq < 4; ++qq)
+          if (F16_OWNS(J)) gwl[(J * 4 + qq) * 64] = acc[J][qq];
     }
   }
   FSTAMP(1)
   double rho = *rho_io;
   if (!(rho > 0.0)) {   // the builder's opt-in start value (no equilibration): balance the two terms of P + rho A'A
     double tr[2] = {r.xown ? Pg[tri(r.xe, r.xe)] : 0.0, 0.0};
-    if (w < NTT) {
-#pragma unroll
-      for (int J = 0; J < NTT; ++J)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
-          if (i == j && i < n) tr[1] += acc[J][qq];
-        }
-    }
-    const bool sums[2] = {true, true};
-    block_reduce<2>(tr, sums, s_red);
-    rho = fmin(fmax(RHO_AUTO_SCALE * sqrt(tr[0] / tr[1]), OSQP_RHO_MIN), OSQP_RHO_MAX);
-    *rho_io = rho;
-  }
-  if (w < NTT) {
 #pragma unroll
     for (int J = 0; J < NTT; ++J)
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
-        acc[J][qq] = (i < n && j < n) ? cs * pp[J][qq] + rho * acc[J][qq] + (i == j ? s_Dv[XOFF + i] : 0.0) : (i == j ? 1.0 : 0.0);
+        if (F16_OWNS(J) && i == j && i < n) tr[1] += acc[J][qq];
       }
-  } else {
-#pragma unroll
-    for (int J = 0; J < NTT; ++J) acc[J] = d4_t{0.0, 0.0, 0.0, 0.0};
+    const bool sums[2] = {true, true};
+    block_reduce<2>(tr, sums, s_red);
+    rho = fmin(fmax(RHO_AUTO_SCALE * sqrt(tr[0] / tr[1]), OSQP_RHO_MIN), OSQP_RHO_MAX);
+    *rho_io = rho;
   }
+#pragma unroll
+  for (int J = 0; J < NTT; ++J)
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
+      const double kij = (i < n && j < n) ? cs * pp[J][qq] + rho * acc[J][qq] + (i == j ? s_Dv[XOFF + (i < n ? i : 0)] : 0.0) : (i == j ? 1.0 : 0.0);
+      acc[J][qq] = F16_OWNS(J) ? kij : 0.0;
+    }
   FSTAMP(2)
   const bool ok = mfma_inverse<NTT>(acc, s_Cs, acc);
   FSTAMP(3)
@@ -723,7 +742,8 @@ __device__ __noinline__ bool kkt_factorise(const double *Pg, double *gw, bool ha
 #pragma unroll
       for (int J = 0; J < NTT; ++J)
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) Mst[(4 * qq + lq) * FN + 16 * J + lc] = -acc[J][qq];
+        for (int qq = 0; qq < 4; ++qq)
+          if (F16_OWNS(J)) Mst[(4 * qq + lq) * FN + 16 * J + lc] = -acc[J][qq];
     }
     __syncthreads();
 #pragma unroll
