@@ -546,8 +546,15 @@ __device__ __noinline__ void ruiz_equilibrate(const double *Pg, int N, int passe
   p_row_norms();
   __syncthreads();
   const int d0 = 2 * q, d1 = 2 * q + 1;
-  const double *g0 = s_Gl + (d0 < N ? d0 : 0) * 27, *g1 = s_Gl + (d1 < N ? d1 : 0) * 27;
-  const double m0 = d0 < N ? 1.0 : 0.0, m1 = d1 < N ? 1.0 : 0.0;
+  // |G_d| of this lane's two Toeplitz blocks, all nine rows, zero beyond the horizon: read ONCE (54 LDS reads per lane that
+  // every pass repeated -- the stores of a pass may alias them as far as the compiler can tell)
+  double ag0[27], ag1[27];
+  {
+    const double *g0 = s_Gl + (d0 < N ? d0 : 0) * 27, *g1 = s_Gl + (d1 < N ? d1 : 0) * 27;
+    const double m0 = d0 < N ? 1.0 : 0.0, m1 = d1 < N ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) { ag0[k] = fabs(g0[k]) * m0; ag1[k] = fabs(g1[k]) * m1; }
+  }
   for (int pass = 0; pass < passes; ++pass) {
     // column norms of the state block of Ab (before the D of the column) and row norms (before the E of the row):
     // lane q covers the blocks d = 2q, 2q+1
@@ -558,13 +565,13 @@ __device__ __noinline__ void ruiz_equilibrate(const double *Pg, int N, int passe
     for (int k = 0; k < 6; ++k) dv[k] = dp[k];               // D of step i-2q-1 (3), of step i-2q (3)
 #pragma unroll
     for (int rr = 0; rr < 9; ++rr) {
-      const double e0 = ep[rr] * m0, e1 = ep[9 + rr] * m1;
+      const double e0 = ep[rr], e1 = ep[9 + rr];
       double m = 0.0;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const double a0 = fabs(g0[rr * 3 + c]), a1 = fabs(g1[rr * 3 + c]);
+        const double a0 = ag0[rr * 3 + c], a1 = ag1[rr * 3 + c];
         colS[c] = fmax(colS[c], fmax(a0 * e0, a1 * e1));
-        m = fmax(m, fmax(a0 * m0 * dv[3 + c], a1 * m1 * dv[c]));
+        m = fmax(m, fmax(a0 * dv[3 + c], a1 * dv[c]));
       }
       rowS[rr] = row_allmax(m);
     }
@@ -609,6 +616,63 @@ __device__ __noinline__ void ruiz_equilibrate(const double *Pg, int N, int passe
 // 4kk..4kk+3, the operand of column tile T is G_(i-j)[S r][c] gathered from LDS, the SAME value serves as the A operand of
 // tile row T and (times w) as the B operand of tile column T --, the command rows (identity) and rate rows (D = I - shift_3)
 // as a diagonal / third-off-diagonal fix-up.  gram: tile row w of this lane (24 values).
+// Causality: row (i, r) of the state block has entries only in columns of steps j <= i, so column tile T sees nothing of
+// the k-steps before kk0(T) = 6 floor(16 T / 3) / 4 and tile (w, J) starts at kk0(max(w, J)): 620 instead of 1,620
+// tile-k-steps at N = 30.  The k range is cut at these thresholds into SEGMENTS with a fixed set of live tiles (segment S:
+// column tiles 0..S), so that a segment is straight-line code -- operands of the next k-step fetched from LDS under the
+// matrix-core products of the current one.  (As ONE loop with a per-tile `if (kk >= kk0(J))` the compiler kept a second copy
+// of every accumulator and waited out the full latency of each product and of each gather in turn: 57 k cycles for the
+// 154 products of the busiest wave.)
+__host__ __device__ constexpr int gram_kk0(int T) { return (6 * ((16 * T) / 3)) >> 2; }
+struct GramOps { double a, b[NT]; };
+template <int NTT, int S>
+__device__ __forceinline__ void gram_load(GramOps &o, int kk, int lq, int N, int jW, int offW, const int (&jT)[NTT],
+                                          const int (&offT)[NTT]) {
+  const int rw = 4 * kk + lq, i = rw / 6, rr = rw - 6 * i;
+  const int base = 27 * i + 3 * (rr < 5 ? rr + 2 : 8);
+  const double wgt = s_Wg[rw];                               // 0 beyond row 6N
+  const bool vi = i < N;
+  // (unconditional reads at clamped addresses, then selects: predicated reads would put a branch around every gather)
+  const int ia = base + offW;
+  const double ga = s_Gl[ia < 0 ? 0 : ia];
+  double gb[S + 1];
+#pragma unroll
+  for (int J = 0; J <= S; ++J) {
+    const int ib = base + offT[J];
+    gb[J] = s_Gl[ib < 0 ? 0 : ib];
+  }
+  o.a = (vi && i >= jW) ? ga : 0.0;
+#pragma unroll
+  for (int J = 0; J <= S; ++J) o.b[J] = (vi && i >= jT[J]) ? gb[J] * wgt : 0.0;
+}
+template <int NTT, int S>
+__device__ __forceinline__ void gram_segment(d4_t (&acc)[NT], int lo, int hi, int lq, int N, int jW, int offW,
+                                             const int (&jT)[NTT], const int (&offT)[NTT]) {
+  if (lo >= hi) return;                                      // (uniform)
+  GramOps cur, nxt;
+  gram_load<NTT, S>(cur, lo, lq, N, jW, offW, jT, offT);
+  for (int kk = lo; kk < hi; ++kk) {
+    gram_load<NTT, S>(nxt, kk + 1 < hi ? kk + 1 : kk, lq, N, jW, offW, jT, offT);   // (the last prefetch repeats the current step)
+#pragma unroll
+    for (int J = 0; J <= S; ++J) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a, cur.b[J], acc[J], 0, 0, 0);
+    cur = nxt;
+  }
+}
+template <int NTT, int S>
+struct GramSegments {
+  static __device__ __forceinline__ void run(d4_t (&acc)[NT], int kw, int nk, int lq, int N, int jW, int offW,
+                                             const int (&jT)[NTT], const int (&offT)[NTT]) {
+    GramSegments<NTT, S - 1>::run(acc, kw, nk, lq, N, jW, offW, jT, offT);
+    const int lo = kw > gram_kk0(S) ? kw : gram_kk0(S);
+    const int top = S + 1 < NTT ? gram_kk0(S + 1) : (1 << 20);
+    gram_segment<NTT, S>(acc, lo, top < nk ? top : nk, lq, N, jW, offW, jT, offT);
+  }
+};
+template <int NTT>
+struct GramSegments<NTT, -1> {
+  static __device__ __forceinline__ void run(d4_t (&)[NT], int, int, int, int, int, int, const int (&)[NTT], const int (&)[NTT]) {}
+};
+
 template <int NTT>
 __device__ __forceinline__ void gram_tiles(d4_t (&acc)[NT], int N) {
   const int n = 3 * N;
@@ -627,24 +691,8 @@ __device__ __forceinline__ void gram_tiles(d4_t (&acc)[NT], int N) {
     }
     const int colw = 16 * w + lc;
     const int jW = colw < n ? colw / 3 : 1 << 20, offW = (colw - 3 * (colw / 3)) - 27 * (colw / 3);
-    // causality: row (i, r) of the state block has entries only in columns of steps j <= i, so column tile T sees nothing of
-    // the k-steps before kk0(T) = 6 floor(16 T / 3) / 4 -- tile (w, J) starts at kk0(max(w, J)): 620 instead of 1,620
-    // tile-k-steps at N = 30
     const int nk = (6 * N + 3) >> 2;
-    for (int kk = (6 * ((16 * w) / 3)) >> 2; kk < nk; ++kk) {
-      const int rw = 4 * kk + lq, i = rw / 6, rr = rw - 6 * i;
-      const int base = 27 * i + 3 * (rr < 5 ? rr + 2 : 8);
-      const double wgt = s_Wg[rw];                           // 0 beyond row 6N
-      const bool vi = i < N;
-      const double a_op = (vi && i >= jW) ? s_Gl[base + offW] : 0.0;
-#pragma unroll
-      for (int J = 0; J < NTT; ++J) {
-        if (F16_OWNS(J) && kk >= ((6 * ((16 * J) / 3)) >> 2)) {   // (uniform)
-          const double b_op = (vi && i >= jT[J]) ? s_Gl[base + offT[J]] * wgt : 0.0;
-          acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op, acc[J], 0, 0, 0);
-        }
-      }
-    }
+    GramSegments<NTT, NTT - 1>::run(acc, (6 * ((16 * w) / 3)) >> 2, nk, lq, N, jW, offW, jT, offT);
 #pragma unroll
     for (int J = 0; J < NTT; ++J)
 #pragma unroll
