@@ -35,9 +35,14 @@ namespace f16 {
 constexpr int FT = 512;                    // lanes per aircraft
 constexpr int FN = 3 * FAST_MAXN;          // 96
 
-// workgroup-wide reductions of NV values at once (red: [8][NV] doubles of LDS); max only of non-negative values
+// workgroup-wide reductions of NV <= 16 values at once (red: [8][NV] doubles of LDS); max only of non-negative values.
+// Wave totals on the DPP network (uniform), one LDS slot per (wave, value); then lane i < NV of EVERY wave combines column
+// i over the eight waves (8 reads per lane) and the NV results become wave-uniform again through v_readlane.  (The first
+// version had every lane read all 8 x NV partials: 36 wide reads per lane, 8 clocks each on the one LDS pipe of the CU, for
+// the nine values of the termination test -- more LDS time than three ADMM iterations.)
 template <int NV>
 __device__ __forceinline__ void block_reduce(double (&v)[NV], const bool (&is_sum)[NV], double *red) {
+  static_assert(NV <= 16, "one lane per value");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = is_sum[i] ? wave_reduce_dpp<true>(v[i]) : wave_reduce_dpp<false>(v[i]);
@@ -47,12 +52,21 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], const bool (&is_su
     for (int i = 0; i < NV; ++i) red[wv * NV + i] = v[i];
   }
   __syncthreads();
+  unsigned summask = 0;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    double r = red[i];
-    for (int w = 1; w < FT / 64; ++w) r = is_sum[i] ? r + red[w * NV + i] : fmax(r, red[w * NV + i]);
-    v[i] = r;
-  }
+  for (int i = 0; i < NV; ++i) summask |= is_sum[i] ? (1u << i) : 0u;
+  const int col = lane < NV ? lane : 0;
+  double x[FT / 64];
+#pragma unroll
+  for (int w = 0; w < FT / 64; ++w) x[w] = red[w * NV + col];
+  double rs = x[0], rm = x[0];
+#pragma unroll
+  for (int w = 1; w < FT / 64; ++w) { rs += x[w]; rm = fmax(rm, x[w]); }
+  const double r = ((summask >> col) & 1u) ? rs : rm;
+  const int rlo = __double2loint(r), rhi = __double2hiint(r);
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    v[i] = __hiloint2double(__builtin_amdgcn_readlane(rhi, i), __builtin_amdgcn_readlane(rlo, i));
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -40,13 +40,20 @@ __device__ __forceinline__ double dpp_masked_f64(double v) {      // lanes outsi
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xF, false);
   return __hiloint2double(hi, lo);
 }
+template <int CTRL>
+__device__ __forceinline__ double dpp_all_f64(double v) {         // every row takes part: no `old` operand to set up
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
 template <bool SUM>
 __device__ __forceinline__ double wave_reduce_dpp(double v) {
   auto op = [](double a, double b) { return SUM ? a + b : fmax(a, b); };
-  v = op(v, dpp_masked_f64<0xB1, 0xF>(v));       // quad_perm [1,0,3,2]
-  v = op(v, dpp_masked_f64<0x4E, 0xF>(v));       // quad_perm [2,3,0,1]
-  v = op(v, dpp_masked_f64<0x141, 0xF>(v));      // row_half_mirror
-  v = op(v, dpp_masked_f64<0x140, 0xF>(v));      // row_mirror: every lane of a row holds the row total
+  v = op(v, dpp_all_f64<0xB1>(v));               // quad_perm [1,0,3,2]
+  v = op(v, dpp_all_f64<0x4E>(v));               // quad_perm [2,3,0,1]
+  v = op(v, dpp_all_f64<0x141>(v));              // row_half_mirror
+  v = op(v, dpp_all_f64<0x140>(v));              // row_mirror: every lane of a row holds the row total
   v = op(v, dpp_masked_f64<0x142, 0xA>(v));      // row_bcast:15 -> rows 1, 3
   v = op(v, dpp_masked_f64<0x143, 0xC>(v));      // row_bcast:31 -> rows 2, 3
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
