@@ -412,12 +412,16 @@ def bench_closed_loop(args, dev, rank, world, fdist, barrier):
     res = {}
     short = max(4, T // 5)
     for name, use_plan, steps in (("prepared_plan", True, T), ("one_shot", False, max(4, short // 2)),
-                                  ("prepared_plan_warm_start", True, short), ("prepared_plan_warm_start_check5", True, short)):
+                                  ("prepared_plan_warm_start", True, short), ("prepared_plan_warm_start_check5", True, short),
+                                  ("prepared_plan_builder_rule", True, short),
+                                  ("prepared_plan_builder_rule_warm_start", True, short)):
         env = F16Batch(x0[sl], u0[sl], xcg=0.35, device=dev)
         env.build_ssr()
         if use_plan:
-            env.prepare_MPC(args.mpc_hzn, settings=dict(check_every=5) if name.endswith("check5") else None,
-                            warm_start="warm_start" in name)
+            st = dict(check_every=5) if name.endswith("check5") else {}
+            if "builder_rule" in name:
+                st.update(F16Batch.solver_modes()["builder_rule"])
+            env.prepare_MPC(args.mpc_hzn, settings=st or None, warm_start="warm_start" in name)
         fdist.closed_loop_mpc_rollout(env, steps=2, hzn=args.mpc_hzn, gather=False, use_plan=use_plan)
         env.reset()
         barrier()
@@ -444,7 +448,8 @@ def bench_closed_loop(args, dev, rank, world, fdist, barrier):
     res["hzn"] = args.mpc_hzn
     res["note"] = ("prepared_plan / one_shot start every solve cold, as the reference does (a new OSQP object per call); "
                    "warm_start is the opt-in extension (OSQP's in-object default); check5 = the same with the termination test "
-                   "every 5 iterations instead of OSQP's 25 (a warm-started solve needs fewer than 25)")
+                   "every 5 iterations instead of OSQP's 25 (a warm-started solve needs fewer than 25); builder_rule = the opt-in "
+                   "solver settings (no equilibration, start value of rho from the traces; KKT factorisation cached in the plan)")
     return res
 
 
