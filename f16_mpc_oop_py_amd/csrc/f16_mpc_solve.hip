@@ -369,6 +369,20 @@ __device__ __forceinline__ double reduce3(double v0, double v1, double v2, bool 
   k += dpp_f64<DPP_XOR1>(k);
   return k;
 }
+// The same with the three inputs in SLOT ORDER -- a = the value this lane's half of the row keeps (h ? v2 : v0), b = v1,
+// c = the value it hands to its mirror partner (h ? v0 : v2): the caller stores its operator rows in that order per lane
+// (stage 2: the rows of the re-laid KKT inverse), which removes the four selects of the mirror step.  v1 is summed on both
+// halves (the upper half's copy ends in lanes 12-15, which own nothing).
+__device__ __forceinline__ double reduce3_slots(double a, double b, double c, bool g) {
+  const double k0 = a + dpp_f64<DPP_MIRROR>(c);
+  const double k1 = b + dpp_f64<DPP_MIRROR>(b);
+  const double s = g ? k0 : k1;
+  double k = g ? k1 : k0;
+  k += dpp_f64<DPP_HMIRROR>(s);
+  k += dpp_f64<DPP_XOR2>(k);
+  k += dpp_f64<DPP_XOR1>(k);
+  return k;
+}
 // reduce4: quad k of the row (lanes 4k..4k+3) ends up with the total of v[k] -- mirror step keeps two of the four values
 // and hands two over, half-mirror step keeps one, then two butterfly steps.  Written naively that is twelve selects per
 // call; instead the caller keeps its four values in slot order (slot_of below): slot 0 = the value this lane's quad ends
@@ -724,7 +738,8 @@ __device__ __forceinline__ void gram_tiles(d4_t (&acc)[NT], int N) {
 // ---- One KKT factorisation: K = c P + sigma D^-2 + rho A'WA as matrix-core tiles (Gram product above; it does not depend
 // on rho, so the first factorisation of a solve parks it in the workspace `gw` and the rho updates read it back), blocked
 // sweep on the matrix cores (mfma_inverse), then the RE-LAYOUT for the iterations: lane q of DPP row blk receives
-// K^-1[3 blk + c][6 q + cc] (c < 3, cc < 6; the layout of the cached P entries) through LDS, one tile row at a time, in
+// K^-1[3 blk + c][6 q + cc] (c < 3 -- in the slot order of reduce3_slots: rows 2, 1, 0 in the upper half of a DPP row --,
+// cc < 6; up to that order the layout of the cached P entries) through LDS, one tile row at a time, in
 // the memory of the iteration vectors (dead during a factorisation).  rho <= 0 on entry: the builder's opt-in start value
 // 2 sqrt(tr P / tr A'A) (no equilibration).  mrow: 18 values per lane.  Returns whether every pivot block was positive
 // definite (uniform).
@@ -810,7 +825,7 @@ __device__ __noinline__ bool kkt_factorise(const double *Pg, double *gw, bool ha
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const int i = 3 * r.blk + c;
+      const int i = 3 * r.blk + (r.h ? 2 - c : c);          // slot order of reduce3_slots: the upper half of a row holds rows 2, 1, 0
       if ((i >> 4) == ww) {
 #pragma unroll
         for (int cc = 0; cc < 6; ++cc) mr[c][cc] = (6 * r.q + cc) < 16 * NTT ? Mst[(i & 15) * FN + 6 * r.q + cc] : 0.0;
@@ -915,7 +930,7 @@ __device__ __noinline__ int admm_iterate(SolveState *st, const double *mrow_in, 
       for (int cc = 0; cc < 6; ++cc)
 #pragma unroll
         for (int c = 0; c < 3; ++c) p3[c] = fma(mrow[c][cc], rj[cc], p3[c]);
-      xt_own = reduce3(p3[0], p3[1], p3[2], h, g);
+      xt_own = reduce3_slots(p3[0], p3[1], p3[2], g);
       if (xown) xtP[XOFF + xe] = xt_own;
     }
     MSTAMP(2)
