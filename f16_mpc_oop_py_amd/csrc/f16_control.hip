@@ -1001,6 +1001,12 @@ static int mpc_work_alloc(f16_ctx *ctx, MpcArgs &a, bool with_ext, void *stream,
   const size_t np = (size_t)(3 * a.N) * (3 * a.N + 1) / 2;
   const size_t need = (np + (with_ext ? mpc_ext_doubles(a.N) : 0) + (with_gram ? MPC_TILE_DOUBLES : 0)) * (size_t)a.B * sizeof(double);
   *block = nullptr;
+  // Not under stream capture: replays of a graph holding these stream-ordered allocation / free nodes were measured to
+  // return wrong results intermittently on ROCm 7.2 (the workspace is not stable across replays).  A prepared plan owns its
+  // workspace for its lifetime and IS capturable (f16_mpc_plan_solve; tests).
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+    return set_error(F16_EINVAL, "one-shot MPC calls cannot be captured into a HIP graph (per-call workspace): use f16_mpc_plan_solve");
   if (int rc = hip_check(hipMallocFromPoolAsync(block, need, ctx->pool, (hipStream_t)stream), "hipMallocFromPoolAsync QP workspace")) return rc;
   a.Ppk = (double *)*block;
   a.ext = with_ext ? a.Ppk + np * (size_t)a.B : nullptr;

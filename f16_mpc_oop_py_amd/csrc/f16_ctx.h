@@ -13,7 +13,7 @@ struct f16_ctx {
   double *h_one;    // pinned mirror
   // One-shot MPC calls keep NO mutable state that two calls could share:
   //  * the QP workspace (packed P and A'A + extras per aircraft) is allocated and freed PER CALL, stream-ordered
-  //    (hipMallocFromPoolAsync / hipFreeAsync on the caller's stream, legal under stream capture), from this pool, whose
+  //    (hipMallocFromPoolAsync / hipFreeAsync on the caller's stream; refused under stream capture), from this pool, whose
   //    release threshold keeps the memory cached between calls;
   //  * the dispatch-order history (iteration counts of the previous call | order derived from them, [2][B] int32) is
   //    kept per (stream, batch size): calls on one stream are ordered, calls on different streams never touch the same

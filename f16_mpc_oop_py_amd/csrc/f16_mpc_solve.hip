@@ -88,7 +88,7 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 #ifdef F16_EXP_STAMPM
 __device__ double g_inv_stamp[16];      // diagnostic build: per-wave work / barrier-wait cycles of the factorisation
 __device__ double g_it_stamp[8 * 6];    // per wave: cycles in phase A, barrier, B, barrier, C (+ test), barrier, summed over iterations
-__device__ double g_f_stamp[6];         // last factorisation of workgroup 0: Gram, assembly, sweep, re-layout; equilibration; iterations stamped
+__device__ double g_f_stamp[8];         // last factorisation of workgroup 0: Gram, assembly, sweep, re-layout; equilibration; iterations stamped
 #endif
 constexpr int NT = FN / 16;   // 6 tile rows / columns
 
@@ -496,7 +496,7 @@ __shared__ __attribute__((aligned(16))) double s_Cs[2 * FN * 4 + 40];      // pi
 __shared__ double s_rhs[FN], s_wc[FN], s_wr[FN + 4], s_yc[FN], s_yr[FN + 4], s_red[8 * 9];
 __shared__ double s_sg2[FN], s_cq[FN], s_q[FN], s_cD[FN], s_cinv;          // per variable: sigma D^-2, c q, q, c D; 1 / c
 __shared__ double s_Dv[XTP], s_Es9[ES9], s_Ecv[FN], s_Erv[FN + 4], s_Wg[WGN], s_Wcv[FN], s_Wrv[FN + 4], s_nPm[FN];
-__shared__ __attribute__((aligned(16))) double s_Gl[27 * FAST_MAXN];       // all nine rows of every G_k: equilibration, Gram
+__shared__ __attribute__((aligned(16))) double s_Gl[27 * (FAST_MAXN + 1)]; // all nine rows of every G_k (equilibration, Gram) + a zero block
 __shared__ double s_px[18 * FT];       // this lane's 18 entries of P (termination test): lane q of row blk holds P[3 blk + c][6 q + cc]
 __shared__ double s_lc[4 * FT];        // per constraint row: lower bound | upper bound | weight W = E^2 | rho-vector factor
 
@@ -653,37 +653,75 @@ __device__ __noinline__ void ruiz_equilibrate(const double *Pg, int N, int passe
 // 154 products of the busiest wave.)
 __host__ __device__ constexpr int gram_kk0(int T) { return (6 * ((16 * T) / 3)) >> 2; }
 struct GramOps { double a, b[NT]; };
+struct GramAddr { int i, iw, ia, ib[NT]; };                  // row step, LDS indices of the weight and of the gathers
+struct GramRaw { double wgt, ga, gb[NT]; };
+// The operands of one k-step in three stages, so that the loop below can keep them in flight: indices (integer arithmetic),
+// LDS reads, finish (weights and causality masks).
 template <int NTT, int S>
-__device__ __forceinline__ void gram_load(GramOps &o, int kk, int lq, int N, int jW, int offW, const int (&jT)[NTT],
-                                          const int (&offT)[NTT]) {
+__device__ __forceinline__ void gram_addr(GramAddr &A, int kk, int lq, int offW, const int (&offT)[NTT]) {
   const int rw = 4 * kk + lq, i = rw / 6, rr = rw - 6 * i;
   const int base = 27 * i + 3 * (rr < 5 ? rr + 2 : 8);
-  const double wgt = s_Wg[rw];                               // 0 beyond row 6N
-  const bool vi = i < N;
-  // (unconditional reads at clamped addresses, then selects: predicated reads would put a branch around every gather)
+  A.i = i; A.iw = rw;
+  // In segment S the column tiles 0..S-2 lie wholly below the diagonal (every row step i >= every column step j: index
+  // >= 0, no mask); tiles S-1 and S straddle it.  Rows beyond 6N (last k-step) carry weight 0 and gather from the
+  // zero-filled block N of s_Gl.
   const int ia = base + offW;
-  const double ga = s_Gl[ia < 0 ? 0 : ia];
-  double gb[S + 1];
+  A.ia = ia < 0 ? 0 : ia;
 #pragma unroll
   for (int J = 0; J <= S; ++J) {
     const int ib = base + offT[J];
-    gb[J] = s_Gl[ib < 0 ? 0 : ib];
+    A.ib[J] = (J >= S - 1 && ib < 0) ? 0 : ib;
   }
-  o.a = (vi && i >= jW) ? ga : 0.0;
-#pragma unroll
-  for (int J = 0; J <= S; ++J) o.b[J] = (vi && i >= jT[J]) ? gb[J] * wgt : 0.0;
 }
+template <int S>
+__device__ __forceinline__ void gram_read(GramRaw &R, const GramAddr &A) {
+  R.wgt = s_Wg[A.iw];                                        // 0 beyond row 6N
+  R.ga = s_Gl[A.ia];
+#pragma unroll
+  for (int J = 0; J <= S; ++J) R.gb[J] = s_Gl[A.ib[J]];
+}
+template <int NTT, int S>
+__device__ __forceinline__ void gram_finish(GramOps &o, const GramAddr &A, const GramRaw &R, int jW, const int (&jT)[NTT]) {
+  o.a = A.i >= jW ? R.ga : 0.0;
+#pragma unroll
+  for (int J = 0; J <= S; ++J) {
+    const double v = R.gb[J] * R.wgt;
+    o.b[J] = (J >= S - 1) ? (A.i >= jT[J] ? v : 0.0) : v;
+  }
+}
+// One segment: the reads of k-step kk+1 and the indices of kk+2 are issued before the products of kk (left to itself the
+// compiler waits for each k-step's gathers right after issuing them: ~850 clocks per k-step for ~200 clocks of products).
 template <int NTT, int S>
 __device__ __forceinline__ void gram_segment(d4_t (&acc)[NT], int lo, int hi, int lq, int N, int jW, int offW,
                                              const int (&jT)[NTT], const int (&offT)[NTT]) {
+  (void)N;
   if (lo >= hi) return;                                      // (uniform)
-  GramOps cur, nxt;
-  gram_load<NTT, S>(cur, lo, lq, N, jW, offW, jT, offT);
-  for (int kk = lo; kk < hi; ++kk) {
-    gram_load<NTT, S>(nxt, kk + 1 < hi ? kk + 1 : kk, lq, N, jW, offW, jT, offT);   // (the last prefetch repeats the current step)
+  GramAddr A0, A1, A2;
+  GramRaw R0, R1;
+  GramOps o;
+  const int last = hi - 1;
+  gram_addr<NTT, S>(A0, lo, lq, offW, offT);
+  gram_read<S>(R0, A0);
+  gram_addr<NTT, S>(A1, lo + 1 < hi ? lo + 1 : last, lq, offW, offT);
+  // two k-steps per trip with the raw operands in ping-pong registers (a rotating copy R0 = R1 makes the compiler wait for
+  // the reads it has just issued)
+  for (int kk = lo; kk < hi; kk += 2) {
+    gram_read<S>(R1, A1);                                    // k-step kk + 1 (past the end: repeats hi - 1, harmless)
+    F16_LDS_PHASE();
+    gram_addr<NTT, S>(A2, kk + 2 < hi ? kk + 2 : last, lq, offW, offT);
+    gram_finish<NTT, S>(o, A0, R0, jW, jT);
 #pragma unroll
-    for (int J = 0; J <= S; ++J) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a, cur.b[J], acc[J], 0, 0, 0);
-    cur = nxt;
+    for (int J = 0; J <= S; ++J) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a, o.b[J], acc[J], 0, 0, 0);
+    if (kk + 1 < hi) {                                       // (uniform)
+      gram_read<S>(R0, A2);                                  // k-step kk + 2
+      F16_LDS_PHASE();
+      gram_addr<NTT, S>(A0, kk + 3 < hi ? kk + 3 : last, lq, offW, offT);
+      gram_finish<NTT, S>(o, A1, R1, jW, jT);
+#pragma unroll
+      for (int J = 0; J <= S; ++J) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a, o.b[J], acc[J], 0, 0, 0);
+    }
+    // next trip: step kk + 2 is (A2, R0), step kk + 3 is A0 (indices only so far)
+    A1 = A0; A0 = A2;
   }
 }
 template <int NTT, int S>
@@ -771,7 +809,14 @@ __device__ __noinline__ bool kkt_factorise(const double *Pg, double *gw, bool ha
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) acc[J][qq] = F16_OWNS(J) ? gwl[(J * 4 + qq) * 64] : 0.0;
   } else {
+#ifdef F16_EXP_GRAMSTAMP
+    FSTAMP(0)
+#endif
     gram_tiles<NTT>(acc, N);
+#ifdef F16_EXP_GRAMSTAMP
+    FSTAMP(1)
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_f_stamp[6] = (double)(tF[1] - tF[0]);
+#endif
     if (gwl) {
 #pragma unroll
       for (int J = 0; J < NTT; ++J)
@@ -1072,7 +1117,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
   const double *Pg = a.Ppk + (size_t)b * (n * (n + 1) / 2);
   const double *Gg = exw + n, *pred = exw + n + 27 * N;
   double *const exm = exw + mpc_ext_model(N);                 // A | Q | Qbar | rho, ok of a prepared plan
-  for (int i = tid; i < 27 * N; i += FT) s_Gl[i] = Gg[i];
+  for (int i = tid; i < 27 * (N + 1); i += FT) s_Gl[i] = i < 27 * N ? Gg[i] : 0.0;      // (block N: what rows beyond 6N gather)
   const double qe = xown ? exw[xe] : 0.0;
   // the termination test needs P x: row blk's 16 lanes split the columns six apiece, so a lane touches the SAME 18
   // entries of P at every test -- fetched once here into per-lane LDS slots
@@ -1100,7 +1145,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
   if (kind == 3) s_Erv[k3] = 1.0;
   __syncthreads();                                            // zeros, G, D = E = 1 are in place
 #ifdef F16_EXP_STAMPM
-  if (blockIdx.x == 0) { if (tid < 48) g_it_stamp[tid] = 0.0; if (tid < 6) g_f_stamp[tid] = 0.0; }
+  if (blockIdx.x == 0) { if (tid < 48) g_it_stamp[tid] = 0.0; if (tid < 8) g_f_stamp[tid] = 0.0; }
   const unsigned long long tE0 = __builtin_amdgcn_s_memtime();
 #endif
   if (a.mode == 0 && a.s.scaling > 0) {
@@ -1197,7 +1242,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
   __syncthreads();      // diagnostic build: the u_seq column of the aircraft solved by workgroup 0 is replaced by the stamps
   if (blockIdx.x == 0 && a.useq) {
     if (tid < 48) a.useq[tid * a.ld + b] = g_it_stamp[tid] / fmax(g_f_stamp[5], 1.0);
-    if (tid < 6) a.useq[(66 + tid) * a.ld + b] = g_f_stamp[tid];
+    if (tid < 8) a.useq[(66 + tid) * a.ld + b] = g_f_stamp[tid];
     if (tid < 16) a.useq[(50 + tid) * a.ld + b] = g_inv_stamp[tid];
   }
 #endif

@@ -146,7 +146,9 @@ int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double
  * u_seq (may be NULL) gets the full [3*hzn][ld] sequence, info (may be NULL) gets [4][ld] = iterations, r_prim, r_dual
  * (unscaled), rho.
  * Nothing the results depend on is retained between calls: the QP workspace is allocated and freed per call, stream-ordered
- * on `stream` (legal under stream capture); calls on different streams of one context do not share buffers.
+ * on `stream`; calls on different streams of one context do not share buffers.  Under stream capture the call returns
+ * F16_EINVAL (graph replays of the stream-ordered allocation were measured unreliable on ROCm 7.2): capture
+ * f16_mpc_plan_solve instead, whose workspace lives with the plan.
  * Scheduling only: workgroups are dispatched longest-first by the iteration counts of the previous call of the same
  * batch size on the same stream (results do not depend on it; F16_MPC_DISPATCH_ORDER=0 keeps the caller's order). */
 typedef struct f16_qp_settings {

@@ -585,3 +585,37 @@ def test_lqr_gain_on_config3_workload_sample(oracle):
         worst_x = max(worst_x, np.abs(Xg[b] - Xref).max() / np.abs(Xref).max())
     assert worst_x < 1e-8, worst_x
     assert worst_k < 1e-6, worst_k
+
+
+def test_plan_solves_replay_from_a_hip_graph_and_one_shot_calls_refuse_capture():
+    """A prepared plan owns its workspace, so its solve can be captured into a HIP graph (through torch) and replayed: six
+    replays return what the eager call returns, bit for bit.  The one-shot call allocates per call, stream-ordered; graphs
+    holding those allocation nodes replayed with wrong results intermittently on ROCm 7.2, so it refuses to be captured."""
+    from f16_mpc_oop_py_amd import F16Batch, lib
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(256, seed=5)
+    env = F16Batch(x0, u0, xcg=0.35)
+    env.build_ssr()
+    env.prepare_MPC(30)
+    u_eager = env._calc_MPC_action(0, 0, 0, 30, use_plan=True).clone()
+    assert torch.equal(u_eager, env._calc_MPC_action(0, 0, 0, 30))       # plan == one-shot
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        env._calc_MPC_action(0, 0, 0, 30, use_plan=True)        # (first call on a side stream outside the capture)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        u_cap = env._calc_MPC_action(0, 0, 0, 30, use_plan=True)
+    for _ in range(6):
+        u_cap.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(u_cap, u_eager)
+    g2 = torch.cuda.CUDAGraph()
+    with pytest.raises(lib.F16HipError):
+        with torch.cuda.graph(g2):
+            env._calc_MPC_action(0, 0, 0, 30)
+    torch.cuda.synchronize()
+    assert torch.equal(env._calc_MPC_action(0, 0, 0, 30), u_eager)       # the context is still usable afterwards

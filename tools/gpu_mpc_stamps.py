@@ -23,4 +23,4 @@ print("cycles per iteration, rows = waves, cols = A, bar1, B, bar2, C, bar3 (s_m
 print(s, s.sum(1))
 print("factorisation, per wave (work, barrier wait) cycles:", info["u_seq"][0, 50:66].cpu().numpy().reshape(8, 2))
 print("last factorisation, wave 0: P loads + gram / assembly (+ trace) / sweep / re-layout cycles:", info["u_seq"][0, 66:70].cpu().numpy())
-print("equilibration cycles:", float(info["u_seq"][0, 70]), " iterations stamped:", float(info["u_seq"][0, 71]))
+print("equilibration cycles:", float(info["u_seq"][0, 70]), " iterations stamped:", float(info["u_seq"][0, 71]), " gram product alone (F16_EXP_GRAMSTAMP builds):", float(info["u_seq"][0, 72]))
