@@ -457,7 +457,14 @@ __device__ __forceinline__ double conv_forward_row(const double *G, const double
 #else
 #define BSTAMP(i)
 #endif
-template <bool SETUP_ONLY>
+// Per-lane values of the constraint rows a lane owns (rows l, l + 64, ...): registers up to MAXN; beyond (BIG: horizons up
+// to BIG_MAXN, the reference's own sweep range env.py:426-436) they live in the per-aircraft global workspace, as does the
+// packed KKT inverse -- a slow path that exists so that the horizon limit is not a hard wall.
+template <bool BIG_> struct RowVec;
+template <> struct RowVec<false> { double v[MAXT]; __device__ __forceinline__ double &operator[](int i) { return v[i]; } };
+template <> struct RowVec<true> { double *p; __device__ __forceinline__ double &operator[](int i) { return p[i]; } };
+
+template <bool SETUP_ONLY, bool BIG = false>
 __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int N = a.N, n = 3 * N, np = n * (n + 1) / 2, ms = 6 * N, m = 12 * N;
@@ -466,8 +473,10 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
   // R0 is time-shared: DARE scratch -> (build) pred | Q-weighted error | q -> (generic solver) packed KKT inverse.
   // Build-only launches keep the footprint at 17.8 KB for N = 30 (eight wavefronts per CU): the Q G_k / Qbar G_k blocks
   // of the P recursion are formed just in time (jit, 54 doubles) instead of being stored for all k.
-  const int r0 = SETUP_ONLY ? 1100 : max(np, 1100);
-  double *Minv = al.take(r0);
+  const int r0 = (SETUP_ONLY || BIG) ? 1100 : max(np, 1100);
+  double *const R0 = al.take(r0);
+  double *Minv = R0;                  // packed KKT inverse of the generic solver (BIG: in the global workspace, set per aircraft)
+  const int TM = BIG ? (m + 63) / 64 : MAXT;     // constraint rows per lane
   double *G = al.take(N * 27);
   double *A = al.take(81), *Q = al.take(81), *Qb = al.take(81);
   double *jit = al.take(54);
@@ -476,10 +485,11 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
   double *qv, *wbuf, *pred;           // q | QQ (x_ref - MM x) | MM x: A^(i+1) x
   double *xs = nullptr, *xt = nullptr, *rhs = nullptr, *tv = nullptr;      // generic solver only
   double *Dg = nullptr, *E9 = nullptr, *Ec = nullptr, *Er = nullptr;       // generic solver: equilibration, then Gram weights
-  if (SETUP_ONLY) { pred = Minv; wbuf = Minv + 9 * N; qv = Minv + 18 * N; }      // 21 N <= 840 < 1100
-  else { qv = al.take(n); wbuf = al.take(m); pred = al.take(9 * N); xs = al.take(n); xt = al.take(n); rhs = al.take(n); tv = al.take(n);
-         Dg = al.take(n); E9 = al.take(9 * N); Ec = al.take(n); Er = al.take(n + 3); }
-  double *scr = Minv, *X = Minv + 760;                  // DARE scratch (748 doubles), then X (82)
+  if (SETUP_ONLY && !BIG) { pred = R0; wbuf = R0 + 9 * N; qv = R0 + 18 * N; }      // 21 N <= 840 < 1100
+  else { qv = al.take(n); wbuf = al.take(m); pred = al.take(9 * N); }
+  if (!SETUP_ONLY) { xs = al.take(n); xt = al.take(n); rhs = al.take(n); tv = al.take(n);
+                     Dg = al.take(n); E9 = al.take(9 * N); Ec = al.take(n); Er = al.take(n + 3); }
+  double *scr = R0, *X = R0 + 760;                  // DARE scratch (748 doubles), then X (82)
 
 #ifdef F16_EXP_STAMPB
   unsigned long long tB[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tb0 = __builtin_amdgcn_s_memtime();
@@ -587,7 +597,7 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
     // fewer LDS bytes but only N active lanes and as many address computations for the packed stores: 20 % slower.
     double *Pg = a.Ppk + (size_t)b * np;
     if (!update_only) {
-      constexpr int MAXCH = (9 * MAXN + F16_WAVE - 1) / F16_WAVE;
+      constexpr int MAXCH = (9 * (BIG ? BIG_MAXN : MAXN) + F16_WAVE - 1) / F16_WAVE;
       double tq[MAXCH];
 #pragma unroll
       for (int t = 0; t < MAXCH; ++t) tq[t] = 0.0;
@@ -631,27 +641,33 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
     }
     BSTAMP(5)
     // ---------------- bounds of the kept rows (utils.py:129-152): [6N state | 3N command | 3N rate]
-    double lo[MAXT], hi[MAXT], z[MAXT], y[MAXT], dy[MAXT];
+    RowVec<BIG> lo, hi, z, y, dy, Eo, eqf;
+    if constexpr (BIG) {
+      double *rows = a.bigws + (size_t)b * mpc_big_doubles(N);
+      Minv = rows + 7 * (size_t)(64 * TM);
+      lo.p = rows; hi.p = rows + 64 * TM; z.p = rows + 2 * 64 * TM; y.p = rows + 3 * 64 * TM; dy.p = rows + 4 * 64 * TM;
+      Eo.p = rows + 5 * 64 * TM; eqf.p = rows + 6 * 64 * TM;
+    }
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-      const int row = l + 64 * t;
-      lo[t] = 0.0; hi[t] = 0.0; z[t] = 0.0; y[t] = 0.0; dy[t] = 0.0;
+    for (int t = 0; t < TM; ++t) {
+      const int row = l + 64 * t, ri = BIG ? row : t;
+      lo[ri] = 0.0; hi[ri] = 0.0; z[ri] = 0.0; y[ri] = 0.0; dy[ri] = 0.0;
       if (row < ms) {
         const int i = row / 6, rr = row - 6 * i;
         const double pm = pred[i * 9 + SROW[rr]];
-        lo[t] = SLB[rr] - pm;
-        hi[t] = SUB[rr] - pm;
+        lo[ri] = SLB[rr] - pm;
+        hi[ri] = SUB[rr] - pm;
       } else if (row < ms + n) {
         const int c = (row - ms) % 3;
-        lo[t] = ULB[c]; hi[t] = UUB[c];
+        lo[ri] = ULB[c]; hi[ri] = UUB[c];
       } else if (row < m) {
         const int k = row - ms - n, c = k % 3;
         if (k < 3) {
           const double act = a.x[(13 + c) * a.ld + b];
-          lo[t] = act + RLB[c] * a.dt;
-          hi[t] = act + RUB[c] * a.dt;
+          lo[ri] = act + RLB[c] * a.dt;
+          hi[ri] = act + RUB[c] * a.dt;
         } else {
-          lo[t] = RLB[c]; hi[t] = RUB[c];              // reference quirk: not multiplied by dt (utils.py:151-152)
+          lo[ri] = RLB[c]; hi[ri] = RUB[c];              // reference quirk: not multiplied by dt (utils.py:151-152)
         }
       }
     }
@@ -711,24 +727,23 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
       __syncthreads();
     }
     // per-row E, scaled bounds, rho-vector factor and Gram weight of the kept rows; sigma D^-2 per variable
-    double Eo[MAXT], eqf[MAXT];
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-      const int row = l + 64 * t;
-      Eo[t] = 1.0; eqf[t] = 1.0;
+    for (int t = 0; t < TM; ++t) {
+      const int row = l + 64 * t, ri = BIG ? row : t;
+      Eo[ri] = 1.0; eqf[ri] = 1.0;
       if (row < m) {
-        Eo[t] = row < ms ? E9[9 * (row / 6) + SROW[row % 6]] : (row < ms + n ? Ec[row - ms] : Er[row - ms - n]);
-        lo[t] *= Eo[t]; hi[t] *= Eo[t];
-        eqf[t] = (hi[t] - lo[t] < OSQP_RHO_TOL) ? OSQP_RHO_EQ_OVER_RHO_INEQ : 1.0;
+        Eo[ri] = row < ms ? E9[9 * (row / 6) + SROW[row % 6]] : (row < ms + n ? Ec[row - ms] : Er[row - ms - n]);
+        lo[ri] *= Eo[ri]; hi[ri] *= Eo[ri];
+        eqf[ri] = (hi[ri] - lo[ri] < OSQP_RHO_TOL) ? OSQP_RHO_EQ_OVER_RHO_INEQ : 1.0;
       }
     }
     __syncthreads();                                      // E9 / Ec / Er are read; they now become the Gram weights W
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-      const int row = l + 64 * t;
-      if (row < ms) E9[9 * (row / 6) + SROW[row % 6]] = Eo[t] * Eo[t] * eqf[t];
-      else if (row < ms + n) Ec[row - ms] = Eo[t] * Eo[t] * eqf[t];
-      else if (row < m) Er[row - ms - n] = Eo[t] * Eo[t] * eqf[t];
+    for (int t = 0; t < TM; ++t) {
+      const int row = l + 64 * t, ri = BIG ? row : t;
+      if (row < ms) E9[9 * (row / 6) + SROW[row % 6]] = Eo[ri] * Eo[ri] * eqf[ri];
+      else if (row < ms + n) Ec[row - ms] = Eo[ri] * Eo[ri] * eqf[ri];
+      else if (row < m) Er[row - ms - n] = Eo[ri] * Eo[ri] * eqf[ri];
     }
     for (int e = l; e < n; e += F16_WAVE) Dg[e] = sigma / (Dg[e] * Dg[e]);     // Dg <- sigma D^-2  (c D of the rho estimate: sqrt back)
     __syncthreads();
@@ -779,9 +794,9 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
       ++it;
       // w = E (rho zb - yb) -> t = A' w ; rhs = sigma D^-2 x - c q + t
 #pragma unroll
-      for (int t = 0; t < MAXT; ++t) {
-        const int row = l + 64 * t;
-        if (row < m) wbuf[row] = Eo[t] * (rho * eqf[t] * z[t] - y[t]);
+      for (int t = 0; t < TM; ++t) {
+        const int row = l + 64 * t, ri = BIG ? row : t;
+        if (row < m) wbuf[row] = Eo[ri] * (rho * eqf[ri] * z[ri] - y[ri]);
       }
       __syncthreads();
       conv_adjoint<6>(tv, G, wbuf, N, SROW);
@@ -790,20 +805,20 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
       symv(xt, Minv, rhs, n);                               // x~
       // zb~ = E A x~ ; relaxation, projection, dual update
 #pragma unroll
-      for (int t = 0; t < MAXT; ++t) {
-        const int row = l + 64 * t;
+      for (int t = 0; t < TM; ++t) {
+        const int row = l + 64 * t, ri = BIG ? row : t;
         if (row < m) {
           double zt;
           if (row < ms) zt = conv_forward_row(G, xt, row / 6, SROW[row % 6]);
           else if (row < ms + n) zt = xt[row - ms];
           else { const int k = row - ms - n; zt = xt[k] - (k >= 3 ? xt[k - 3] : 0.0); }
-          zt *= Eo[t];
-          const double ro = rho * eqf[t];
-          const double zr = alpha * zt + (1 - alpha) * z[t];
-          const double zn = fmin(fmax(zr + y[t] / ro, lo[t]), hi[t]);
-          dy[t] = ro * (zr - zn);
-          y[t] = y[t] + dy[t];
-          z[t] = zn;
+          zt *= Eo[ri];
+          const double ro = rho * eqf[ri];
+          const double zr = alpha * zt + (1 - alpha) * z[ri];
+          const double zn = fmin(fmax(zr + y[ri] / ro, lo[ri]), hi[ri]);
+          dy[ri] = ro * (zr - zn);
+          y[ri] = y[ri] + dy[ri];
+          z[ri] = zn;
         }
       }
       for (int e = l; e < n; e += F16_WAVE) xs[e] = alpha * xt[e] + (1 - alpha) * xs[e];
@@ -812,17 +827,17 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
         // residuals of the UNSCALED problem (OSQP termination test) + the scaled ones for the rho estimate
         double r1 = 0.0, nAx = 0.0, nz = 0.0, r1s = 0.0, nAxs = 0.0, nzs = 0.0;
 #pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-          const int row = l + 64 * t;
+        for (int t = 0; t < TM; ++t) {
+          const int row = l + 64 * t, ri = BIG ? row : t;
           if (row < m) {
             double ax;
             if (row < ms) ax = conv_forward_row(G, xs, row / 6, SROW[row % 6]);
             else if (row < ms + n) ax = xs[row - ms];
             else { const int k = row - ms - n; ax = xs[k] - (k >= 3 ? xs[k - 3] : 0.0); }
-            const double zu = z[t] / Eo[t];
+            const double zu = z[ri] / Eo[ri];
             r1 = fmax(r1, fabs(ax - zu)); nAx = fmax(nAx, fabs(ax)); nz = fmax(nz, fabs(zu));
-            r1s = fmax(r1s, fabs(Eo[t] * ax - z[t])); nAxs = fmax(nAxs, fabs(Eo[t] * ax)); nzs = fmax(nzs, fabs(z[t]));
-            wbuf[row] = Eo[t] * y[t];
+            r1s = fmax(r1s, fabs(Eo[ri] * ax - z[ri])); nAxs = fmax(nAxs, fabs(Eo[ri] * ax)); nzs = fmax(nzs, fabs(z[ri]));
+            wbuf[row] = Eo[ri] * y[ri];
           }
         }
         __syncthreads();
@@ -844,12 +859,12 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
           // OSQP primal-infeasibility certificate on dy (auxil.c:is_primal_infeasible)
           double ndy = 0.0, supp = 0.0;
 #pragma unroll
-          for (int t = 0; t < MAXT; ++t) {
-            const int row = l + 64 * t;
+          for (int t = 0; t < TM; ++t) {
+            const int row = l + 64 * t, ri = BIG ? row : t;
             if (row < m) {
-              ndy = fmax(ndy, fabs(Eo[t] * dy[t]));
-              supp += hi[t] * fmax(dy[t], 0.0) + lo[t] * fmin(dy[t], 0.0);
-              wbuf[row] = Eo[t] * dy[t];
+              ndy = fmax(ndy, fabs(Eo[ri] * dy[ri]));
+              supp += hi[ri] * fmax(dy[ri], 0.0) + lo[ri] * fmin(dy[ri], 0.0);
+              wbuf[row] = Eo[ri] * dy[ri];
             }
           }
           ndy = wave_max(ndy);
@@ -894,12 +909,14 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
   }
 }
 
-static size_t mpc_lds_doubles(int N, bool setup_only) {      // mirrors the Bump allocations at the top of k_mpc
+static size_t mpc_lds_doubles(int N, bool setup_only, bool big = false) {      // mirrors the Bump allocations at the top of k_mpc
   const int n = 3 * N, np = n * (n + 1) / 2, m = 12 * N;
   auto ev = [](int v) { return (size_t)((v + 1) & ~1); };
-  const int r0 = (!setup_only && np > 1100) ? np : 1100;
+  const int r0 = (!setup_only && !big && np > 1100) ? np : 1100;
   const size_t common = ev(r0) + ev(N * 27) + ev(81) * 3 + ev(54) + ev(9) * 2;
-  return setup_only ? common : common + ev(n) + ev(m) + ev(9 * N) + 4 * ev(n) + 2 * ev(n) + ev(9 * N) + ev(n + 3);
+  const size_t vecs = ev(n) + ev(m) + ev(9 * N);             // q | weighted error | pred (build-only launches up to MAXN overlay them on r0)
+  if (setup_only) return big ? common + vecs : common;
+  return common + vecs + 4 * ev(n) + 2 * ev(n) + ev(9 * N) + ev(n + 3);
 }
 
 }  // namespace f16
@@ -991,6 +1008,12 @@ static int mpc_lds_opt_in() {
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void *)k_mpc<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(mpc_lds_doubles(MAXN, true) * sizeof(double)));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void *)k_mpc<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(mpc_lds_doubles(BIG_MAXN, false, true) * sizeof(double)));
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void *)k_mpc<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(mpc_lds_doubles(BIG_MAXN, true, true) * sizeof(double)));
   if (int rc = hip_check(e, "hipFuncSetAttribute(k_mpc)")) return rc;
   ready[dev] = true;
   return F16_OK;
@@ -999,7 +1022,9 @@ static int mpc_lds_opt_in() {
 // Per-call QP workspace, stream-ordered (see f16_ctx.h): [B][np] P | [B][ext] extras | [B][tiles] A'WA of the fast solver.
 static int mpc_work_alloc(f16_ctx *ctx, MpcArgs &a, bool with_ext, void *stream, void **block, bool with_gram = false) {
   const size_t np = (size_t)(3 * a.N) * (3 * a.N + 1) / 2;
-  const size_t need = (np + (with_ext ? mpc_ext_doubles(a.N) : 0) + (with_gram ? MPC_TILE_DOUBLES : 0)) * (size_t)a.B * sizeof(double);
+  const bool big = a.N > MAXN;
+  const size_t need = (np + (with_ext ? mpc_ext_doubles(a.N) : 0) + (with_gram ? MPC_TILE_DOUBLES : 0) + (big ? mpc_big_doubles(a.N) : 0)) *
+                      (size_t)a.B * sizeof(double);
   *block = nullptr;
   // Not under stream capture: replays of a graph holding these stream-ordered allocation / free nodes were measured to
   // return wrong results intermittently on ROCm 7.2 (the workspace is not stable across replays).  A prepared plan owns its
@@ -1011,6 +1036,7 @@ static int mpc_work_alloc(f16_ctx *ctx, MpcArgs &a, bool with_ext, void *stream,
   a.Ppk = (double *)*block;
   a.ext = with_ext ? a.Ppk + np * (size_t)a.B : nullptr;
   a.gramws = with_gram ? a.Ppk + (np + mpc_ext_doubles(a.N)) * (size_t)a.B : nullptr;
+  a.bigws = big ? a.Ppk + (np + (with_ext ? mpc_ext_doubles(a.N) : 0) + (with_gram ? MPC_TILE_DOUBLES : 0)) * (size_t)a.B : nullptr;
   return F16_OK;
 }
 static int mpc_work_free(void *block, void *stream) {
@@ -1037,18 +1063,21 @@ static f16_ctx::sched_entry *mpc_sched_entry(f16_ctx *ctx, void *stream, long B)
 // the caller frees it); 2: build, then the register-resident 512-thread solver (N <= 32).
 static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream, int mode, void **keep = nullptr) {
   const int N = a.N;
-  if (N < 1 || N > MAXN) return set_error(F16_EINVAL, "horizon must be 1..40 for the LDS-resident QP solver");
-  const size_t lds = mpc_lds_doubles(N, mode != 0) * sizeof(double);
+  const bool big = N > MAXN;
+  if (N < 1 || N > BIG_MAXN || (big && mode == 2)) return set_error(F16_EINVAL, "horizon must be 1..150 (plans: 1..32)");
+  const size_t lds = mpc_lds_doubles(N, mode != 0, big) * sizeof(double);
   if (lds > 160 * 1024) return set_error(F16_EINVAL, "horizon too large for LDS");
   if (int rc = mpc_lds_opt_in()) return rc;
   void *block = nullptr;
   if (int rc = mpc_work_alloc(ctx, a, mode != 0, stream, &block, mode == 2 && a.s.adaptive_rho)) return rc;
   int rc = F16_OK;
   if (mode == 0) {
-    hipLaunchKernelGGL(k_mpc<false>, dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
+    if (big) hipLaunchKernelGGL((k_mpc<false, true>), dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_mpc<false>, dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
     rc = hip_check(hipGetLastError(), "f16_mpc_batch launch");
   } else {
-    hipLaunchKernelGGL(k_mpc<true>, dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
+    if (big) hipLaunchKernelGGL((k_mpc<true, true>), dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_mpc<true>, dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
     rc = hip_check(hipGetLastError(), "f16_mpc_batch setup launch");
 #ifdef F16_EXP_STAMPB
     mode = 1;
@@ -1195,7 +1224,7 @@ extern "C" int f16_mpc_qp_debug(f16_ctx *ctx, const double *Ad, const double *Bd
   if (!ctx || !Ad || !Bd || !Cd || !x || !dem || b < 0 || b >= ld || !h_P || !h_q || !h_A || !h_l || !h_u)
     return set_error(F16_EINVAL, "bad argument to f16_mpc_qp_debug");
   const int N = hzn, n = 3 * N, rows = 15 * N;
-  if (N < 1 || N > MAXN) return set_error(F16_EINVAL, "horizon must be 1..40");
+  if (N < 1 || N > BIG_MAXN) return set_error(F16_EINVAL, "horizon must be 1..150");
   const size_t np = (size_t)n * (n + 1) / 2;
   const size_t ndbg = mpc_ext_doubles(N);
   double *d_u = nullptr;

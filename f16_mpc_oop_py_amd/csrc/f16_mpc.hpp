@@ -24,6 +24,8 @@ __host__ __device__ inline double osqp_limit_scaling(double v) {
 static __constant__ double XLB9[9] = {-1e30, -1e30, -20., -30., -300., -100., -50., -1e30, 0.};   // all nine MPC state rows
 constexpr int MAXN = 40;                         // horizon limit of the LDS-resident solver
 constexpr int MAXT = (12 * MAXN + 63) / 64;      // constraint rows per lane
+constexpr int BIG_MAXN = 150;                    // horizon limit of the slow path (row values and KKT inverse in HBM): the
+                                                 // reference's own sweep range, env.py:426-436
 static __constant__ int SROW[6] = {2, 3, 4, 5, 6, 8};   // MPC states with finite bounds: alpha,beta,p,q,r,lf2 (parameters.py:59-95,135)
 static __constant__ double SLB[6] = {-20., -30., -300., -100., -50., 0.};
 static __constant__ double SUB[6] = {90., 30., 300., 100., 50., 25.};
@@ -37,6 +39,7 @@ struct MpcArgs {
   double *Ppk;                // workspace [B][np] packed P (A'A is never stored: the solvers form the weighted Gram themselves)
   double *ext;                // workspace [B][mpc_ext_doubles(N)]: q | G | pred | A | Q | Qbar | rho, ok | scaling (setup kernel -> solver / debug)
   double *tiles;              // prepared plans without equilibration: [B][MPC_TILE_DOUBLES] the re-laid KKT inverse
+  double *bigws;              // horizons beyond MAXN: [B][mpc_big_doubles(N)] seven per-row vectors | packed KKT inverse
   double *gramws;             // [B][MPC_TILE_DOUBLES] A'WA as matrix-core tiles, written by a solve's first factorisation and
                               // re-read by its rho updates (the Gram product does not depend on rho); may be null (recomputed)
   int mode;                   // 0 one-shot; 1 prepare (build + factor, keep everything, no iterations); 2 solve from a plan
@@ -54,6 +57,10 @@ struct MpcArgs {
 // per-aircraft extras written by the setup kernel: q[n] | G[27N] | pred[9N] | A[81] Q[81] Qbar[81] | rho, ok
 __host__ __device__ inline size_t mpc_ext_doubles(int N) { return (size_t)3 * N + 27 * N + 9 * N + 243 + 2; }
 __host__ __device__ inline size_t mpc_ext_model(int N) { return (size_t)3 * N + 27 * N + 9 * N; }      // offset of A | Q | Qbar | rho
+__host__ __device__ inline size_t mpc_big_doubles(int N) {      // (see k_mpc<false, true>)
+  const size_t rows = (size_t)64 * ((12 * N + 63) / 64), n = (size_t)3 * N;
+  return 7 * rows + n * (n + 1) / 2;
+}
 constexpr int MPC_WARM_DOUBLES = 3 * 512;
 constexpr int MPC_TILE_DOUBLES = 6 * 6 * 4 * 64;   // six tile rows x six tiles x four accumulator registers x 64 lanes
 

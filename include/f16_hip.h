@@ -143,6 +143,8 @@ int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double
  * equilibration and are then left out of the iteration (OSQP carries them with rho_min = 1e-6; they never bind).
  * Opt-in alternative (the builder's rule, faster on this family of QPs): scaling = 0, rho = 0 -> no equilibration and
  * the start value rho = 2 sqrt(tr P / tr A'A); scaling = 0, rho > 0 -> no equilibration, fixed start value.
+ * Horizons: 1 <= hzn <= 150.  hzn <= 32 runs the register-resident solver, hzn <= 40 the LDS-resident one, larger horizons
+ * (the reference's own sweep goes to 150, env.py:426-436) a slow path of the same algorithm with its operands in HBM.
  * u_seq (may be NULL) gets the full [3*hzn][ld] sequence, info (may be NULL) gets [4][ld] = iterations, r_prim, r_dual
  * (unscaled), rho.
  * Nothing the results depend on is retained between calls: the QP workspace is allocated and freed per call, stream-ordered

@@ -216,8 +216,8 @@ def test_mpc_horizon_limits_and_closed_loop_smoke():
     env.build_ssr()
     from f16_mpc_oop_py_amd import lib
     with pytest.raises(lib.F16HipError):
-        env._calc_MPC_action(0, 0, 0, 41)
-    for N in (1, 2, 10, 40):
+        env._calc_MPC_action(0, 0, 0, 151)
+    for N in (1, 2, 10, 40, 41):
         u = env._calc_MPC_action(0, 0, 0, N)
         assert torch.isfinite(u).all()
     # test_env.py:480-495 closed-loop pattern: cmd = MPC(...,10); u.values[1:] = cmd; step(u.values)
@@ -463,7 +463,7 @@ def test_every_horizon_instantiation_vs_same_algorithm_oracle(generic, mode):
                     assert np.abs(info["u_seq"][b].cpu().numpy() - ref["x"]).max() < 1e-6, (N, b)
     from f16_mpc_oop_py_amd import lib
     with pytest.raises(lib.F16HipError):
-        env._calc_MPC_action(0, 0, 0, 41)
+        env._calc_MPC_action(0, 0, 0, 151)
     with pytest.raises(lib.F16HipError):
         env._calc_MPC_action(0, 0, 0, 0)
 
@@ -619,3 +619,34 @@ def test_plan_solves_replay_from_a_hip_graph_and_one_shot_calls_refuse_capture()
             env._calc_MPC_action(0, 0, 0, 30)
     torch.cuda.synchronize()
     assert torch.equal(env._calc_MPC_action(0, 0, 0, 30), u_eager)       # the context is still usable afterwards
+
+
+@pytest.mark.parametrize("mode", ["osqp", "builder"])
+def test_horizons_beyond_the_on_chip_solvers_vs_same_algorithm_oracle(mode):
+    """Horizons 41..150 (the reference sweeps N = 1..150, env.py:426-436) run through the slow path of the generic
+    solver (per-row values and the packed KKT inverse in the per-aircraft HBM workspace): the QP it builds equals the
+    restated setup_OSQP, and the solve follows the CPU twin iterate for iterate (same iteration count, u_seq to 1e-8)."""
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(3, seed=21)
+    env = make_env(x0, u0, xcg=0.35)
+    env.build_ssr()
+    Ad, Bd, Cd = _model_np(env)
+    dem = (0.02, -0.01, 0.01)
+    for N in (41, 57, 150):
+        u, info = env._calc_MPC_action(*dem, N, settings=mode_settings(mode), return_info=True)
+        torch.cuda.synchronize()
+        st = info["status"].cpu().numpy()
+        assert set(np.unique(st)) <= {0, 128} and tuple(info["u_seq"].shape) == (3, 3 * N)
+        b = 1
+        Pd, qd, Ad_, ld_, ud_ = env.setup_OSQP(*dem, N, b=b)
+        P, q, A, l, uu = mo.mpc_qp(x0[b], Ad[b], Bd[b], Cd[b], N, 0.001, *dem)
+        assert np.abs(Pd - P).max() <= 1e-10 * np.abs(P).max() and np.abs(qd.ravel() - q.ravel()).max() <= 1e-10 * np.abs(q).max()
+        assert np.array_equal(Ad_ != 0, A != 0) and np.abs(Ad_ - A).max() <= 1e-12 * np.abs(A).max()
+        fin = np.isfinite(l)
+        assert np.array_equal(np.isfinite(ld_.ravel()), fin) and np.abs(ld_.ravel()[fin] - l[fin]).max() < 1e-9
+        ref = MODES[mode][1](P, q, A, l, uu)
+        assert int(info["iters"][b]) == ref["iters"], N
+        assert bool(ref["infeasible"]) == (st[b] == 128), N
+        if not ref["infeasible"]:
+            assert np.abs(info["u_seq"][b].cpu().numpy() - ref["x"]).max() < 1e-8, N
+            assert np.abs(u[b].cpu().numpy() - ref["x"][:3]).max() < 1e-8
