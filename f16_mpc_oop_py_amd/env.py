@@ -426,3 +426,12 @@ class F16Batch:
         return ucmd.t()
 
     calc_MPC_action = _calc_MPC_action
+
+    def _calc_constr_checking_hzn(self, max_hzn=150, settings=None):
+        """env.py:426-436: the first move of calc_MPC_action(0, 0, 0, N) for every horizon N = 1..max_hzn (the reference
+        fills u[:, N-1] for one aircraft; here [B, 3, max_hzn]).  Horizons beyond 40 take the slow HBM-resident solver."""
+        import torch
+        out = torch.empty((self.B, 3, max_hzn), dtype=torch.float64, device=self.device)
+        for i in range(max_hzn):
+            out[:, :, i] = self._calc_MPC_action(0, 0, 0, i + 1, settings=settings)
+        return out

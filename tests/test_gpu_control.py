@@ -650,3 +650,16 @@ def test_horizons_beyond_the_on_chip_solvers_vs_same_algorithm_oracle(mode):
         if not ref["infeasible"]:
             assert np.abs(info["u_seq"][b].cpu().numpy() - ref["x"]).max() < 1e-8, N
             assert np.abs(u[b].cpu().numpy() - ref["x"][:3]).max() < 1e-8
+
+
+def test_constraint_checking_horizon_sweep_surface():
+    """F16._calc_constr_checking_hzn (env.py:426-436): first moves for N = 1..max_hzn, here for a batch; every column equals
+    the direct call at that horizon (incl. two horizons on the slow path)."""
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(4, seed=9)
+    env = make_env(x0, u0, xcg=0.35)
+    env.build_ssr()
+    sw = env._calc_constr_checking_hzn(max_hzn=42)
+    assert tuple(sw.shape) == (4, 3, 42)
+    for N in (1, 10, 30, 33, 41, 42):
+        assert torch.equal(sw[:, :, N - 1], env._calc_MPC_action(0, 0, 0, N), ), N
