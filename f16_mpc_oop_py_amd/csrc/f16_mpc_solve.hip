@@ -14,13 +14,16 @@
 //     stage 1   t  = CCs' w_s      (3N x 6N, block upper-triangular Toeplitz)      utils.py:163 (A' part)
 //     stage 2   x~ = (P + sigma I + rho A'A)^-1 rhs        (3N x 3N dense)          OSQP linear system
 //     stage 3   z~ = CCs x~        (6N x 3N, block lower-triangular Toeplitz)       utils.py:163 (A part)
-//   * the KKT matrix is inverted ON THE fp64 MATRIX CORES (v_mfma_f64_16x16x4_f64, blocked symmetric sweep, four
-//     pivots per step) with the matrix resident in the MFMA accumulators, and stage 2 multiplies straight out of those
-//     accumulators (24 fp64 per lane on the six tile-row waves) -- the inverse never touches LDS or HBM;
+//   * the kernel is a thin driver over three out-of-line phases that share namespace-scope LDS: ruiz_equilibrate (once),
+//     then kkt_factorise / admm_iterate alternately -- each phase has a register allocation of its own;
+//   * the KKT matrix c P + sigma D^-2 + rho A'WA is assembled (Gram product) and inverted ON THE fp64 MATRIX CORES
+//     (v_mfma_f64_16x16x4_f64, blocked symmetric sweep, four pivots per step, ONE product per tile and step) with the
+//     matrix resident in the MFMA accumulators; the inverse is then re-laid through LDS so that stage 2 is 18 FMAs per
+//     lane on all eight waves -- it never touches HBM;
 //   * stages 1 and 3 are the same block-Toeplitz operator used both ways: lane q of the 16-lane DPP row of horizon
 //     step i holds the two 6x3 blocks G_{2q}, G_{2q+1} (36 fp64), reads 12 / 6 contiguous operand doubles from LDS;
 //   * partial sums of a row are combined inside the DPP row by recursive halving (mirror / half-mirror / quad
-//     exchanges), so an iteration has three workgroup barriers and ~70 KB of LDS traffic (the first version: five
+//     exchanges), so an iteration has three workgroup barriers and ~120 KB of LDS data return (the first version: five
 //     barriers, 410 KB).
 #include <hip/hip_runtime.h>
 #include <math.h>
