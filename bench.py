@@ -209,7 +209,16 @@ def run(args):
         tg = fdist.max_over_ranks(time.perf_counter() - t0, dev)
         out["allgather"] = {"ms": tg * 1e3, "bytes_received_per_gpu": int(full.numel() * 8),
                             "GB/s_per_gpu": full.numel() * 8 / tg / 1e9, "layout": "[T,18,W,B/W] view of the receive buffer",
+                            "algo": "collective (all_gather_into_tensor)",
                             "steps_per_s_including_collation": world * B * T / (elapsed / args.steps + tg)}
+        del full
+        # the same collation as W - 1 direct sends / receives per rank (one peer per xGMI link), for comparison
+        barrier()
+        t0 = time.perf_counter()
+        full = fdist.all_gather_trajectories(traj, layout="ranks", algo="direct")
+        barrier()
+        td = fdist.max_over_ranks(time.perf_counter() - t0, dev)
+        out["allgather"]["direct_p2p"] = {"ms": td * 1e3, "GB/s_per_gpu": full.numel() * 8 / td / 1e9}
         del full
     del traj
     if not args.no_large:

@@ -41,7 +41,7 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
-def all_gather_trajectories(traj_local, total=None, layout="flat", chunk_bytes=1 << 28):
+def all_gather_trajectories(traj_local, total=None, layout="flat", chunk_bytes=1 << 28, algo="collective"):
     """Collate the per-rank trajectory shards traj_local [T,18,Bl] (equal Bl on every rank; global aircraft
     g = rank*Bl + b) on every rank.
 
@@ -51,14 +51,31 @@ def all_gather_trajectories(traj_local, total=None, layout="flat", chunk_bytes=1
         interleaves the ranks at a granularity of Bl doubles, which no all-gather can write directly, so the shard is
         gathered in chunks of time samples (<= chunk_bytes received per chunk) and each chunk is scattered straight
         into its place in the result: peak extra memory is one chunk, not a second copy of the whole trajectory.
-    `total` trims padded aircraft off the end (flat layout only)."""
+    `total` trims padded aircraft off the end (flat layout only).
+    algo="direct" (layout="ranks" only): every rank sends its shard straight to every peer and receives theirs
+        (W - 1 sends + W - 1 receives posted as ONE batch of point-to-point operations) -- the one-peer-per-link pattern
+        SURVEY.md 8(e) describes for the xGMI mesh (7 links per GPU), beside the library's all-gather ("collective").  Same
+        result; `bench.py` times both on a multi-GPU run."""
     W = world_size()
     if W == 1:
         return traj_local if layout == "flat" else traj_local.unsqueeze(2)
     T, K, Bl = traj_local.shape
     src = traj_local.contiguous()
+    if algo not in ("collective", "direct") or (algo == "direct" and layout != "ranks"):
+        raise ValueError("algo must be 'collective' or 'direct' (direct: layout='ranks' only)")
     if layout == "ranks":
         recv = torch.empty((W, T, K, Bl), dtype=src.dtype, device=src.device)
+        if algo == "direct":
+            me = dist.get_rank()
+            recv[me].copy_(src)
+            ops = []
+            for d in range(1, W):                                         # peer order staggered by rank: no hot receiver
+                to, frm = (me + d) % W, (me - d) % W
+                ops.append(dist.P2POp(dist.isend, src, to))
+                ops.append(dist.P2POp(dist.irecv, recv[frm], frm))
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+            return recv.permute(1, 2, 0, 3)
         dist.all_gather_into_tensor(recv.view(-1), src.view(-1))          # flat: valid for RCCL and gloo
         return recv.permute(1, 2, 0, 3)
     if layout != "flat":

@@ -45,6 +45,8 @@ def _worker_body(q):
     view = fdist.all_gather_trajectories(mine, layout="ranks")
     ok = ok and tuple(view.shape) == (T, 18, w, Bt // w) and not view.is_contiguous()
     ok = ok and bool(torch.equal(view.reshape(T, 18, Bt), full))
+    direct = fdist.all_gather_trajectories(mine, layout="ranks", algo="direct")      # W - 1 sends / receives per rank
+    ok = ok and tuple(direct.shape) == (T, 18, w, Bt // w) and bool(torch.equal(direct.reshape(T, 18, Bt), full))
     ok = ok and bool(torch.equal(fdist.all_gather_trajectories(mine, total=Bt - 1), full[..., :Bt - 1]))
     mx = fdist.max_over_ranks(1.0 + r)
     sm = fdist.sum_over_ranks(10.0 * (r + 1))
