@@ -44,6 +44,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-mpc", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the large-batch roofline leg")
     ap.add_argument("--no-config5", action="store_true", help="skip the closed-loop leg")
+    ap.add_argument("--allgather-direct", action="store_true",
+                    help="multi-GPU runs: also time the all-gather as direct point-to-point sends / receives")
     ap.add_argument("--large-batch", type=int, default=262144)
     ap.add_argument("--mpc-hzn", type=int, default=30)
     ap.add_argument("--config5-batch", type=int, default=8192, help="aircraft per GPU in the closed-loop leg")
@@ -212,14 +214,17 @@ def run(args):
                             "algo": "collective (all_gather_into_tensor)",
                             "steps_per_s_including_collation": world * B * T / (elapsed / args.steps + tg)}
         del full
-        # the same collation as W - 1 direct sends / receives per rank (one peer per xGMI link), for comparison
-        barrier()
-        t0 = time.perf_counter()
-        full = fdist.all_gather_trajectories(traj, layout="ranks", algo="direct")
-        barrier()
-        td = fdist.max_over_ranks(time.perf_counter() - t0, dev)
-        out["allgather"]["direct_p2p"] = {"ms": td * 1e3, "GB/s_per_gpu": full.numel() * 8 / td / 1e9}
-        del full
+        if args.allgather_direct:
+            # opt-in (--allgather-direct): the same collation as W - 1 direct sends / receives per rank (one peer per
+            # xGMI link), for comparison; not in the default run (unrehearsed on RCCL hardware: a stall would cost the
+            # scaling run)
+            barrier()
+            t0 = time.perf_counter()
+            full = fdist.all_gather_trajectories(traj, layout="ranks", algo="direct")
+            barrier()
+            td = fdist.max_over_ranks(time.perf_counter() - t0, dev)
+            out["allgather"]["direct_p2p"] = {"ms": td * 1e3, "GB/s_per_gpu": full.numel() * 8 / td / 1e9}
+            del full
     del traj
     if not args.no_large:
         out["roofline_large_batch"] = bench_large(args, dev, rank)
