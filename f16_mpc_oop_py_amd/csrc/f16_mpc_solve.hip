@@ -742,7 +742,10 @@ struct GramSegments<NTT, -1> {
   static __device__ __forceinline__ void run(d4_t (&)[NT], int, int, int, int, int, int, const int (&)[NTT], const int (&)[NTT]) {}
 };
 
-template <int NTT>
+// LOWER: only the tiles on and below the diagonal (J <= tile row) -- the matrix is symmetric, and tile row w then runs ONE
+// segment (its tiles 0..w all start at kk0(w)): 45 x 1, 38 x 2, 30 x 3, 21 x 4, 14 x 5, 6 x 6 products on waves 0..5 at N = 30
+// instead of 154 on wave 0 and 36 on wave 5.  The caller mirrors the result through the Gram workspace.
+template <int NTT, bool LOWER = false>
 __device__ __forceinline__ void gram_tiles(d4_t (&acc)[NT], int N) {
   const int n = 3 * N;
   const int tid = threadIdx.x, lc = tid & 15, lq = (tid & 63) >> 4;
@@ -761,13 +764,24 @@ __device__ __forceinline__ void gram_tiles(d4_t (&acc)[NT], int N) {
     const int colw = 16 * w + lc;
     const int jW = colw < n ? colw / 3 : 1 << 20, offW = (colw - 3 * (colw / 3)) - 27 * (colw / 3);
     const int nk = (6 * N + 3) >> 2;
-    GramSegments<NTT, NTT - 1>::run(acc, (6 * ((16 * w) / 3)) >> 2, nk, lq, N, jW, offW, jT, offT);
+    if (LOWER) {
+      switch (w) {
+        case 0: gram_segment<NTT, 0>(acc, gram_kk0(0), nk, lq, N, jW, offW, jT, offT); break;
+        case 1: if (NTT > 1) gram_segment<NTT, (NTT > 1 ? 1 : 0)>(acc, gram_kk0(1), nk, lq, N, jW, offW, jT, offT); break;
+        case 2: if (NTT > 2) gram_segment<NTT, (NTT > 2 ? 2 : 0)>(acc, gram_kk0(2), nk, lq, N, jW, offW, jT, offT); break;
+        case 3: if (NTT > 3) gram_segment<NTT, (NTT > 3 ? 3 : 0)>(acc, gram_kk0(3), nk, lq, N, jW, offW, jT, offT); break;
+        case 4: if (NTT > 4) gram_segment<NTT, (NTT > 4 ? 4 : 0)>(acc, gram_kk0(4), nk, lq, N, jW, offW, jT, offT); break;
+        default: if (NTT > 5) gram_segment<NTT, (NTT > 5 ? 5 : 0)>(acc, gram_kk0(5), nk, lq, N, jW, offW, jT, offT); break;
+      }
+    } else {
+      GramSegments<NTT, NTT - 1>::run(acc, (6 * ((16 * w) / 3)) >> 2, nk, lq, N, jW, offW, jT, offT);
+    }
 #pragma unroll
     for (int J = 0; J < NTT; ++J)
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
-        if (F16_OWNS(J) && i < n && j < n) {
+        if (F16_OWNS(J) && (!LOWER || J <= w) && i < n && j < n) {
           if (i == j) acc[J][qq] += s_Wcv[i] + s_Wrv[i] + s_Wrv[i + 3];
           else if (i == j + 3) acc[J][qq] -= s_Wrv[i];
           else if (j == i + 3) acc[J][qq] -= s_Wrv[j];
@@ -815,18 +829,31 @@ __device__ __noinline__ bool kkt_factorise(const double *Pg, double *gw, bool ha
 #ifdef F16_EXP_GRAMSTAMP
     FSTAMP(0)
 #endif
-    gram_tiles<NTT>(acc, N);
-#ifdef F16_EXP_GRAMSTAMP
-    FSTAMP(1)
-    if (blockIdx.x == 0 && threadIdx.x == 0) g_f_stamp[6] = (double)(tF[1] - tF[0]);
-#endif
     if (gwl) {
+      // With a Gram workspace (kept for the rho updates anyway): compute the tiles on and below the diagonal only -- balanced
+      // over the waves --, park each tile AND its transpose, then every wave reads its whole tile row back (one L2 round trip).
+      gram_tiles<NTT, true>(acc, N);
 #pragma unroll
       for (int J = 0; J < NTT; ++J)
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq)
-          if (F16_OWNS(J)) gwl[(J * 4 + qq) * 64] = acc[J][qq];
+          if (F16_OWNS(J) && J <= w) {
+            gwl[(J * 4 + qq) * 64] = acc[J][qq];
+            // element (4 qq + lq, lc) of tile (w, J) = element (lc, 4 qq + lq) of tile (J, w): register lc / 4 of lane 16 (lc % 4) + 4 qq + lq
+            if (J < w) gw[((size_t)(J * NT + w) * 4 + (lc >> 2)) * 64 + 16 * (lc & 3) + 4 * qq + lq] = acc[J][qq];
+          }
+      __syncthreads();                                      // (workgroup-scope visibility of the global stores)
+#pragma unroll
+      for (int J = 0; J < NTT; ++J)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) acc[J][qq] = F16_OWNS(J) ? gwl[(J * 4 + qq) * 64] : 0.0;
+    } else {
+      gram_tiles<NTT>(acc, N);
     }
+#ifdef F16_EXP_GRAMSTAMP
+    FSTAMP(1)
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_f_stamp[6] = (double)(tF[1] - tF[0]);
+#endif
   }
   FSTAMP(1)
   double rho = *rho_io;
