@@ -17,7 +17,7 @@ for d in dirs:
             name = r["Kernel_Name"]
             if "k_mpc" not in name and "k_lqr" not in name:
                 continue
-            short = "k_mpc_fast" if "k_mpc_fast" in name else ("k_mpc<true> (build)" if ("ILb1" in name or "k_mpc<true>" in name) else name[:40])
+            short = "k_mpc_fast" if "k_mpc_fast" in name else ("k_mpc<true> (build)" if ("ILb1" in name or "k_mpc<true" in name) else name[:40])
             a = acc[(short, r["Counter_Name"])]
             a[0] += float(r["Counter_Value"]); a[1] += 1
 out = os.path.join(REPO, "profiles", f"{tag}_pmc_mpc.csv")
