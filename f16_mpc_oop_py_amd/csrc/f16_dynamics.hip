@@ -409,6 +409,7 @@ __global__ __launch_bounds__(256 * GROUPS) void k_rollout_q(DynArgs a) {
       // first-half results wave 2 keeps in registers for the second half
       double xd[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       double U = 0, V = 0, W = 0, s_t = 0, c_t = 0, s_phi = 0, c_phi = 0, cb = 0, vtc = 0, r1 = 0, r2 = 0, r3 = 0;
+      double fu0 = 0, fv0 = 0, fw0 = 0, mo0 = 0, mo1 = 0, mo2 = 0;
       if (wave == 0) {
         int sa_ = 0;
         double latd;
@@ -420,6 +421,14 @@ __global__ __launch_bounds__(256 * GROUPS) void k_rollout_q(DynArgs a) {
         const double tot = quad_lat((const double *)tab, xa, s, sa_);
         if (s < 3) xt[3 + s][ac] = tot;
         xst[1][ac] = sa_;
+        {   // the rate-product terms of the moment equations (C/nlplant.c:413-436, Heng = 0) do not need the totals: first half
+          const double Jy = 55814.0, Jxz = 982.0, Jz = 63100.0, Jx = 9496.0;
+          const double rden = 1.0 / (9496.0 * 63100.0 - 982.0 * 982.0);
+          const double P = x[9], Q = x[10], R = x[11];
+          mo0 = (Jxz * (Jx - Jy + Jz) * P * Q - (Jz * (Jz - Jy) + Jxz * Jxz) * Q * R) * rden;
+          mo1 = F16_DIVC((Jz - Jx) * P * R - Jxz * (P * P - R * R), Jy);
+          mo2 = ((Jx * (Jx - Jy) + Jxz * Jxz) * P * Q - Jxz * (Jx - Jy + Jz) * Q * R) * rden;
+        }
       } else if (wave == 2) {
         // sin / cos of phi, theta, psi, alpha: one angle per sub-lane, then shared across the quad
         const double ang = s == 0 ? xa[3] : (s == 1 ? xa[4] : (s == 2 ? xa[5] : xa[7]));
@@ -454,6 +463,18 @@ __global__ __launch_bounds__(256 * GROUPS) void k_rollout_q(DynArgs a) {
         xd[5] = (Q * s_phi + R * c_phi) / c_t;
         (void)rct;
 #endif
+        // this wave has slack in the first half and sets the pace of the second: what the force equations and the Euler
+        // update do not need the coefficient totals for is done here (same expressions, :383-387 regrouped)
+        {
+          const double g = 32.17, m = 636.94;
+          fu0 = R * V - Q * W - g * s_t + F16_DIVC(xa[12], m);
+          fv0 = P * W - R * U + g * c_t * s_phi;
+          fw0 = Q * U - P * V + g * c_t * c_phi;
+          if (live) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) x[k] += xd[k] * a.dt;   // env.py:126 (navigation / kinematic states)
+          }
+        }
       } else {
         double vt = xa[6];
         if (vt <= 0.01) vt = 0.01;
@@ -480,11 +501,11 @@ __global__ __launch_bounds__(256 * GROUPS) void k_rollout_q(DynArgs a) {
         if (live) {
           st |= xst[0][ac] | xst[1][ac];
           const double Cx = xt[0][ac], Cz = xt[1][ac], Cy = xt[3][ac] + xt[8][ac], qbar = xt[6][ac];
-          const double g = 32.17, m = 636.94, S = 300.0;
-          const double P = xa[9], Q = xa[10], R = xa[11], Thr = xa[12];
-          const double Udot = R * V - Q * W - g * s_t + F16_DIVC(qbar * S * Cx, m) + F16_DIVC(Thr, m);     // :383-387
-          const double Vdot = P * W - R * U + g * c_t * s_phi + F16_DIVC(qbar * S * Cy, m);
-          const double Wdot = Q * U - P * V + g * c_t * c_phi + F16_DIVC(qbar * S * Cz, m);
+          const double m = 636.94, S = 300.0;
+          const double qsm = F16_DIVC(qbar * S, m);
+          const double Udot = fu0 + qsm * Cx;                                                          // :383-387
+          const double Vdot = fv0 + qsm * Cy;
+          const double Wdot = fw0 + qsm * Cz;
 #ifdef F16_FAST_DIV
           xd[6] = (U * Udot + V * Vdot + W * Wdot) * r1;                                                 // :393-405
           xd[7] = (U * Wdot - W * Udot) * r2;
@@ -495,17 +516,20 @@ __global__ __launch_bounds__(256 * GROUPS) void k_rollout_q(DynArgs a) {
           xd[8] = (Vdot * vtc - V * xd[6]) / (vtc * vtc * cb);
 #endif
 #pragma unroll
-          for (int k = 0; k < 9; ++k) x[k] += xd[k] * a.dt;   // env.py:126
+          for (int k = 6; k < 9; ++k) x[k] += xd[k] * a.dt;   // env.py:126 (x[0..5] were advanced in the first half)
         }
       } else if (wave == 1) {
         if (live) {
-          double xm[18];
           const double Cy = xt[3][ac] + xt[8][ac];
           const double Cn = xt[4][ac] + xt[9][ac] - Cy * (0.35 - a.xcg) * (11.32 / 30.0);   // C/nlplant.c:367
           const double Cl = xt[5][ac] + xt[10][ac];
-          plant_moments(x[9], x[10], x[11], xt[6][ac], Cl, xt[2][ac], Cn, xm);
-#pragma unroll
-          for (int k = 9; k < 12; ++k) x[k] += xm[k] * a.dt;
+          const double Jy = 55814.0, Jxz = 982.0, Jz = 63100.0, Jx = 9496.0, S = 300.0;
+          const double rden = 1.0 / (9496.0 * 63100.0 - 982.0 * 982.0);
+          const double qs = xt[6][ac] * S;
+          const double L_tot = Cl * qs * 30.0, M_tot = xt[2][ac] * qs * 11.32, N_tot = Cn * qs * 30.0;   // :413-415
+          x[9] += (mo0 + (Jz * L_tot + Jxz * N_tot) * rden) * a.dt;                                  // :417-436 + env.py:126
+          x[10] += (mo1 + F16_DIVC(M_tot, Jy)) * a.dt;
+          x[11] += (mo2 + (Jx * N_tot + Jxz * L_tot) * rden) * a.dt;
         }
       }
     }
