@@ -64,6 +64,20 @@ def _compile_and_link(srcs, flags, out, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "..", "build", "obj")
     os.makedirs(objdir, exist_ok=True)
+    # one builder at a time per tree: the ranks of a multi-GPU run may all find a stale library at once
+    import fcntl
+    lock = open(os.path.join(objdir, ".lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        return _compile_and_link_locked(srcs, flags, out, verbose, hipcc, objdir)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _compile_and_link_locked(srcs, flags, out, verbose, hipcc, objdir):
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
     hdr = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)):
         if f.endswith((".h", ".hpp", ".inc")):
