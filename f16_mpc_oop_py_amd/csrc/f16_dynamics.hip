@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256 * GROUPS) void k_rollout_q(DynArgs a) {
     const double ucmd = a.u[s * a.ld + b];                 // wave 3: sub-lane s drives actuator s
     double xact = s == 0 ? x[12] : (s == 1 ? x[13] : (s == 2 ? x[14] : x[15]));   // wave 3: its actuator state
     int st = a.status ? a.status[b] : 0;
-    double *tr = a.traj ? a.traj + b : nullptr;            // next sample (written by wave 3 from the published state)
+    double *tr = a.traj ? a.traj + b : nullptr;            // next sample (written by wave 2 from the published state)
     int until_store = a.traj_every;
 #ifdef F16_EXP_STAMPQ
     unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, t0 = __builtin_amdgcn_s_memtime();
@@ -388,8 +388,9 @@ __global__ __launch_bounds__(256 * GROUPS) void k_rollout_q(DynArgs a) {
       __syncthreads();
       QSTAMP(tA)
       // trajectory sample of the step that just finished: all 18 states straight from the published copy, by the wave
-      // with the most slack in the first half (sub-lane s stores states s, s+4, s+8, ...)
-      if (wave == 3 && tr && t > 0 && --until_store == 0) {
+      // with the most slack in the first half (wave 2 since the actuator wave became the longest; sub-lane s stores states
+      // s, s+4, s+8, ...)
+      if (wave == 2 && tr && t > 0 && --until_store == 0) {
         until_store = a.traj_every;
         if (valid) {
 #pragma unroll
