@@ -50,35 +50,64 @@ def parse_args(argv=None):
     ap.add_argument("--mpc-hzn", type=int, default=30)
     ap.add_argument("--config5-batch", type=int, default=8192, help="aircraft per GPU in the closed-loop leg")
     ap.add_argument("--config5-steps", type=int, default=100)
+    ap.add_argument("--rank-timeout", type=float, default=900.0,
+                    help="self-launched multi-rank runs (--gpus N without a launcher): seconds after which the parent kills "
+                         "the ranks it started and exits non-zero with their stderr tails")
+    ap.add_argument("--dry-run-stall-rank", type=int, default=-1,
+                    help="(test) --dry-run: this rank sleeps instead of entering the first collective")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch path only: rendezvous, shard bookkeeping and the collectives on CPU tensors (no GPU needed)")
     return ap.parse_args(argv)
 
 
 # ------------------------------------------------------------------------------------------------ launcher
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, deadline_s):
     """Parent of a multi-rank run.  Must not import torch / touch the GPU: children are fresh processes (never an exec of
-    a process that has initialised HIP).  Rank 0's stdout is relayed, the other ranks' stdout goes to stderr."""
+    a process that has initialised HIP).  Rank 0's stdout is relayed, the other ranks' stdout goes to stderr; every rank's
+    stderr is relayed AND its tail kept.  The run is bounded in time: when `deadline_s` expires (a rank stalled in its
+    first collective would otherwise hold the caller until an external limit) or a rank dies, the children started here
+    -- exactly those -- are killed, the ranks' stderr tails are printed and the parent exits non-zero."""
+    import collections
+    import threading
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    procs, tails, threads = [], [], []
+    chunks = []
+
+    def pump(stream, tail, sink):
+        for line in iter(stream.readline, b""):
+            tail.append(line)
+            if sink is not None:
+                sink.write(line.decode(errors="replace"))
+                sink.flush()
+
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    import threading
-    chunks = []
-    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
-    reader.start()
-    rc = 0
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        procs.append(p)
+        tails.append(collections.deque(maxlen=40))
+        out_tail = collections.deque(maxlen=100000) if r == 0 else collections.deque(maxlen=40)
+        if r == 0:
+            chunks = out_tail
+        threads.append(threading.Thread(target=pump, args=(p.stdout, out_tail, None if r == 0 else sys.stderr), daemon=True))
+        threads.append(threading.Thread(target=pump, args=(p.stderr, tails[r], sys.stderr), daemon=True))
+    for t in threads:
+        t.start()
+    t_end = time.monotonic() + deadline_s
+    rc, why = 0, None
     while any(p.poll() is None for p in procs):
-        failed = [p for p in procs if p.poll() not in (None, 0)]
+        failed = [i for i, p in enumerate(procs) if p.poll() not in (None, 0)]
         if failed:                              # a rank died: the others would wait in a collective until its timeout
-            rc = failed[0].returncode
+            rc, why = procs[failed[0]].returncode, f"rank {failed[0]} exited with status {procs[failed[0]].returncode}"
             time.sleep(2.0)
+        elif time.monotonic() > t_end:
+            rc, why = 124, f"no result within --rank-timeout {deadline_s:.0f} s (ranks still running: " \
+                           f"{[i for i, p in enumerate(procs) if p.poll() is None]})"
+        if why:
             for p in procs:
                 if p.poll() is None:
                     p.kill()                    # exactly the children started above
@@ -87,16 +116,22 @@ def spawn_ranks(n, argv):
     for p in procs:
         p.wait()
         rc = rc or p.returncode
-    reader.join(10)
-    sys.stdout.write(b"".join(chunks).decode())
+    for t in threads:
+        t.join(5)
+    sys.stdout.write(b"".join(chunks).decode(errors="replace"))
     sys.stdout.flush()
-    return rc
+    if why:
+        sys.stderr.write(f"bench.py launcher: {why}; killed the remaining ranks\n")
+        for r in range(n):
+            sys.stderr.write(f"---- rank {r} stderr tail ----\n" + b"".join(tails[r]).decode(errors="replace"))
+        sys.stderr.flush()
+    return rc or (1 if why else 0)
 
 
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.rank_timeout))
     if args.dry_run:
         return dry_run(args)
     run(args)
@@ -109,6 +144,8 @@ def dry_run(args):
     import torch.distributed as dist
     from f16_mpc_oop_py_amd import dist as fdist
     rank, world, local = fdist.init_from_env()
+    if rank == args.dry_run_stall_rank:          # (test of the launcher's deadline: a rank that never arrives)
+        time.sleep(3600)
     T, Bl = 4, 6
     lo, hi = fdist.shard_bounds(world * Bl, world, rank)
     full = torch.arange(T * 18 * world * Bl, dtype=torch.float64).reshape(T, 18, world * Bl)
@@ -120,12 +157,23 @@ def dry_run(args):
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": fdist.world_size(), "requested_gpus": args.gpus,
                           "allgather_ok": ok, "max_over_ranks": t,
-                          "backend": dist.get_backend() if world > 1 else None}))
+                          "backend": dist.get_backend() if world > 1 else None, "versions": versions()}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if not ok:
         sys.exit(1)
+
+
+def versions():
+    """torch / HIP / RCCL versions of the process group that actually ran (rank 0 prints them with the result)."""
+    import torch
+    v = {"torch": torch.__version__, "hip": getattr(torch.version, "hip", None)}
+    try:
+        v["rccl"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        v["rccl"] = None
+    return v
 
 
 # ------------------------------------------------------------------------------------------------ the bench
@@ -196,6 +244,7 @@ def run(args):
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel_ms": kern_ms, "bytes_per_launch": B * T * BYTES_PER_STORED_STEP,
                      "note": "B=4096: 256 workgroups of 16 aircraft (four lanes per aircraft, four role wavefronts), one per CU; bound by the per-step dependency chain (lookup round trips + fp64 issue), not HBM (DESIGN.md 4)"},
+        "versions": versions(),
         "scaling_note": "1/2/4/8-GPU values exist only where the driver ran this command on an 8-GPU node; the builder's "
                         "box has one GPU (multi-rank paths rehearsed there with F16_DIST_BACKEND=gloo)",
     }

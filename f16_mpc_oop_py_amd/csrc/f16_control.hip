@@ -1113,6 +1113,11 @@ extern "C" int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, c
   if (a.s.check_every < 1 || a.s.rho_every < 1 || !(a.s.rho >= 0) || !(a.s.sigma > 0) || a.s.scaling < 0 || a.s.scaling > 100 ||
       (a.s.scaling > 0 && !(a.s.rho > 0)))
     return set_error(F16_EINVAL, "bad QP settings (the automatic start value of rho, rho = 0, needs scaling = 0)");
+  // the rho estimate is formed from the residuals of a termination test, so it can only run on an iteration that has one
+  // (osqp.c adapts independently of check_termination; here an interval that is not a multiple would silently become the
+  // least common multiple)
+  if (a.s.adaptive_rho && a.s.rho_every % a.s.check_every != 0)
+    return set_error(F16_EINVAL, "bad QP settings: rho_every must be a multiple of check_every");
   // solver selection: the register-resident solver covers N <= 32; a negative max_iter forces the generic kernel (tests)
   const bool generic = hzn > FAST_MAXN || a.s.max_iter < 0;
   if (a.s.max_iter < 0) a.s.max_iter = -a.s.max_iter;
@@ -1154,9 +1159,9 @@ extern "C" int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const doub
   p->warm = nullptr; p->warm_on = false; p->have_prev = false; p->sched = nullptr; p->have_order = false;
   if (s) p->s = *s; else f16_qp_default_settings(&p->s);
   if (p->s.check_every < 1 || p->s.rho_every < 1 || !(p->s.rho >= 0) || !(p->s.sigma > 0) || p->s.max_iter < 1 || p->s.scaling < 0 ||
-      p->s.scaling > 100 || (p->s.scaling > 0 && !(p->s.rho > 0))) {
+      p->s.scaling > 100 || (p->s.scaling > 0 && !(p->s.rho > 0)) || (p->s.adaptive_rho && p->s.rho_every % p->s.check_every != 0)) {
     delete p;
-    return set_error(F16_EINVAL, "bad QP settings");
+    return set_error(F16_EINVAL, "bad QP settings (rho_every must be a multiple of check_every)");
   }
   const size_t np = (size_t)(3 * hzn) * (3 * hzn + 1) / 2;
   const size_t per = np + mpc_ext_doubles(hzn) + 2 * MPC_TILE_DOUBLES;      // P | extras | inverse (scaling = 0) | A'WA

@@ -29,7 +29,10 @@ def init_from_env(backend=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool
         # F16_DIST_BACKEND=gloo: rehearsal of the multi-rank paths on a box with fewer GPUs than ranks
         backend = backend or os.environ.get("F16_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        kw = {}
+        # bounded collectives: a rank that never arrives makes the others fail after F16_DIST_TIMEOUT seconds (default 300)
+        # instead of holding the run until an external limit (torch's defaults are 10 / 30 minutes)
+        import datetime
+        kw = {"timeout": datetime.timedelta(seconds=float(os.environ.get("F16_DIST_TIMEOUT", "300")))}
         if backend == "nccl":
             torch.cuda.set_device(local)
             kw["device_id"] = torch.device("cuda", local)

@@ -56,20 +56,25 @@ def _fingerprint():
     return h.hexdigest()
 
 
-def _compile_and_link(srcs, flags, out, verbose=False):
+def _compile_and_link(srcs, flags, out, verbose=False, stamp=None, fp=None):
     """One object per source, compiled in parallel and cached under build/obj/ by a hash of (source, every header, flags);
-    then one link.  A change to one kernel file recompiles that file only."""
-    import hashlib
-    from concurrent.futures import ThreadPoolExecutor
+    then one link.  A change to one kernel file recompiles that file only.  One builder at a time per tree (file lock);
+    the stamp is re-checked after the lock is taken and written inside it, so that the ranks of a multi-GPU run that all
+    find a stale library do not relink in turn."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "..", "build", "obj")
     os.makedirs(objdir, exist_ok=True)
-    # one builder at a time per tree: the ranks of a multi-GPU run may all find a stale library at once
     import fcntl
     lock = open(os.path.join(objdir, ".lock"), "w")
     fcntl.flock(lock, fcntl.LOCK_EX)
     try:
-        return _compile_and_link_locked(srcs, flags, out, verbose, hipcc, objdir)
+        if stamp and fp and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == fp:
+            return                      # another process built it while this one waited for the lock
+        _compile_and_link_locked(srcs, flags, out, verbose, hipcc, objdir)
+        if stamp and fp:
+            with open(stamp + ".tmp", "w") as f:
+                f.write(fp + "\n")
+            os.replace(stamp + ".tmp", stamp)
     finally:
         fcntl.flock(lock, fcntl.LOCK_UN)
         lock.close()
@@ -114,9 +119,7 @@ def build(force=False, verbose=False):
     stamp = SO_PATH + ".stamp"
     if not force and os.path.exists(SO_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == fp:
         return SO_PATH
-    _compile_and_link(srcs, HIPCC_FLAGS + os.environ.get("F16_HIPCC_EXTRA", "").split(), SO_PATH, verbose)
-    with open(stamp, "w") as f:
-        f.write(fp + "\n")
+    _compile_and_link(srcs, HIPCC_FLAGS + os.environ.get("F16_HIPCC_EXTRA", "").split(), SO_PATH, verbose, stamp, fp)
     return SO_PATH
 
 
@@ -130,10 +133,19 @@ def build_strict(force=False):
     if not force and os.path.exists(STRICT_SO_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == h:
         return STRICT_SO_PATH
     flags = [f for f in HIPCC_FLAGS if f not in _NUMERICS] + ["-ffp-contract=off"]
-    _compile_and_link(srcs, flags, STRICT_SO_PATH)
-    with open(stamp, "w") as f:
-        f.write(h + "\n")
+    _compile_and_link(srcs, flags, STRICT_SO_PATH, False, stamp, h)
     return STRICT_SO_PATH
+
+
+def strict_path():
+    """Path of the up-to-date strict library, or an error naming the build command -- for callers that must not compile
+    (GPU test processes: see load())."""
+    import hashlib
+    h = hashlib.sha256(_fingerprint().encode() + b"strict").hexdigest()
+    stamp = STRICT_SO_PATH + ".stamp"
+    if os.path.exists(STRICT_SO_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == h:
+        return STRICT_SO_PATH
+    raise F16HipError(f"{STRICT_SO_PATH} is missing or stale: run `python -c 'import __graft_entry__ as g; g.build()'`")
 
 
 _LIB = None
@@ -146,17 +158,22 @@ def load():
     if _LIB is not None:
         return _LIB
     import torch  # noqa: F401  (must precede CDLL, see docstring)
+    # load() never compiles: it may be called from a process that has already initialised the GPU (bench.run after
+    # torch.cuda.set_device, or anything under `rocprofv3 -- python3 ...`, whose preload is inherited by children), and
+    # the hipcc -> clang -> lld chain would be an exec hop of such a process.  A stale or missing binary is an error that
+    # names the build command; F16_AUTOBUILD=1 opts back in for interactive use, and is ignored under a profiler preload.
     stamp = SO_PATH + ".stamp"
+    build_cmd = "python -c 'import __graft_entry__ as g; g.build()'"
     stale = not os.path.exists(SO_PATH) or not os.path.exists(stamp) or open(stamp).read().strip() != _fingerprint()
     if stale and "F16HIP_SO" not in os.environ:
-        # csrc/ or the build flags changed since the binary was built (or it was never built): rebuild rather than run
-        # tests against an old binary; without a compiler this is an error, never a fallback
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        if not os.path.exists(hipcc):
-            raise F16HipError(f"{SO_PATH} is missing or stale and {hipcc} is not available to rebuild it")
-        build()
+        profiled = bool(os.environ.get("LD_PRELOAD")) or any(k.startswith(("ROCP_", "ROCPROFILER_")) for k in os.environ)
+        if os.environ.get("F16_AUTOBUILD") == "1" and not profiled:
+            build()
+        else:
+            raise F16HipError(f"{SO_PATH} is missing or older than csrc/ (or built with other flags): run `{build_cmd}` "
+                              f"first (load() does not compile; F16_AUTOBUILD=1 opts in outside a profiler)")
     if not os.path.exists(SO_PATH):
-        raise F16HipError(f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        raise F16HipError(f"{SO_PATH} is missing: run `{build_cmd}`")
     L = ctypes.CDLL(SO_PATH)
     vp, d, i, l, u = ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_long, ctypes.c_uint
     L.f16_create.argtypes = [ctypes.POINTER(vp), i]

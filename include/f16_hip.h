@@ -138,7 +138,8 @@ int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double
  * OSQP's published ADMM with Ruiz equilibration (`scaling` passes, D / E / c), rho = 0.1, sigma 1e-6, alpha 1.6,
  * termination on the UNSCALED residuals (eps 1e-3) every `check_every` iterations, rho re-estimated from the SCALED
  * residuals every `rho_every` iterations (OSQP's own interval is wall-clock based; 100 is its no-timer constant
- * ADAPTIVE_RHO_FIXED) and applied when it moves by more than 5x, primal-infeasibility certificate (-> NaN command +
+ * ADAPTIVE_RHO_FIXED; must be a multiple of `check_every`, else F16_EINVAL: the estimate is formed from the residuals of a
+ * termination test) and applied when it moves by more than 5x, primal-infeasibility certificate (-> NaN command +
  * F16_ST_QP_INFEASIBLE, as OSQP returns).  Rows of A with two infinite bounds (phi, theta, lf1) take part in the
  * equilibration and are then left out of the iteration (OSQP carries them with rho_min = 1e-6; they never bind).
  * Opt-in alternative (the builder's rule, faster on this family of QPs): scaling = 0, rho = 0 -> no equilibration and

@@ -23,8 +23,8 @@ def golden(name):
 def oracle():
     """The C restatement (checker).  Built on demand with plain gcc."""
     so = os.path.join(REPO, "oracle", "libf16_oracle.so")
-    if not os.path.exists(so):
-        subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "libf16_oracle.so"])
+    # always through make (incremental): a stale checker binary would silently compare the kernels with old code
+    subprocess.check_call(["make", "-s", "-C", os.path.join(REPO, "oracle"), "libf16_oracle.so"])
     from oracle import mpc_oracle
     return mpc_oracle.COracle(so)
 

@@ -102,6 +102,24 @@ def test_bench_parent_propagates_a_rank_failure():
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
+def test_bench_parent_kills_a_stalled_run_inside_its_deadline():
+    """A rank that never enters the first collective (here: it sleeps) must not hold the caller: the parent kills the
+    children it started when --rank-timeout expires, prints the ranks' stderr tails and exits non-zero."""
+    import subprocess
+    import sys
+    import time
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["F16_DIST_BACKEND"] = "gloo"
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run", "--dry-run-stall-rank", "1",
+                        "--rank-timeout", "20"], env=env, capture_output=True, text=True, timeout=240)
+    dt = time.monotonic() - t0
+    assert r.returncode != 0 and dt < 120, (r.returncode, dt)
+    assert "rank-timeout" in r.stderr and "rank 1 stderr tail" in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 def test_single_process_paths_need_no_group():
     t = torch.zeros(3, 18, 4, dtype=torch.float64)
     assert fdist.all_gather_trajectories(t) is t

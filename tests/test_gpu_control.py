@@ -352,6 +352,29 @@ def test_mpc_full_size_properties():
     assert np.abs(u3 - u[idx]).max() < 2e-3
 
 
+def test_config4_full_size_every_64th_aircraft_vs_oracle_chain(oracle):
+    """BASELINE config 4 at FULL size (B = 4096, N = 30, xcg 0.35, the reference's solver settings) against the checker:
+    every 64th aircraft's first move, iteration count and status word vs the C restatement of the whole chain on the CPU
+    (its own linearisation + ZOH + DARE + dense setup_OSQP + the OSQP twin, env.py:373-424).  The two chains differ at
+    the 1e-9 level in (Ad, Bd) (device libm), so iterates agree to ~1e-7 until a termination test falls the other way;
+    then the answers are one test interval apart, i.e. inside the solver's own tolerance."""
+    from f16_mpc_oop_py_amd.workload import config4_states
+    B, N = 4096, 30
+    x0, u0 = config4_states(B)
+    env = make_env(x0, u0, xcg=0.35)
+    env.build_ssr()
+    u, info = env._calc_MPC_action(0.0, 0.0, 0.0, N, return_info=True)
+    idx = np.arange(0, B, 64)
+    ref = oracle.mpc_batch(x0[idx], N, xcg=0.35, nthreads=8)
+    ug, itg, stg = u.cpu().numpy()[idx], info["iters"].cpu().numpy()[idx].astype(int), info["status"].cpu().numpy()[idx]
+    assert np.array_equal(stg, ref["status"]), (stg, ref["status"])
+    same = itg == ref["iters"]
+    assert same.mean() >= 0.9, (itg, ref["iters"])
+    assert np.abs(itg - ref["iters"]).max() <= 100
+    assert np.abs(ug[same] - ref["u"][same]).max() < 1e-5
+    assert np.abs(ug - ref["u"]).max() < 5e-3
+
+
 @pytest.mark.parametrize("N", [10, 30])
 def test_prepared_plan_is_bit_identical_and_closed_loop(N):
     """f16_mpc_plan_*: the model-only part of calc_MPC_action prepared once (the reference freezes the model,
