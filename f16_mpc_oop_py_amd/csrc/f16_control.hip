@@ -1059,6 +1059,18 @@ static f16_ctx::sched_entry *mpc_sched_entry(f16_ctx *ctx, void *stream, long B)
   return &e;
 }
 
+// The solve behind a build: one wavefront per aircraft where that solver applies (k_mpc_fast then only equilibrates, mode 3),
+// else the 512-lane workgroup per aircraft.  F16_MPC_WAVE=0 keeps the latter everywhere (A/B runs, cross-checks).
+static int mpc_solve_dispatch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
+  if (a.mode == 0 && mpc_wave_enabled(a)) {
+    MpcArgs e = a;
+    e.mode = 3; e.order = nullptr; e.iters_out = nullptr; e.warm = nullptr;
+    if (int rc = mpc_fast_solve_launch(ctx, e, stream)) return rc;
+    return mpc_wave_solve_launch(ctx, a, stream);
+  }
+  return mpc_fast_solve_launch(ctx, a, stream);
+}
+
 // mode 0: generic one-wave kernel (build + ADMM); 1: build only (workspace P, A'A, q|G|pred; *keep receives the block,
 // the caller frees it); 2: build, then the register-resident 512-thread solver (N <= 32).
 static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream, int mode, void **keep = nullptr) {
@@ -1069,7 +1081,9 @@ static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream, int mode, void **k
   if (lds > 160 * 1024) return set_error(F16_EINVAL, "horizon too large for LDS");
   if (int rc = mpc_lds_opt_in()) return rc;
   void *block = nullptr;
-  if (int rc = mpc_work_alloc(ctx, a, mode != 0, stream, &block, mode == 2 && a.s.adaptive_rho)) return rc;
+  // the wavefront solver (f16_mpc_wave.hip: N <= 30, equilibrated solves) keeps its per-aircraft workspace in the Gram block
+  const bool wave_ok = mode == 2 && N <= WAVE_MAXN && a.s.scaling > 0 && a.s.max_iter > 0;
+  if (int rc = mpc_work_alloc(ctx, a, mode != 0, stream, &block, mode == 2 && (a.s.adaptive_rho || wave_ok))) return rc;
   int rc = F16_OK;
   if (mode == 0) {
     if (big) hipLaunchKernelGGL((k_mpc<false, true>), dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
@@ -1089,7 +1103,7 @@ static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream, int mode, void **k
       const char *ev = getenv("F16_MPC_DISPATCH_ORDER");
       f16_ctx::sched_entry *se = (ev && ev[0] == '0') ? nullptr : mpc_sched_entry(ctx, stream, a.B);
       if (se) { a.iters_out = se->buf; a.order = se->valid ? se->buf + a.B : nullptr; }
-      rc = mpc_fast_solve_launch(ctx, a, stream);
+      rc = mpc_solve_dispatch(ctx, a, stream);
       if (!rc && se) {
         rc = mpc_plan_order_launch(se->buf, se->buf + a.B, a.B, a.s.check_every, stream);
         if (!rc) se->valid = 1;
@@ -1197,7 +1211,7 @@ extern "C" int f16_mpc_plan_solve(f16_mpc_plan *p, const double *x, const double
   a.order = p->have_order ? p->sched + p->B : nullptr;
   if (int rc = plan_launch_build(p, a, stream)) return rc;
   if (p->s.scaling > 0) a.mode = 0;                    // nothing cached beyond the model part: full solver prologue
-  if (int rc = mpc_fast_solve_launch(p->ctx, a, stream)) return rc;
+  if (int rc = mpc_solve_dispatch(p->ctx, a, stream)) return rc;
   if (int rc = mpc_plan_order_launch(p->sched, p->sched + p->B, p->B, p->s.check_every, stream)) return rc;
   p->have_order = true;
   p->have_prev = p->warm_on;

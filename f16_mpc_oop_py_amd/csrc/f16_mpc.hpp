@@ -42,7 +42,8 @@ struct MpcArgs {
   double *bigws;              // horizons beyond MAXN: [B][mpc_big_doubles(N)] seven per-row vectors | packed KKT inverse
   double *gramws;             // [B][MPC_TILE_DOUBLES] A'WA as matrix-core tiles, written by a solve's first factorisation and
                               // re-read by its rho updates (the Gram product does not depend on rho); may be null (recomputed)
-  int mode;                   // 0 one-shot; 1 prepare (build + factor, keep everything, no iterations); 2 solve from a plan
+  int mode;                   // 0 one-shot; 1 prepare (build + factor, keep everything, no iterations); 2 solve from a plan;
+                              // 3 equilibration only: D | E | c -> gramws + WAVE_SCAL_OFF (for the wavefront solver)
   double *warm;               // plans with warm start: [B][MPC_WARM_DOUBLES] x, z, y of the previous solve (per lane)
   int warm_load;              // start from them (else from zero, as the reference's fresh OSQP object does)
   const int32_t *order;       // plans: workgroup -> aircraft map (longest solve of the previous call first), or null
@@ -63,6 +64,13 @@ __host__ __device__ inline size_t mpc_big_doubles(int N) {      // (see k_mpc<fa
 }
 constexpr int MPC_WARM_DOUBLES = 3 * 512;
 constexpr int MPC_TILE_DOUBLES = 6 * 6 * 4 * 64;   // six tile rows x six tiles x four accumulator registers x 64 lanes
+
+// f16_mpc_wave.hip: one wavefront per aircraft (N <= 30, equilibrated solves); its per-aircraft workspace is the `gramws`
+// block: A'WA tiles in front, D | E | c of the equilibration (written by k_mpc_fast in mode 3) at WAVE_SCAL_OFF
+constexpr int WAVE_MAXN = 30;
+constexpr int WAVE_SCAL_OFF = 7936;
+bool mpc_wave_enabled(const MpcArgs &a);
+int mpc_wave_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream);
 
 // f16_mpc_solve.hip
 constexpr int FAST_MAXN = 32;

@@ -1178,10 +1178,19 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
   if (blockIdx.x == 0) { if (tid < 48) g_it_stamp[tid] = 0.0; if (tid < 8) g_f_stamp[tid] = 0.0; }
   const unsigned long long tE0 = __builtin_amdgcn_s_memtime();
 #endif
-  if (a.mode == 0 && a.s.scaling > 0) {
+  if ((a.mode == 0 || a.mode == 3) && a.s.scaling > 0) {
     double o3[3];
     ruiz_equilibrate<NTT>(Pg, N, a.s.scaling, qe, o3);
     De = o3[0]; Eo = o3[1]; cs = o3[2];
+  }
+  if (a.mode == 3) {   // equilibration only: D | E of the kept state rows | E command | E rate | c for the wavefront solver
+    double *const sc = a.gramws + (size_t)b * MPC_TILE_DOUBLES + WAVE_SCAL_OFF;
+    if (xown) sc[xe] = De;
+    if (kind == 1) sc[96 + 6 * blk + sub] = Eo;
+    else if (kind == 2) sc[288 + k3] = Eo;
+    else if (kind == 3) sc[384 + k3] = Eo;
+    if (tid == 0) sc[480] = cs;
+    return;
   }
 #ifdef F16_EXP_STAMPM
   if (blockIdx.x == 0 && tid == 0) g_f_stamp[4] = (double)(__builtin_amdgcn_s_memtime() - tE0);

@@ -1,0 +1,866 @@
+// f16_mpc_wave.hip -- ONE WAVEFRONT PER AIRCRAFT: the OSQP solve of the condensed MPC QP (env.py:420-424) for N <= 30, gfx950.
+//
+// Same algorithm, same coordinates and the same arithmetic rules as f16_mpc_solve.hip (x, z, y = yb / E unscaled; linear system
+// (c P + sigma D^-2 + rho A'WA) x~ = sigma D^-2 x - c q + A' W (rho z - y); termination on the unscaled residuals; rho estimate on
+// the scaled ones) -- what changes is the mapping.  There: one 512-lane workgroup per aircraft, 54 FMAs per lane and iteration
+// under ~270 instructions of reductions, loads and three workgroup barriers.  Here: a workgroup IS one wavefront, four of them
+// resident per CU (one per SIMD, 40 KB of LDS each), no barrier anywhere:
+//   * the KKT inverse lives in LDS as a SYMMETRIC block image (15 x 15 blocks of 6 x 6, every unordered pair of block rows once,
+//     34.6 KB): lane (r, s) holds blocks (r, r - (2s+1)) and (r, r - (2s+2)) (mod 15; s = 3: the diagonal block) and uses each
+//     twice -- y_r += B x_c and y_c += B' x_r, the second fetched by its owner with ds_bpermute (tools/wave_tables.py emulates
+//     and checks the layout);
+//   * the two block-Toeplitz operators (utils.py:171-197: CC[i,j] = A^(i-j) B; stage 1 = CCs' w, stage 3 = CCs x~) share 72
+//     register-resident doubles per lane: lane (o, t) of octet o (steps 4o..4o+3) holds the kept rows of G_4t..G_4t+3; partial
+//     sums meet inside the octet by recursive halving on the DPP network (row split free by a per-lane row order of G);
+//   * the KKT matrix is assembled and inverted on the fp64 matrix cores by the SAME blocked symmetric sweep as
+//     f16_mpc_solve.hip (four pivots per step, one v_mfma_f64_16x16x4_f64 per tile and step), but with all 21 lower-triangular
+//     tiles in this one wavefront's accumulators; the pivot panel goes through LDS without a barrier;
+//   * Ruiz equilibration: k_mpc_fast in its scale-only mode (f16_mpc_solve.hip) leaves D, E, c in the workspace.
+// Launch: grid = B workgroups of 64 lanes, __launch_bounds__(64, 1) (512 registers), 40,960 B of static LDS.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdlib.h>
+
+#include "f16_mpc.hpp"
+#include "f16_smallmat.hpp"
+#include "f16_wave_tables.inc"
+
+namespace f16 {
+namespace wave {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+constexpr int WN = WAVE_MAXN;              // 30
+constexpr int NB = 15, NL = 60;            // block rows; lanes that hold blocks
+constexpr int NT = 6;                      // 16 x 16 tiles per side of the padded 96 x 96 tile image
+constexpr int NTILES = NT * (NT + 1) / 2;  // 21 lower-triangular tiles
+constexpr int FN = 16 * NT;                // 96
+
+// ---- LDS map (doubles).  [0, KI_SIZE) is the block image of the KKT inverse during the iterations and scratch of the
+// factorisation before that; the vectors of the iteration sit behind it.
+constexpr int KI_SIZE = 36 * NL * 2;                  // 4320
+constexpr int WS_REC = 12;                             // state-row vectors: per step rows 0..5, then 3,4,5,0,1,2
+constexpr int WS_OFF = KI_SIZE, WS_SIZE = (WN + 7) * WS_REC;           // 444
+constexpr int WC_OFF = WS_OFF + WS_SIZE, WC_SIZE = 92;                 // command rows (also: rhs of the linear system)
+constexpr int WR_OFF = WC_OFF + WC_SIZE, WR_SIZE = 96;                 // rate rows (read up to k + 3)
+constexpr int XT_PAD = 21, XT_OFF = WR_OFF + WR_SIZE, XT_SIZE = XT_PAD + 3 * WN + 5;     // x~ / x behind 7 zero steps
+constexpr int LDS_DOUBLES = 5120;                      // 40,960 B: four wavefront-workgroups per CU
+static_assert(XT_OFF + XT_SIZE <= LDS_DOUBLES, "LDS map");
+// scratch of the factorisation phases inside [0, KI_SIZE)
+constexpr int GL_OFF = 0, GL_SIZE = 27 * (WN + 1) + 1;                 // all nine rows of every G_k + a zero block
+constexpr int WG_OFF = GL_OFF + GL_SIZE, WG_SIZE = 6 * WN + 8;         // Gram weights of the kept state rows (zero padded)
+constexpr int WCV_OFF = WG_OFF + WG_SIZE, WRV_OFF = WCV_OFF + 96;      // Gram weights of command / rate rows (rate: + 4)
+constexpr int PAN_DI = FN * 4, PAN_OK = FN * 4 + 16, PAN_SIZE = FN * 4 + 18;
+constexpr int PAN_OFF = WRV_OFF + 100;
+static_assert(PAN_OFF + 2 * PAN_SIZE <= KI_SIZE, "factorisation scratch");
+static_assert((PAN_OFF & 1) == 0 && (PAN_SIZE & 1) == 0 && (XT_OFF & 1) == 0 && (WS_OFF & 1) == 0 && (WC_OFF & 1) == 0, "16-byte alignment");
+
+// ---- per-aircraft workspace in HBM (the `gramws` block of MpcArgs, MPC_TILE_DOUBLES = 9216 doubles)
+constexpr int GW_TILES = 0;                            // [21][4][64] A'WA as lower-triangular tiles
+constexpr int GW_SCAL = WAVE_SCAL_OFF;                 // D[96] | E state [192] | E command [96] | E rate [96] | c   (k_mpc_fast mode 3)
+static_assert(NTILES * 256 <= WAVE_SCAL_OFF && WAVE_SCAL_OFF + 488 <= MPC_TILE_DOUBLES, "workspace map");
+
+__shared__ __attribute__((aligned(16))) double s_w[LDS_DOUBLES];
+
+__device__ __forceinline__ int tile_idx(int w, int J) { return w * (w + 1) / 2 + J; }
+
+template <int CTRL>
+__device__ __forceinline__ double dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HMIRROR = 0x141;
+__device__ __forceinline__ double bperm(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+#define WAVE_LDS_PHASE() __builtin_amdgcn_sched_barrier(0x7)      /* memory operations stay put, ALU may float */
+// producer lanes -> consumer lanes of the SAME wavefront through LDS: the LDS queue of a wave is in order; this keeps the
+// compiler from moving accesses across and drains the counter
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+
+struct Role {
+  int l, o, t, estar, par, h, b1, b2, istep;   // octet layout: lane (o, t) owns step istep = 4 o + t / 2
+  int r, s, cA, cB;                            // block layout: quad r = block row, s = lane % 4
+  bool act;                                    // istep < N
+};
+__device__ __forceinline__ Role role(int N) {
+  Role R;
+  R.l = threadIdx.x; R.o = R.l >> 3; R.t = R.l & 7;
+  R.b2 = (R.t >> 2) & 1; R.b1 = (R.t >> 1) & 1; R.par = R.t & 1;
+  R.estar = R.t >> 1; R.h = R.par ^ R.b2;
+  R.istep = 4 * R.o + R.estar; R.act = R.istep < N;
+  R.r = R.l >> 2; R.s = R.l & 3;
+  const int rr = R.r < NB ? R.r : NB - 1;
+  R.cA = (rr + NB - (2 * R.s + 1)) % NB;
+  R.cB = R.s < 3 ? (rr + NB - (2 * R.s + 2)) % NB : rr;
+  return R;
+}
+
+// ---- per-lane constants of a solve: the lane's three owned variables (both lanes of a pair hold them), its three state
+// rows (step istep, kept rows 3h..3h+2) and its three command (par = 0) or rate (par = 1) rows of the same step.
+struct LaneConst {
+  double sg[3], cq[3], q[3], cD[3];            // sigma D^-2, c q, q, c D of the owned variables
+  double loA[3], hiA[3], WA[3], loB[3], hiB[3], WB[3];   // bounds and row weight W = E^2
+  int eqA, eqB;                                // bit c: the row carries 1e3 rho (equality row after scaling)
+  double cs, cinv;
+};
+struct SolveState {
+  double x[3], zA[3], yA[3], dyA[3], zB[3], yB[3], dyB[3];
+  double rho, rp, rd;
+  int it, to_check, done, converged, infeasible;
+};
+struct IterSettings { double alpha, eps_abs, eps_rel, eps_prim_inf; int max_iter, check_every, rho_every, adaptive_rho; };
+
+// ----------------------------------------------------------------------------------------------------------------
+// The two block-Toeplitz stages on the lane's 72 register-resident doubles Gd[u][rr'][c] = G_(4t+u)[kept row][c]; row slot
+// rr' < 3 is kept row 3h + rr', rr' >= 3 kept row 3(1-h) + rr' - 3 (h = par ^ b2), so that the first halving step of stage 3
+// is free of selects.  Zero for lags beyond the horizon.
+__device__ __forceinline__ void load_G(double (&Gd)[4][6][3], const double *Gg, const Role &R, int N) {
+  constexpr int SR[6] = {2, 3, 4, 5, 6, 8};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int d = 4 * R.t + u;
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) {
+      const int lo3 = rr % 3;
+      // kept-row index of slot rr for h = 0 / h = 1
+      const int k0 = rr < 3 ? lo3 : 3 + lo3, k1 = rr < 3 ? 3 + lo3 : lo3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double g0 = d < N ? Gg[d * 27 + SR[k0] * 3 + c] : 0.0, g1 = d < N ? Gg[d * 27 + SR[k1] * 3 + c] : 0.0;
+        Gd[u][rr][c] = R.h ? g1 : g0;
+      }
+    }
+  }
+}
+
+// stage 1: (CCs' v)_j, j = 4o + e, from the state-row vector in LDS (record of 12 per step); returns the three totals of step
+// istep in BOTH lanes of the pair (t, t ^ 1).
+__device__ __forceinline__ void stage1(const double (&Gd)[4][6][3], const double *vs, const Role &R, int N, double (&out)[3]) {
+  const int base = 4 * (R.o + R.t), wb = base < N ? base : N;
+  const double2 *wp = reinterpret_cast<const double2 *>(vs + WS_REC * wb + 6 * R.h);
+  double wv[7][6];
+#pragma unroll
+  for (int m = 0; m < 7; ++m) {
+    const double2 a = wp[6 * m], b = wp[6 * m + 1], c = wp[6 * m + 2];
+    wv[m][0] = a.x; wv[m][1] = a.y; wv[m][2] = b.x; wv[m][3] = b.y; wv[m][4] = c.x; wv[m][5] = c.y;
+  }
+  WAVE_LDS_PHASE();
+  double acc[4][3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; u += 2)
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) { s0 = fma(Gd[u][rr][c], wv[e + u][rr], s0); s1 = fma(Gd[u + 1][rr][c], wv[e + u + 1][rr], s1); }
+      acc[e][c] = s0 + s1;
+    }
+  // halving: half-mirror partner keeps the other pair of steps, xor-2 partner the other step of the pair, xor-1 partner shares
+  double k[2][3];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double keep = R.b2 ? acc[2 + m][c] : acc[m][c], send = R.b2 ? acc[m][c] : acc[2 + m][c];
+      k[m][c] = keep + dpp<DPP_HMIRROR>(send);
+    }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const double keep = R.b1 ? k[1][c] : k[0][c], send = R.b1 ? k[0][c] : k[1][c];
+    const double v = keep + dpp<DPP_XOR2>(send);
+    out[c] = v + dpp<DPP_XOR1>(v);
+  }
+}
+
+// stage 3: (CCs v)_i, i = 4o + e, from the zero-padded variable vector in LDS (step s at 3 (s + 7)); returns the lane's three
+// kept rows 3h..3h+2 of step istep.
+__device__ __forceinline__ void stage3(const double (&Gd)[4][6][3], const double *vx, const Role &R, double (&out)[3]) {
+  const int s0 = 4 * (R.o - R.t) - 3, sb = s0 > -7 ? s0 : -7;
+  const double2 *xp = reinterpret_cast<const double2 *>(vx + 3 * (sb + 7));
+  double xv[7][3];
+  {
+    double f[22];
+#pragma unroll
+    for (int m = 0; m < 11; ++m) { const double2 a = xp[m]; f[2 * m] = a.x; f[2 * m + 1] = a.y; }
+#pragma unroll
+    for (int m = 0; m < 7; ++m)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xv[m][c] = f[3 * m + c];
+  }
+  WAVE_LDS_PHASE();
+  double acc[4][6];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) {
+      double s0_ = 0.0, s1_ = 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; u += 2)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { s0_ = fma(Gd[u][rr][c], xv[e - u + 3][c], s0_); s1_ = fma(Gd[u + 1][rr][c], xv[e - u + 2][c], s1_); }
+      acc[e][rr] = s0_ + s1_;
+    }
+  double v1[4][3];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int r3 = 0; r3 < 3; ++r3) v1[e][r3] = acc[e][r3] + dpp<DPP_XOR1>(acc[e][3 + r3]);      // partner's slots 3..5 are this lane's rows
+  double k[2][3];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r3 = 0; r3 < 3; ++r3) {
+      const double keep = R.b2 ? v1[2 + m][r3] : v1[m][r3], send = R.b2 ? v1[m][r3] : v1[2 + m][r3];
+      k[m][r3] = keep + dpp<DPP_HMIRROR>(send);
+    }
+#pragma unroll
+  for (int r3 = 0; r3 < 3; ++r3) {
+    const double keep = R.b1 ? k[1][r3] : k[0][r3], send = R.b1 ? k[0][r3] : k[1][r3];
+    out[r3] = keep + dpp<DPP_XOR2>(send);
+  }
+}
+
+// ---- y = M v for the symmetric block image: M from LDS (KI) or gathered from the packed P in HBM (termination test).
+// v: natural order, 6 r at v[6 r]; all four lanes of quad r receive y[6r..6r+5].
+template <bool FROM_P>
+__device__ __forceinline__ void sym_matvec(const double *Pg, int n, const double *v, const Role &R, double (&y)[6]) {
+  // (FROM_P: the operand sits at an odd double index -- 8-byte loads)
+  double A[6][6], Bk[6][6];
+  const int lb = R.l < NL ? R.l : NL - 1;
+  if (FROM_P) {
+#pragma unroll
+    for (int e = 0; e < 72; ++e) {
+      const unsigned ij = F16_WAVE_PGATH[e * 64 + R.l];
+      const int i = (int)(ij >> 8), j = (int)(ij & 255);
+      const bool in = i < n && j < n;                      // (i >= j)
+      const double pv = Pg[in ? i * (i + 1) / 2 + j : 0];
+      const double val = in ? pv : 0.0;
+      if (e < 36) A[e / 6][e % 6] = val; else Bk[(e - 36) / 6][(e - 36) % 6] = val;
+    }
+  } else {
+    const double2 *ki = reinterpret_cast<const double2 *>(s_w) + lb;
+#pragma unroll
+    for (int m = 0; m < 18; ++m) {
+      const double2 a = ki[m * NL], b = ki[(18 + m) * NL];
+      A[(2 * m) / 6][(2 * m) % 6] = a.x; A[(2 * m + 1) / 6][(2 * m + 1) % 6] = a.y;
+      Bk[(2 * m) / 6][(2 * m) % 6] = b.x; Bk[(2 * m + 1) / 6][(2 * m + 1) % 6] = b.y;
+    }
+  }
+  const int rr = R.r < NB ? R.r : NB - 1;
+  double xr[6], xa[6], xb[6];
+  if (FROM_P) {
+#pragma unroll
+    for (int m = 0; m < 6; ++m) { xr[m] = v[6 * rr + m]; xa[m] = v[6 * R.cA + m]; xb[m] = v[6 * R.cB + m]; }
+  } else {
+    const double2 *pr = reinterpret_cast<const double2 *>(v + 6 * rr), *pa = reinterpret_cast<const double2 *>(v + 6 * R.cA),
+                  *pb = reinterpret_cast<const double2 *>(v + 6 * R.cB);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const double2 a = pr[m], b = pa[m], c = pb[m];
+      xr[2 * m] = a.x; xr[2 * m + 1] = a.y; xa[2 * m] = b.x; xa[2 * m + 1] = b.y; xb[2 * m] = c.x; xb[2 * m + 1] = c.y;
+    }
+  }
+  WAVE_LDS_PHASE();
+  double yd[6], ytA[6], ytB[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { s0 = fma(A[i][j], xa[j], s0); s1 = fma(Bk[i][j], xb[j], s1); }
+    yd[i] = s0 + s1;
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { s0 = fma(A[i][j], xr[i], s0); s1 = fma(Bk[i][j], xr[i], s1); }
+    ytA[j] = s0; ytB[j] = s1;
+  }
+  // the transposed products belong to block rows cA / cB: their quads fetch them (lane (c, s) from lane (c + k, s))
+  const int srcA = 4 * ((rr + 2 * R.s + 1) % NB) + R.s, srcB = 4 * ((rr + 2 * R.s + 2) % NB) + R.s;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const double pa = bperm(ytA[j], srcA), pb = bperm(ytB[j], srcB);
+    double sm = yd[j] + pa + (R.s < 3 ? pb : 0.0);
+    sm += dpp<DPP_XOR1>(sm);
+    sm += dpp<DPP_XOR2>(sm);
+    y[j] = sm;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// A'WA of the kept state rows as lower-triangular matrix-core tiles (the Gram product of f16_mpc_solve.hip: k-step kk covers rows
+// 4kk..4kk+3 of the 6N x 3N block-Toeplitz matrix, gathered from the nine-row G image in LDS; causality skips the k-steps
+// before gram_kk0), one tile row at a time in this wavefront, + the command / rate rows as a diagonal / third-off-diagonal
+// fix-up; parked in the workspace (it does not depend on rho).
+__host__ __device__ constexpr int gram_kk0(int T) { return (6 * ((16 * T) / 3)) >> 2; }
+template <int W>
+__device__ __forceinline__ void gram_row(double *gw, int N, int lc, int lq, int lane) {
+  const int n = 3 * N;
+  const double *Gl = s_w + GL_OFF, *Wg = s_w + WG_OFF, *Wcv = s_w + WCV_OFF, *Wrv = s_w + WRV_OFF;
+  d4_t acc[W + 1];
+#pragma unroll
+  for (int J = 0; J <= W; ++J) acc[J] = d4_t{0.0, 0.0, 0.0, 0.0};
+  int offT[W + 1], jT[W + 1];
+#pragma unroll
+  for (int T = 0; T <= W; ++T) {
+    const int col = 16 * T + lc;
+    jT[T] = col < n ? col / 3 : 1 << 20;
+    offT[T] = (col - 3 * (col / 3)) - 27 * (col / 3);
+  }
+  const int nk = (6 * N + 3) >> 2;
+  for (int kk = gram_kk0(W); kk < nk; ++kk) {
+    const int rw = 4 * kk + lq, i = rw / 6, rr = rw - 6 * i;
+    const int base = 27 * i + 3 * (rr < 5 ? rr + 2 : 8);
+    const double wgt = Wg[rw];                           // 0 beyond row 6N
+    const int ia = base + offT[W];
+    const double ga = Gl[ia < 0 ? 0 : ia];
+    const double a_op = i >= jT[W] ? ga : 0.0;
+#pragma unroll
+    for (int J = 0; J <= W; ++J) {
+      const int ib = base + offT[J];
+      const double gb = Gl[ib < 0 ? 0 : ib];
+      const double b_op = i >= jT[J] ? gb * wgt : 0.0;
+      acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op, acc[J], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int J = 0; J <= W; ++J)
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int i = 16 * W + 4 * qq + lq, j = 16 * J + lc;
+      double v = acc[J][qq];
+      if (i < n && j < n) {
+        if (i == j) v += Wcv[i] + Wrv[i] + Wrv[i + 3];
+        else if (i == j + 3) v -= Wrv[i];
+        else if (j == i + 3) v -= Wrv[j];
+      }
+      gw[(tile_idx(W, J) * 4 + qq) * 64 + lane] = v;
+    }
+}
+__device__ __noinline__ void gram_tiles(double *gw, int N) {
+  const int l = threadIdx.x, lc = l & 15, lq = l >> 4;
+  gram_row<0>(gw, N, lc, lq, l);
+  gram_row<1>(gw, N, lc, lq, l);
+  gram_row<2>(gw, N, lc, lq, l);
+  gram_row<3>(gw, N, lc, lq, l);
+  gram_row<4>(gw, N, lc, lq, l);
+  gram_row<5>(gw, N, lc, lq, l);
+}
+
+// ---- the blocked symmetric sweep (f16_mpc_solve.hip: inverse_step) on all 21 lower-triangular tiles in ONE wavefront.
+__device__ __forceinline__ double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+}
+__device__ __forceinline__ bool inv4_spd(const double (&d)[4][4], double (&o)[4][4]) {
+  const double a = d[0][0], b = d[1][0], c = d[1][1];
+  const double detA = a * c - b * b;
+  const double ia = rcp_nr(detA);
+  const double A00 = c * ia, A10 = -b * ia, A11 = a * ia;
+  const double B00 = d[2][0], B01 = d[2][1], B10 = d[3][0], B11 = d[3][1];
+  const double T00 = B00 * A00 + B01 * A10, T01 = B00 * A10 + B01 * A11;
+  const double T10 = B10 * A00 + B11 * A10, T11 = B10 * A10 + B11 * A11;
+  const double S00 = d[2][2] - (T00 * B00 + T01 * B01);
+  const double S10 = d[3][2] - (T10 * B00 + T11 * B01);
+  const double S11 = d[3][3] - (T10 * B10 + T11 * B11);
+  const double detS = S00 * S11 - S10 * S10;
+  const double is = rcp_nr(detS);
+  const double I00 = S11 * is, I10 = -S10 * is, I11 = S00 * is;
+  const double L00 = -(I00 * T00 + I10 * T10), L01 = -(I00 * T01 + I10 * T11);
+  const double L10 = -(I10 * T00 + I11 * T10), L11 = -(I10 * T01 + I11 * T11);
+  o[2][2] = I00; o[3][2] = o[2][3] = I10; o[3][3] = I11;
+  o[2][0] = o[0][2] = L00; o[2][1] = o[1][2] = L01; o[3][0] = o[0][3] = L10; o[3][1] = o[1][3] = L11;
+  o[0][0] = A00 - (T00 * L00 + T10 * L10);
+  o[1][0] = o[0][1] = A10 - (T01 * L00 + T11 * L10);
+  o[1][1] = A11 - (T01 * L01 + T11 * L11);
+  return a > 0.0 && detA > 0.0 && S00 > 0.0 && detS > 0.0;
+}
+__device__ __forceinline__ double sel4(double v0, double v1, double v2, double v3, int k) {
+  const double lo = (k & 1) ? v1 : v0, hi = (k & 1) ? v3 : v2;
+  return (k & 2) ? hi : lo;
+}
+// pan: C[col][0..3] = M[pivot row][col] (FN x 4) | D^-1 (4 x 4) | ok flag.  Publish pivots 16 Kt + 4 KQ .. + 3 from the tiles.
+template <int Kt, int KQ>
+__device__ __forceinline__ void publish_panel(const d4_t (&acc)[NTILES], double *pan, int lc, int lq, int l) {
+  // the part of the pivot rows left of and inside the diagonal tile: tile row Kt, register KQ
+#pragma unroll
+  for (int J = 0; J <= Kt; ++J) pan[(16 * J + lc) * 4 + lq] = acc[tile_idx(Kt, J)][KQ];
+  // the part right of the diagonal tile = the pivot COLUMNS of the tile rows below (symmetry): lanes whose column is a pivot
+  if ((lc >> 2) == KQ) {
+#pragma unroll
+    for (int w = Kt + 1; w < NT; ++w)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pan[(16 * w + 4 * q + lq) * 4 + (lc & 3)] = acc[tile_idx(w, Kt)][q];
+  }
+  wave_lds_sync();
+  double D[4][4], Di[4][4];
+  const double2 *src = reinterpret_cast<const double2 *>(pan + (16 * Kt + 4 * KQ) * 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double2 u = src[2 * i], v = src[2 * i + 1];
+    D[i][0] = u.x; D[i][1] = u.y; D[i][2] = v.x; D[i][3] = v.y;
+  }
+  const bool good = inv4_spd(D, Di);
+  if (l < 4) {
+    double2 *dst = reinterpret_cast<double2 *>(pan + PAN_DI + 4 * l);
+    dst[0] = make_double2(sel4(Di[0][0], Di[1][0], Di[2][0], Di[3][0], l), sel4(Di[0][1], Di[1][1], Di[2][1], Di[3][1], l));
+    dst[1] = make_double2(sel4(Di[0][2], Di[1][2], Di[2][2], Di[3][2], l), sel4(Di[0][3], Di[1][3], Di[2][3], Di[3][3], l));
+    if (l == 0) pan[PAN_OK] = good ? 1.0 : 0.0;
+  }
+  wave_lds_sync();
+}
+template <int Kt, int KQ>
+__device__ __forceinline__ void sweep_step(d4_t (&acc)[NTILES], const double *cb, int lc, int lq, double ndel, bool &ok) {
+  const bool pl = (lc >> 2) == KQ;                       // this lane's column (within a tile) is a pivot column
+  double2 a0, a1;
+  double a_op[NT], b_op[NT];
+  {
+    const double2 *ra = reinterpret_cast<const double2 *>(cb + PAN_DI + 4 * lq);       // row l/16 of D^-1
+    a0 = ra[0]; a1 = ra[1];
+    const double okf = cb[PAN_OK];
+    const double dpiv = cb[PAN_DI + 4 * lq + (lc & 3)];
+#pragma unroll
+    for (int w = 0; w < NT; ++w) {
+      const double2 *src = reinterpret_cast<const double2 *>(cb + (16 * w + lc) * 4);
+      const double2 c0 = src[0], c1 = src[1];
+      a_op[w] = -(c0.x * a0.x + c0.y * a0.y + c1.x * a1.x + c1.y * a1.y);
+      b_op[w] = cb[(16 * w + lc) * 4 + lq];
+    }
+    ok = ok && okf > 0.5;
+    if (pl) { a_op[Kt] = dpiv; b_op[Kt] = ndel; }
+  }
+  // pivot columns (tile column Kt, tile rows Kt..) and pivot rows (tile row Kt, register KQ) start from zero
+#pragma unroll
+  for (int w = Kt; w < NT; ++w)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[tile_idx(w, Kt)][q] = pl ? 0.0 : acc[tile_idx(w, Kt)][q];
+#pragma unroll
+  for (int J = 0; J <= Kt; ++J) acc[tile_idx(Kt, J)][KQ] = 0.0;
+#pragma unroll
+  for (int w = 0; w < NT; ++w)
+#pragma unroll
+    for (int J = 0; J <= w; ++J)
+      acc[tile_idx(w, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op[w], b_op[J], acc[tile_idx(w, J)], 0, 0, 0);
+}
+template <int Kt>
+__device__ __forceinline__ void sweep_tile_row(d4_t (&acc)[NTILES], double *c0, double *c1, int lc, int lq, int l, double ndel, bool &ok) {
+  // entry: the panel of pivots (Kt, 0) is in c0
+  sweep_step<Kt, 0>(acc, c0, lc, lq, ndel, ok);
+  publish_panel<Kt, 1>(acc, c1, lc, lq, l);
+  sweep_step<Kt, 1>(acc, c1, lc, lq, ndel, ok);
+  publish_panel<Kt, 2>(acc, c0, lc, lq, l);
+  sweep_step<Kt, 2>(acc, c0, lc, lq, ndel, ok);
+  publish_panel<Kt, 3>(acc, c1, lc, lq, l);
+  sweep_step<Kt, 3>(acc, c1, lc, lq, ndel, ok);
+  if (Kt + 1 < NT) publish_panel<(Kt + 1 < NT ? Kt + 1 : 0), 0>(acc, c0, lc, lq, l);
+}
+
+// One KKT factorisation: K = c P + sigma D^-2 + rho A'WA as lower-triangular tiles (identity on the padding), the sweep, and
+// the scatter of the inverse into the symmetric block image in LDS (table KSCAT).  sg2v: sigma D^-2 per variable (LDS).
+__device__ __noinline__ bool factorise(const double *Pg, const double *gw, const double *sg2v, int N, double cs, double rho) {
+  const int n = 3 * N, l = threadIdx.x, lc = l & 15, lq = l >> 4;
+  d4_t acc[NTILES];
+#pragma unroll
+  for (int w = 0; w < NT; ++w)
+#pragma unroll
+    for (int J = 0; J <= w; ++J)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
+        const bool in = i < n && j < n;
+        const int hi_ = i >= j ? i : j, lo_ = i >= j ? j : i;
+        const double pv = Pg[in ? hi_ * (hi_ + 1) / 2 + lo_ : 0];
+        const double gv = gw[(tile_idx(w, J) * 4 + qq) * 64 + l];
+        const double dg = sg2v[i < n ? i : 0];
+        acc[tile_idx(w, J)][qq] = in ? cs * pv + rho * gv + (i == j ? dg : 0.0) : (i == j ? 1.0 : 0.0);
+      }
+  double *c0 = s_w + PAN_OFF, *c1 = s_w + PAN_OFF + PAN_SIZE;
+  bool ok = true;
+  const double ndel = (lq == (lc & 3)) ? -1.0 : 0.0;
+  wave_lds_sync();
+  publish_panel<0, 0>(acc, c0, lc, lq, l);
+  sweep_tile_row<0>(acc, c0, c1, lc, lq, l, ndel, ok);
+  sweep_tile_row<1>(acc, c0, c1, lc, lq, l, ndel, ok);
+  sweep_tile_row<2>(acc, c0, c1, lc, lq, l, ndel, ok);
+  sweep_tile_row<3>(acc, c0, c1, lc, lq, l, ndel, ok);
+  sweep_tile_row<4>(acc, c0, c1, lc, lq, l, ndel, ok);
+  sweep_tile_row<5>(acc, c0, c1, lc, lq, l, ndel, ok);
+  wave_lds_sync();
+  // acc = MINUS the inverse: scatter into the block image (the panels are dead)
+#pragma unroll
+  for (int t = 0; t < NTILES; ++t)
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const unsigned d = F16_WAVE_KSCAT[(t * 4 + qq) * 64 + l];
+      const unsigned d0 = d & 0xFFFFu, d1 = d >> 16;
+      const double v = -acc[t][qq];
+      if (d0 != 0xFFFFu) s_w[d0] = v;
+      if (d1 != 0xFFFFu) s_w[d1] = v;
+    }
+  wave_lds_sync();
+  return __ballot(!ok) == 0;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// The iterations between two factorisations (f16_mpc_solve.hip: admm_iterate, rule for rule).
+__device__ __noinline__ int iterate(SolveState *st, const LaneConst *lcp, const double *Pg, const double *Gg, int N, IterSettings o) {
+  const Role R = role(N);
+  const int n = 3 * N;
+  const LaneConst C = *lcp;
+  double Gd[4][6][3];
+  load_G(Gd, Gg, R, N);
+  double x[3], zA[3], yA[3], dyA[3], zB[3], yB[3], dyB[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { x[c] = st->x[c]; zA[c] = st->zA[c]; yA[c] = st->yA[c]; dyA[c] = st->dyA[c];
+                                zB[c] = st->zB[c]; yB[c] = st->yB[c]; dyB[c] = st->dyB[c]; }
+  double rho = st->rho, rp = st->rp, rd = st->rd;
+  int it = st->it, to_check = st->to_check;
+  bool done = false, converged = false, infeasible = false, refactor = false;
+  const double rho1 = rho, rhoE = rho * OSQP_RHO_EQ_OVER_RHO_INEQ, rinv1 = 1.0 / rho1, rinvE = 1.0 / rhoE;
+  double roA[3], riA[3], roB[3], riB[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    roA[c] = ((C.eqA >> c) & 1) ? rhoE : rho1; riA[c] = ((C.eqA >> c) & 1) ? rinvE : rinv1;
+    roB[c] = ((C.eqB >> c) & 1) ? rhoE : rho1; riB[c] = ((C.eqB >> c) & 1) ? rinvE : rinv1;
+  }
+  double *const ws = s_w + WS_OFF, *const wc = s_w + WC_OFF, *const wr = s_w + WR_OFF, *const xt = s_w + XT_OFF;
+  double *const rhs = wc;                                   // (the owner of k reads wc[k] before it writes rhs[k])
+  const int kx = 3 * R.istep;                               // first owned variable / command / rate row
+  const bool wrx = R.act && R.par == 0;                     // one lane of the pair writes what both own
+  double *const wsn = ws + WS_REC * R.istep + 3 * R.h, *const wsr = ws + WS_REC * R.istep + 6 + 3 * (1 - R.h);
+  double *const wB = (R.par ? wr : wc) + kx;
+  auto put_rows = [&](const double (&vA)[3], const double (&vB)[3]) {      // row vectors -> LDS (stage-1 operand, adjoint terms)
+    if (R.act) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { wsn[c] = vA[c]; wsr[c] = vA[c]; wB[c] = vB[c]; }
+    }
+  };
+  // zero what carries zero padding, then w = W (rho z - y) of the current point
+  for (int i = R.l; i < WS_SIZE + WC_SIZE + WR_SIZE + XT_SIZE; i += 64) s_w[WS_OFF + i] = 0.0;
+  wave_lds_sync();
+  {
+    double wA[3], wBv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { wA[c] = C.WA[c] * (roA[c] * zA[c] - yA[c]); wBv[c] = C.WB[c] * (roB[c] * zB[c] - yB[c]); }
+    put_rows(wA, wBv);
+  }
+  wave_lds_sync();
+  while (!done && !refactor) {
+    ++it;
+    // ---- A: rhs = sigma D^-2 x - c q + A' W (rho z - y)
+    {
+      double t1[3];
+      stage1(Gd, ws, R, N, t1);
+      double wce[3], wre[3], wrn[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { wce[c] = wc[R.act ? kx + c : 0]; wre[c] = wr[R.act ? kx + c : 0]; wrn[c] = wr[R.act ? kx + c + 3 : 0]; }
+      WAVE_LDS_PHASE();
+      if (wrx) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rhs[kx + c] = C.sg[c] * x[c] - C.cq[c] + (t1[c] + wce[c] + (wre[c] - wrn[c]));
+      }
+    }
+    wave_lds_sync();
+    // ---- B: x~ = K^-1 rhs
+    {
+      double y6[6];
+      sym_matvec<false>(nullptr, n, rhs, R, y6);
+      wave_lds_sync();                                      // (every lane has read rhs / wc)
+      if (R.s == 0 && R.r < NB) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) xt[XT_PAD + 6 * R.r + j] = y6[j];
+      }
+    }
+    wave_lds_sync();
+    // ---- C: z~ = A x~, relaxation, projection, dual update (unscaled z, y = yb / E)
+    {
+      double z3[3], xk[3], xkm[3];
+      stage3(Gd, xt, R, z3);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { xk[c] = xt[XT_PAD + (R.act ? kx + c : 0)]; xkm[c] = xt[XT_PAD + (R.act ? kx + c : 0) - 3]; }
+      WAVE_LDS_PHASE();
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        x[c] = o.alpha * xk[c] + (1 - o.alpha) * x[c];
+        {
+          const double zr = o.alpha * z3[c] + (1 - o.alpha) * zA[c];
+          const double zn = fmin(fmax(fma(yA[c], riA[c], zr), C.loA[c]), C.hiA[c]);
+          dyA[c] = roA[c] * (zr - zn); yA[c] = yA[c] + dyA[c]; zA[c] = zn;
+        }
+        {
+          const double zt = R.par ? xk[c] - xkm[c] : xk[c];
+          const double zr = o.alpha * zt + (1 - o.alpha) * zB[c];
+          const double zn = fmin(fmax(fma(yB[c], riB[c], zr), C.loB[c]), C.hiB[c]);
+          dyB[c] = roB[c] * (zr - zn); yB[c] = yB[c] + dyB[c]; zB[c] = zn;
+        }
+      }
+    }
+    const bool check = --to_check == 0 || it >= o.max_iter;
+    if (to_check == 0) to_check = o.check_every;
+    if (check) {
+      // ---- residuals (OSQP termination test on the UNSCALED problem): A x, P x, A' W y / c
+      wave_lds_sync();
+      {
+        double eA[3], eB[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { eA[c] = C.WA[c] * yA[c]; eB[c] = C.WB[c] * yB[c]; }
+        put_rows(eA, eB);
+        if (wrx) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) xt[XT_PAD + kx + c] = x[c];
+        }
+      }
+      wave_lds_sync();
+      double ax3[3], aty3[3], axB[3];
+      stage3(Gd, xt, R, ax3);
+      stage1(Gd, ws, R, N, aty3);
+      double aty[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int k = R.act ? kx + c : 0;
+        aty[c] = C.cinv * (aty3[c] + wc[k] + (wr[k] - wr[k + 3]));
+        const double xkk = xt[XT_PAD + k], xkm = xt[XT_PAD + k - 3];
+        axB[c] = R.par ? xkk - xkm : xkk;
+      }
+      wave_lds_sync();
+      double px[3];
+      {
+        double p6[6];
+        sym_matvec<true>(Pg, n, xt + XT_PAD, R, p6);
+        wave_lds_sync();
+        if (R.s == 0 && R.r < NB) {
+#pragma unroll
+          for (int j = 0; j < 6; ++j) wc[6 * R.r + j] = p6[j];              // (the command-row buffer is free now)
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) px[c] = wc[R.act ? kx + c : 0];
+      }
+      double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                // r1, |Ax|, |z|, r2, |Px|, |A'y|, |q|, |E dyb|, support(dyb)
+      if (R.act) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          v[0] = fmax(v[0], fmax(fabs(ax3[c] - zA[c]), fabs(axB[c] - zB[c])));
+          v[1] = fmax(v[1], fmax(fabs(ax3[c]), fabs(axB[c])));
+          v[2] = fmax(v[2], fmax(fabs(zA[c]), fabs(zB[c])));
+          v[7] = fmax(v[7], fmax(C.WA[c] * fabs(dyA[c]), C.WB[c] * fabs(dyB[c])));
+          v[8] += C.WA[c] * (C.hiA[c] * fmax(dyA[c], 0.0) + C.loA[c] * fmin(dyA[c], 0.0)) +
+                  C.WB[c] * (C.hiB[c] * fmax(dyB[c], 0.0) + C.loB[c] * fmin(dyB[c], 0.0));
+          v[3] = fmax(v[3], fabs(px[c] + C.q[c] + aty[c]));
+          v[4] = fmax(v[4], fabs(px[c])); v[5] = fmax(v[5], fabs(aty[c])); v[6] = fmax(v[6], fabs(C.q[c]));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = wave_reduce_dpp<false>(v[i]);
+      v[8] = wave_reduce_dpp<true>(v[8]);
+      rp = v[0]; rd = v[3];
+      const double np_ = fmax(v[1], v[2]), nd_ = fmax(fmax(v[4], v[5]), v[6]);
+      if (rp < o.eps_abs + o.eps_rel * np_ && rd < o.eps_abs + o.eps_rel * nd_) { done = true; converged = true; }
+      else {
+        // OSQP primal-infeasibility certificate on dy (auxil.c:is_primal_infeasible)
+        const double ndy = v[7], supp = v[8];
+        if (ndy > o.eps_prim_inf && supp < -o.eps_prim_inf * ndy) {
+          {
+            double eA[3], eB[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { eA[c] = C.WA[c] * dyA[c]; eB[c] = C.WB[c] * dyB[c]; }
+            put_rows(eA, eB);                                 // (the command-row buffer held P x: already consumed)
+          }
+          wave_lds_sync();
+          double t3[3];
+          stage1(Gd, ws, R, N, t3);
+          double wmax = 0.0;
+          if (R.act) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) wmax = fmax(wmax, fabs(t3[c] + wc[kx + c] + (wr[kx + c] - wr[kx + c + 3])));
+          }
+          wmax = wave_reduce_dpp<false>(wmax);
+          if (wmax < o.eps_prim_inf * ndy) { done = true; infeasible = true; }
+        }
+        if (!done) {
+          if (it >= o.max_iter) done = true;
+          else if (o.adaptive_rho && it % o.rho_every == 0) {
+            // auxil.c:compute_rho_estimate on the SCALED residuals
+            double sv[7] = {0, 0, 0, 0, 0, 0, 0};
+            if (R.act) {
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                const double ErA = sqrt(C.WA[c]), ErB = sqrt(C.WB[c]);
+                sv[0] = fmax(sv[0], fmax(ErA * fabs(ax3[c] - zA[c]), ErB * fabs(axB[c] - zB[c])));
+                sv[1] = fmax(sv[1], fmax(ErA * fabs(ax3[c]), ErB * fabs(axB[c])));
+                sv[2] = fmax(sv[2], fmax(ErA * fabs(zA[c]), ErB * fabs(zB[c])));
+                sv[3] = fmax(sv[3], C.cD[c] * fabs(px[c] + C.q[c] + aty[c]));
+                sv[4] = fmax(sv[4], C.cD[c] * fabs(px[c])); sv[5] = fmax(sv[5], C.cD[c] * fabs(aty[c]));
+                sv[6] = fmax(sv[6], C.cD[c] * fabs(C.q[c]));
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) sv[i] = wave_reduce_dpp<false>(sv[i]);
+            const double pr = sv[0] / (fmax(sv[2], sv[1]) + 1e-10), dr = sv[3] / (fmax(fmax(sv[6], sv[5]), sv[4]) + 1e-10);
+            const double nw = fmin(fmax(rho * sqrt(pr / (dr + 1e-10)), OSQP_RHO_MIN), OSQP_RHO_MAX);
+            if (nw > OSQP_ADAPTIVE_RHO_TOLERANCE * rho || nw < rho / OSQP_ADAPTIVE_RHO_TOLERANCE) { rho = nw; refactor = true; }
+          }
+        }
+      }
+      wave_lds_sync();
+    }
+    // w = W (rho z - y) for the next iteration (after a rho update the next call rewrites it with the new rho)
+    {
+      double wA[3], wBv[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { wA[c] = C.WA[c] * (roA[c] * zA[c] - yA[c]); wBv[c] = C.WB[c] * (roB[c] * zB[c] - yB[c]); }
+      put_rows(wA, wBv);
+    }
+    wave_lds_sync();
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { st->x[c] = x[c]; st->zA[c] = zA[c]; st->yA[c] = yA[c]; st->dyA[c] = dyA[c];
+                                st->zB[c] = zB[c]; st->yB[c] = yB[c]; st->dyB[c] = dyB[c]; }
+  st->rho = rho; st->rp = rp; st->rd = rd; st->it = it; st->to_check = to_check;
+  st->done = done; st->converged = converged; st->infeasible = infeasible;
+  return refactor ? 1 : 0;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// The solve of one aircraft per wavefront-workgroup (grid = B).  D, E, c of the equilibration come from the workspace
+// (k_mpc_fast, scale-only mode), P / q / G_k / pred from the build kernel (k_mpc<true>).
+__global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
+  const int N = a.N, n = 3 * N;
+  const Role R = role(N);
+  const int l = R.l;
+  const long b = a.order ? (long)__builtin_amdgcn_readfirstlane(a.order[blockIdx.x]) : (long)blockIdx.x;
+  double *const exw = a.ext + (size_t)b * mpc_ext_doubles(N);
+  const double *Pg = a.Ppk + (size_t)b * (n * (n + 1) / 2);
+  const double *Gg = exw + n, *pred = exw + n + 27 * N;
+  double *const gw = a.gramws + (size_t)b * MPC_TILE_DOUBLES;
+  const double *scal = gw + GW_SCAL;
+  for (int i = l; i < LDS_DOUBLES; i += 64) s_w[i] = 0.0;
+  wave_lds_sync();
+  for (int i = l; i < 27 * N; i += 64) s_w[GL_OFF + i] = Gg[i];          // (block N stays zero: what rows beyond 6N gather)
+  // ---- lane constants: owned variables, state rows (step istep, kept rows 3h..3h+2), command / rate rows of the same step
+  LaneConst C;
+  const double cs = scal[480];
+  C.cs = cs; C.cinv = 1.0 / cs;
+  C.eqA = 0; C.eqB = 0;
+  const int kx = 3 * R.istep;
+  double *const xt = s_w + XT_OFF;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int k = R.act ? kx + c : 0;
+    const double De = R.act ? scal[k] : 1.0, qe = R.act ? exw[k] : 0.0;
+    C.sg[c] = a.s.sigma / (De * De); C.cq[c] = cs * qe; C.q[c] = qe; C.cD[c] = cs * De;
+    {   // state row: kept index kk = 3h + c (utils.py:129-133; rows with two infinite bounds are not kept)
+      const int kk = 3 * R.h + c;
+      const double Eo = R.act ? scal[96 + 6 * R.istep + kk] : 0.0;
+      const double pm = R.act ? pred[R.istep * 9 + SROW[kk]] : 0.0;
+      const double lo = R.act ? SLB[kk] - pm : 0.0, hi = R.act ? SUB[kk] - pm : 0.0;
+      const bool eq = R.act && Eo * (hi - lo) < OSQP_RHO_TOL;
+      C.loA[c] = lo; C.hiA[c] = hi; C.WA[c] = Eo * Eo; C.eqA |= eq ? (1 << c) : 0;
+      if (R.act) s_w[WG_OFF + 6 * R.istep + kk] = Eo * Eo * (eq ? OSQP_RHO_EQ_OVER_RHO_INEQ : 1.0);
+    }
+    {   // command row (par = 0, utils.py:139-140) or rate row (par = 1, utils.py:148-152) of variable k
+      const double Eo = R.act ? scal[(R.par ? 384 : 288) + k] : 0.0;
+      double lo, hi;
+      if (R.par == 0) { lo = ULB[c]; hi = UUB[c]; }
+      else if (R.istep == 0) {
+        const double act = a.x ? a.x[(13 + c) * a.ld + b] : 0.0;
+        lo = act + RLB[c] * a.dt; hi = act + RUB[c] * a.dt;
+      } else { lo = RLB[c]; hi = RUB[c]; }                 // reference quirk: not scaled by dt (utils.py:151-152)
+      if (!R.act) { lo = 0.0; hi = 0.0; }
+      const bool eq = R.act && Eo * (hi - lo) < OSQP_RHO_TOL;
+      C.loB[c] = lo; C.hiB[c] = hi; C.WB[c] = Eo * Eo; C.eqB |= eq ? (1 << c) : 0;
+      if (R.act) s_w[(R.par ? WRV_OFF : WCV_OFF) + k] = Eo * Eo * (eq ? OSQP_RHO_EQ_OVER_RHO_INEQ : 1.0);
+    }
+  }
+  wave_lds_sync();
+  gram_tiles(gw, N);                                         // A'WA -> workspace (every lane reads back what it wrote itself)
+  SolveState st;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { st.x[c] = 0.0; st.zA[c] = 0.0; st.yA[c] = 0.0; st.dyA[c] = 0.0; st.zB[c] = 0.0; st.yB[c] = 0.0; st.dyB[c] = 0.0; }
+  st.rp = INFINITY; st.rd = INFINITY; st.it = 0; st.to_check = a.s.check_every > 0 ? a.s.check_every : 1;
+  st.done = 0; st.converged = 0; st.infeasible = 0; st.rho = a.s.rho;
+  double *const wm = a.warm ? a.warm + (size_t)b * MPC_WARM_DOUBLES + l : nullptr;      // [15][64]: x, zA, yA, zB, yB (unscaled)
+  if (wm && a.warm_load) {
+    bool fin = true;
+    double t15[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) { t15[k] = wm[k * 64]; fin = fin && isfinite(t15[k]); }
+    if (fin) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        st.x[c] = t15[c]; st.zA[c] = t15[3 + c]; st.zB[c] = t15[9 + c];
+        st.yA[c] = C.WA[c] > 0.0 ? cs * t15[6 + c] / C.WA[c] : 0.0;
+        st.yB[c] = C.WB[c] > 0.0 ? cs * t15[12 + c] / C.WB[c] : 0.0;
+      }
+    }
+  }
+  IterSettings o;
+  o.alpha = a.s.alpha; o.eps_abs = a.s.eps_abs; o.eps_rel = a.s.eps_rel; o.eps_prim_inf = a.s.eps_prim_inf;
+  o.max_iter = a.s.max_iter; o.check_every = a.s.check_every; o.rho_every = a.s.rho_every; o.adaptive_rho = a.s.adaptive_rho;
+  bool ok = true, done = false;
+  while (!done) {
+    if (R.act && R.par == 0) {                               // sigma D^-2 for the KKT diagonal (natural order, behind the pad)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xt[XT_PAD + kx + c] = C.sg[c];
+    }
+    wave_lds_sync();
+    ok = factorise(Pg, gw, xt + XT_PAD, N, cs, st.rho) && ok;
+    if (!ok) break;
+    if (!iterate(&st, &C, Pg, Gg, N, o)) done = true;
+  }
+  const bool converged = st.converged != 0, infeasible = st.infeasible != 0;
+  if (wm) {                                                  // keep the solution for the next warm start
+    const bool good = converged && !infeasible;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      wm[c * 64] = good ? st.x[c] : NAN; wm[(3 + c) * 64] = good ? st.zA[c] : NAN; wm[(9 + c) * 64] = good ? st.zB[c] : NAN;
+      wm[(6 + c) * 64] = good ? C.WA[c] * st.yA[c] / cs : NAN; wm[(12 + c) * 64] = good ? C.WB[c] * st.yB[c] / cs : NAN;
+    }
+  }
+  // res.x[0:3] (env.py:424); OSQP hands back NaN for a problem it certifies infeasible
+  if (R.act && R.par == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (R.istep == 0) a.ucmd[c * a.ld + b] = infeasible ? NAN : st.x[c];
+      if (a.useq) a.useq[(kx + c) * a.ld + b] = infeasible ? NAN : st.x[c];
+    }
+  }
+  if (l == 0) {
+    if (a.iters_out) a.iters_out[b] = st.it;
+    if (a.info) {
+      a.info[0 * a.ld + b] = (double)st.it;
+      a.info[1 * a.ld + b] = st.rp;
+      a.info[2 * a.ld + b] = st.rd;
+      a.info[3 * a.ld + b] = st.rho;
+    }
+    if (a.status && infeasible) a.status[b] |= F16_ST_QP_INFEASIBLE;
+    else if (a.status && (!converged || !ok)) a.status[b] |= F16_ST_QP_MAXITER;
+  }
+}
+
+}  // namespace wave
+
+bool mpc_wave_enabled(const MpcArgs &a) {
+  static const bool off = [] { const char *e = getenv("F16_MPC_WAVE"); return e && e[0] == '0'; }();
+  return !off && a.N >= 1 && a.N <= WAVE_MAXN && a.s.scaling > 0 && a.s.max_iter > 0 && a.gramws != nullptr;
+}
+
+int mpc_wave_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
+  (void)ctx;
+  if (a.N < 1 || a.N > WAVE_MAXN || !a.gramws) return set_error(F16_EINVAL, "wavefront MPC solver needs 1 <= N <= 30 and a workspace");
+  if (a.B > 0x7fffffffL) return set_error(F16_EINVAL, "batch too large for one launch");
+  hipLaunchKernelGGL(wave::k_mpc_wave, dim3((unsigned)a.B), dim3(64), 0, (hipStream_t)stream, a);
+  return hip_check(hipGetLastError(), "f16_mpc_batch wavefront solve launch");
+}
+
+}  // namespace f16
