@@ -21,6 +21,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "f16_mpc.hpp"
 #include "f16_smallmat.hpp"
 #include "f16_wave_tables.inc"
@@ -103,13 +105,13 @@ __device__ __forceinline__ Role role(int N) {
 // ---- per-lane constants of a solve: the lane's three owned variables (both lanes of a pair hold them), its three state
 // rows (step istep, kept rows 3h..3h+2) and its three command (par = 0) or rate (par = 1) rows of the same step.
 struct LaneConst {
-  double sg[3], cq[3], q[3], cD[3];            // sigma D^-2, c q, q, c D of the owned variables
+  double sg[3], cq[3];                         // sigma D^-2, c q of the owned variables
   double loA[3], hiA[3], WA[3], loB[3], hiB[3], WB[3];   // bounds and row weight W = E^2
   int eqA, eqB;                                // bit c: the row carries 1e3 rho (equality row after scaling)
   double cs, cinv;
 };
 struct SolveState {
-  double x[3], zA[3], yA[3], dyA[3], zB[3], yB[3], dyB[3];
+  double x[3], zA[3], yA[3], zB[3], yB[3];
   double rho, rp, rd;
   int it, to_check, done, converged, infeasible;
 };
@@ -139,29 +141,33 @@ __device__ __forceinline__ void load_G(double (&Gd)[4][6][3], const double *Gg, 
 }
 
 // stage 1: (CCs' v)_j, j = 4o + e, from the state-row vector in LDS (record of 12 per step); returns the three totals of step
-// istep in BOTH lanes of the pair (t, t ^ 1).
+// istep in BOTH lanes of the pair (t, t ^ 1).  The seven operand steps are a sliding window over the lag u: step m + 4 is
+// fetched under the products of lag m (memory operations keep their order, the arithmetic may float).
 __device__ __forceinline__ void stage1(const double (&Gd)[4][6][3], const double *vs, const Role &R, int N, double (&out)[3]) {
   const int base = 4 * (R.o + R.t), wb = base < N ? base : N;
   const double2 *wp = reinterpret_cast<const double2 *>(vs + WS_REC * wb + 6 * R.h);
   double wv[7][6];
-#pragma unroll
-  for (int m = 0; m < 7; ++m) {
+  auto ld = [&](int m) {
     const double2 a = wp[6 * m], b = wp[6 * m + 1], c = wp[6 * m + 2];
     wv[m][0] = a.x; wv[m][1] = a.y; wv[m][2] = b.x; wv[m][3] = b.y; wv[m][4] = c.x; wv[m][5] = c.y;
-  }
-  WAVE_LDS_PHASE();
+  };
   double acc[4][3];
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      double s0 = 0.0, s1 = 0.0;
+    for (int c = 0; c < 3; ++c) acc[e][c] = 0.0;
+  ld(0); ld(1); ld(2); ld(3);
 #pragma unroll
-      for (int u = 0; u < 4; u += 2)
+  for (int u = 0; u < 4; ++u) {
+    WAVE_LDS_PHASE();
+    if (u < 3) ld(4 + u);
 #pragma unroll
-        for (int rr = 0; rr < 6; ++rr) { s0 = fma(Gd[u][rr][c], wv[e + u][rr], s0); s1 = fma(Gd[u + 1][rr][c], wv[e + u + 1][rr], s1); }
-      acc[e][c] = s0 + s1;
-    }
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) acc[e][c] = fma(Gd[u][rr][c], wv[e + u][rr], acc[e][c]);
+  }
   // halving: half-mirror partner keeps the other pair of steps, xor-2 partner the other step of the pair, xor-1 partner shares
   double k[2][3];
 #pragma unroll
@@ -180,33 +186,32 @@ __device__ __forceinline__ void stage1(const double (&Gd)[4][6][3], const double
 }
 
 // stage 3: (CCs v)_i, i = 4o + e, from the zero-padded variable vector in LDS (step s at 3 (s + 7)); returns the lane's three
-// kept rows 3h..3h+2 of step istep.
+// kept rows 3h..3h+2 of step istep.  Lag u needs the operand steps 3 - u .. 6 - u: from u = 3 down, one more pair per lag.
 __device__ __forceinline__ void stage3(const double (&Gd)[4][6][3], const double *vx, const Role &R, double (&out)[3]) {
   const int s0 = 4 * (R.o - R.t) - 3, sb = s0 > -7 ? s0 : -7;
   const double2 *xp = reinterpret_cast<const double2 *>(vx + 3 * (sb + 7));
-  double xv[7][3];
-  {
-    double f[22];
-#pragma unroll
-    for (int m = 0; m < 11; ++m) { const double2 a = xp[m]; f[2 * m] = a.x; f[2 * m + 1] = a.y; }
-#pragma unroll
-    for (int m = 0; m < 7; ++m)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) xv[m][c] = f[3 * m + c];
-  }
-  WAVE_LDS_PHASE();
+  double f[22];                                            // f[3 m + c] = operand step m, component c
+  auto ld = [&](int p) { const double2 a = xp[p]; f[2 * p] = a.x; f[2 * p + 1] = a.y; };
   double acc[4][6];
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int rr = 0; rr < 6; ++rr) {
-      double s0_ = 0.0, s1_ = 0.0;
+    for (int rr = 0; rr < 6; ++rr) acc[e][rr] = 0.0;
+  ld(0); ld(1); ld(2); ld(3); ld(4); ld(5);               // steps 0..3
 #pragma unroll
-      for (int u = 0; u < 4; u += 2)
+  for (int uu = 0; uu < 4; ++uu) {
+    const int u = 3 - uu;
+    WAVE_LDS_PHASE();
+    if (uu == 0) { ld(6); ld(7); }                          // step 4 (needs f up to 14)
+    if (uu == 1) { ld(8); }                                 // step 5 (up to 17)
+    if (uu == 2) { ld(9); ld(10); }                         // step 6 (up to 20)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { s0_ = fma(Gd[u][rr][c], xv[e - u + 3][c], s0_); s1_ = fma(Gd[u + 1][rr][c], xv[e - u + 2][c], s1_); }
-      acc[e][rr] = s0_ + s1_;
-    }
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[e][rr] = fma(Gd[u][rr][c], f[3 * (e - u + 3) + c], acc[e][rr]);
+  }
   double v1[4][3];
 #pragma unroll
   for (int e = 0; e < 4; ++e)
@@ -512,30 +517,38 @@ __device__ __noinline__ bool factorise(const double *Pg, const double *gw, const
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// The iterations between two factorisations (f16_mpc_solve.hip: admm_iterate, rule for rule).
-__device__ __noinline__ int iterate(SolveState *st, const LaneConst *lcp, const double *Pg, const double *Gg, int N, IterSettings o) {
+// The iterations between two factorisations (f16_mpc_solve.hip: admm_iterate, rule for rule).  Loop nest: the inner loop
+// runs the iterations up to the next termination test and holds nothing but what an iteration needs (the test sits in the
+// outer loop, so that its temporaries and its copies of the stage code do not weigh on the register allocation of the hot
+// loop); the last iteration before a test is peeled, because only it must keep the dual step dy (primal-infeasibility
+// certificate).  ANYEQ = false: no row of this aircraft carries the 1e3 rho of an equality row (the common case): rho and its
+// reciprocal are wave-uniform scalars.
+__device__ __forceinline__ double uniform_f64(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+template <bool ANYEQ>
+__device__ __noinline__ int iterate(SolveState *st, const LaneConst *lcp, const double *Pg, const double *Gg, const double *qv,
+                                    const double *Dv, int N, IterSettings o) {
   const Role R = role(N);
   const int n = 3 * N;
   const LaneConst C = *lcp;
   double Gd[4][6][3];
   load_G(Gd, Gg, R, N);
-  double x[3], zA[3], yA[3], dyA[3], zB[3], yB[3], dyB[3];
+  double x[3], zA[3], yA[3], zB[3], yB[3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) { x[c] = st->x[c]; zA[c] = st->zA[c]; yA[c] = st->yA[c]; dyA[c] = st->dyA[c];
-                                zB[c] = st->zB[c]; yB[c] = st->yB[c]; dyB[c] = st->dyB[c]; }
-  double rho = st->rho, rp = st->rp, rd = st->rd;
+  for (int c = 0; c < 3; ++c) { x[c] = st->x[c]; zA[c] = st->zA[c]; yA[c] = st->yA[c]; zB[c] = st->zB[c]; yB[c] = st->yB[c]; }
+  double rho = uniform_f64(st->rho), rp = st->rp, rd = st->rd;
   int it = st->it, to_check = st->to_check;
   bool done = false, converged = false, infeasible = false, refactor = false;
-  const double rho1 = rho, rhoE = rho * OSQP_RHO_EQ_OVER_RHO_INEQ, rinv1 = 1.0 / rho1, rinvE = 1.0 / rhoE;
-  double roA[3], riA[3], roB[3], riB[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    roA[c] = ((C.eqA >> c) & 1) ? rhoE : rho1; riA[c] = ((C.eqA >> c) & 1) ? rinvE : rinv1;
-    roB[c] = ((C.eqB >> c) & 1) ? rhoE : rho1; riB[c] = ((C.eqB >> c) & 1) ? rinvE : rinv1;
-  }
+  const double rho1 = rho, rhoE = rho * OSQP_RHO_EQ_OVER_RHO_INEQ, rinv1 = uniform_f64(1.0 / rho1), rinvE = uniform_f64(1.0 / rhoE);
+  auto roA = [&](int c) { return ANYEQ ? (((C.eqA >> c) & 1) ? rhoE : rho1) : rho1; };
+  auto riA = [&](int c) { return ANYEQ ? (((C.eqA >> c) & 1) ? rinvE : rinv1) : rinv1; };
+  auto roB = [&](int c) { return ANYEQ ? (((C.eqB >> c) & 1) ? rhoE : rho1) : rho1; };
+  auto riB = [&](int c) { return ANYEQ ? (((C.eqB >> c) & 1) ? rinvE : rinv1) : rinv1; };
   double *const ws = s_w + WS_OFF, *const wc = s_w + WC_OFF, *const wr = s_w + WR_OFF, *const xt = s_w + XT_OFF;
   double *const rhs = wc;                                   // (the owner of k reads wc[k] before it writes rhs[k])
   const int kx = 3 * R.istep;                               // first owned variable / command / rate row
+  const int kxa = R.act ? kx : 0;
   const bool wrx = R.act && R.par == 0;                     // one lane of the pair writes what both own
   double *const wsn = ws + WS_REC * R.istep + 3 * R.h, *const wsr = ws + WS_REC * R.istep + 6 + 3 * (1 - R.h);
   double *const wB = (R.par ? wr : wc) + kx;
@@ -545,25 +558,23 @@ __device__ __noinline__ int iterate(SolveState *st, const LaneConst *lcp, const 
       for (int c = 0; c < 3; ++c) { wsn[c] = vA[c]; wsr[c] = vA[c]; wB[c] = vB[c]; }
     }
   };
-  // zero what carries zero padding, then w = W (rho z - y) of the current point
-  for (int i = R.l; i < WS_SIZE + WC_SIZE + WR_SIZE + XT_SIZE; i += 64) s_w[WS_OFF + i] = 0.0;
-  wave_lds_sync();
-  {
+  auto put_w = [&]() {                                      // w = W (rho z - y)
     double wA[3], wBv[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { wA[c] = C.WA[c] * (roA[c] * zA[c] - yA[c]); wBv[c] = C.WB[c] * (roB[c] * zB[c] - yB[c]); }
+    for (int c = 0; c < 3; ++c) { wA[c] = C.WA[c] * (roA(c) * zA[c] - yA[c]); wBv[c] = C.WB[c] * (roB(c) * zB[c] - yB[c]); }
     put_rows(wA, wBv);
-  }
-  wave_lds_sync();
-  while (!done && !refactor) {
-    ++it;
-    // ---- A: rhs = sigma D^-2 x - c q + A' W (rho z - y)
+  };
+  double dyA[3] = {0.0, 0.0, 0.0}, dyB[3] = {0.0, 0.0, 0.0};
+  // ---- one iteration (KEEP: the dual step survives it)
+  auto iteration = [&](auto keep) {
+    constexpr bool KEEP = decltype(keep)::value;
+    // A: rhs = sigma D^-2 x - c q + A' W (rho z - y)
     {
       double t1[3];
       stage1(Gd, ws, R, N, t1);
       double wce[3], wre[3], wrn[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { wce[c] = wc[R.act ? kx + c : 0]; wre[c] = wr[R.act ? kx + c : 0]; wrn[c] = wr[R.act ? kx + c + 3 : 0]; }
+      for (int c = 0; c < 3; ++c) { wce[c] = wc[kxa + c]; wre[c] = wr[kxa + c]; wrn[c] = wr[kxa + c + 3]; }
       WAVE_LDS_PHASE();
       if (wrx) {
 #pragma unroll
@@ -571,7 +582,7 @@ __device__ __noinline__ int iterate(SolveState *st, const LaneConst *lcp, const 
       }
     }
     wave_lds_sync();
-    // ---- B: x~ = K^-1 rhs
+    // B: x~ = K^-1 rhs
     {
       double y6[6];
       sym_matvec<false>(nullptr, n, rhs, R, y6);
@@ -582,32 +593,47 @@ __device__ __noinline__ int iterate(SolveState *st, const LaneConst *lcp, const 
       }
     }
     wave_lds_sync();
-    // ---- C: z~ = A x~, relaxation, projection, dual update (unscaled z, y = yb / E)
+    // C: z~ = A x~, relaxation, projection, dual update (unscaled z, y = yb / E); w of the new point
     {
       double z3[3], xk[3], xkm[3];
       stage3(Gd, xt, R, z3);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { xk[c] = xt[XT_PAD + (R.act ? kx + c : 0)]; xkm[c] = xt[XT_PAD + (R.act ? kx + c : 0) - 3]; }
+      for (int c = 0; c < 3; ++c) { xk[c] = xt[XT_PAD + kxa + c]; xkm[c] = xt[XT_PAD + kxa + c - 3]; }
       WAVE_LDS_PHASE();
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         x[c] = o.alpha * xk[c] + (1 - o.alpha) * x[c];
         {
           const double zr = o.alpha * z3[c] + (1 - o.alpha) * zA[c];
-          const double zn = fmin(fmax(fma(yA[c], riA[c], zr), C.loA[c]), C.hiA[c]);
-          dyA[c] = roA[c] * (zr - zn); yA[c] = yA[c] + dyA[c]; zA[c] = zn;
+          const double zn = fmin(fmax(fma(yA[c], riA(c), zr), C.loA[c]), C.hiA[c]);
+          const double d = roA(c) * (zr - zn);
+          if (KEEP) dyA[c] = d;
+          yA[c] = yA[c] + d; zA[c] = zn;
         }
         {
           const double zt = R.par ? xk[c] - xkm[c] : xk[c];
           const double zr = o.alpha * zt + (1 - o.alpha) * zB[c];
-          const double zn = fmin(fmax(fma(yB[c], riB[c], zr), C.loB[c]), C.hiB[c]);
-          dyB[c] = roB[c] * (zr - zn); yB[c] = yB[c] + dyB[c]; zB[c] = zn;
+          const double zn = fmin(fmax(fma(yB[c], riB(c), zr), C.loB[c]), C.hiB[c]);
+          const double d = roB(c) * (zr - zn);
+          if (KEEP) dyB[c] = d;
+          yB[c] = yB[c] + d; zB[c] = zn;
         }
       }
     }
-    const bool check = --to_check == 0 || it >= o.max_iter;
+    if (!KEEP) { put_w(); wave_lds_sync(); }                // (after a test the outer loop writes w: the buffers carry the test's vectors)
+  };
+  // zero what carries zero padding, then w of the current point
+  for (int i = R.l; i < WS_SIZE + WC_SIZE + WR_SIZE + XT_SIZE; i += 64) s_w[WS_OFF + i] = 0.0;
+  wave_lds_sync();
+  put_w();
+  wave_lds_sync();
+  while (!done && !refactor) {
+    int nrun = o.max_iter - it < to_check ? o.max_iter - it : to_check;       // iterations up to the next test (>= 1)
+    it += nrun; to_check -= nrun;
     if (to_check == 0) to_check = o.check_every;
-    if (check) {
+    for (; nrun > 1; --nrun) iteration(std::false_type{});
+    iteration(std::true_type{});
+    {
       // ---- residuals (OSQP termination test on the UNSCALED problem): A x, P x, A' W y / c
       wave_lds_sync();
       {
@@ -621,13 +647,16 @@ __device__ __noinline__ int iterate(SolveState *st, const LaneConst *lcp, const 
         }
       }
       wave_lds_sync();
+      double qu[3], cD[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { qu[c] = R.act ? qv[kx + c] : 0.0; cD[c] = C.cs * (R.act ? Dv[kx + c] : 1.0); }
       double ax3[3], aty3[3], axB[3];
       stage3(Gd, xt, R, ax3);
       stage1(Gd, ws, R, N, aty3);
       double aty[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const int k = R.act ? kx + c : 0;
+        const int k = kxa + c;
         aty[c] = C.cinv * (aty3[c] + wc[k] + (wr[k] - wr[k + 3]));
         const double xkk = xt[XT_PAD + k], xkm = xt[XT_PAD + k - 3];
         axB[c] = R.par ? xkk - xkm : xkk;
@@ -644,7 +673,7 @@ __device__ __noinline__ int iterate(SolveState *st, const LaneConst *lcp, const 
         }
         wave_lds_sync();
 #pragma unroll
-        for (int c = 0; c < 3; ++c) px[c] = wc[R.act ? kx + c : 0];
+        for (int c = 0; c < 3; ++c) px[c] = wc[kxa + c];
       }
       double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                // r1, |Ax|, |z|, r2, |Px|, |A'y|, |q|, |E dyb|, support(dyb)
       if (R.act) {
@@ -656,8 +685,8 @@ __device__ __noinline__ int iterate(SolveState *st, const LaneConst *lcp, const 
           v[7] = fmax(v[7], fmax(C.WA[c] * fabs(dyA[c]), C.WB[c] * fabs(dyB[c])));
           v[8] += C.WA[c] * (C.hiA[c] * fmax(dyA[c], 0.0) + C.loA[c] * fmin(dyA[c], 0.0)) +
                   C.WB[c] * (C.hiB[c] * fmax(dyB[c], 0.0) + C.loB[c] * fmin(dyB[c], 0.0));
-          v[3] = fmax(v[3], fabs(px[c] + C.q[c] + aty[c]));
-          v[4] = fmax(v[4], fabs(px[c])); v[5] = fmax(v[5], fabs(aty[c])); v[6] = fmax(v[6], fabs(C.q[c]));
+          v[3] = fmax(v[3], fabs(px[c] + qu[c] + aty[c]));
+          v[4] = fmax(v[4], fabs(px[c])); v[5] = fmax(v[5], fabs(aty[c])); v[6] = fmax(v[6], fabs(qu[c]));
         }
       }
 #pragma unroll
@@ -699,9 +728,9 @@ __device__ __noinline__ int iterate(SolveState *st, const LaneConst *lcp, const 
                 sv[0] = fmax(sv[0], fmax(ErA * fabs(ax3[c] - zA[c]), ErB * fabs(axB[c] - zB[c])));
                 sv[1] = fmax(sv[1], fmax(ErA * fabs(ax3[c]), ErB * fabs(axB[c])));
                 sv[2] = fmax(sv[2], fmax(ErA * fabs(zA[c]), ErB * fabs(zB[c])));
-                sv[3] = fmax(sv[3], C.cD[c] * fabs(px[c] + C.q[c] + aty[c]));
-                sv[4] = fmax(sv[4], C.cD[c] * fabs(px[c])); sv[5] = fmax(sv[5], C.cD[c] * fabs(aty[c]));
-                sv[6] = fmax(sv[6], C.cD[c] * fabs(C.q[c]));
+                sv[3] = fmax(sv[3], cD[c] * fabs(px[c] + qu[c] + aty[c]));
+                sv[4] = fmax(sv[4], cD[c] * fabs(px[c])); sv[5] = fmax(sv[5], cD[c] * fabs(aty[c]));
+                sv[6] = fmax(sv[6], cD[c] * fabs(qu[c]));
               }
             }
 #pragma unroll
@@ -713,19 +742,13 @@ __device__ __noinline__ int iterate(SolveState *st, const LaneConst *lcp, const 
         }
       }
       wave_lds_sync();
+      // w of the current point for the next iteration (after a rho update the next call rewrites it with the new rho)
+      put_w();
+      wave_lds_sync();
     }
-    // w = W (rho z - y) for the next iteration (after a rho update the next call rewrites it with the new rho)
-    {
-      double wA[3], wBv[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { wA[c] = C.WA[c] * (roA[c] * zA[c] - yA[c]); wBv[c] = C.WB[c] * (roB[c] * zB[c] - yB[c]); }
-      put_rows(wA, wBv);
-    }
-    wave_lds_sync();
   }
 #pragma unroll
-  for (int c = 0; c < 3; ++c) { st->x[c] = x[c]; st->zA[c] = zA[c]; st->yA[c] = yA[c]; st->dyA[c] = dyA[c];
-                                st->zB[c] = zB[c]; st->yB[c] = yB[c]; st->dyB[c] = dyB[c]; }
+  for (int c = 0; c < 3; ++c) { st->x[c] = x[c]; st->zA[c] = zA[c]; st->yA[c] = yA[c]; st->zB[c] = zB[c]; st->yB[c] = yB[c]; }
   st->rho = rho; st->rp = rp; st->rd = rd; st->it = it; st->to_check = to_check;
   st->done = done; st->converged = converged; st->infeasible = infeasible;
   return refactor ? 1 : 0;
@@ -758,7 +781,7 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
   for (int c = 0; c < 3; ++c) {
     const int k = R.act ? kx + c : 0;
     const double De = R.act ? scal[k] : 1.0, qe = R.act ? exw[k] : 0.0;
-    C.sg[c] = a.s.sigma / (De * De); C.cq[c] = cs * qe; C.q[c] = qe; C.cD[c] = cs * De;
+    C.sg[c] = a.s.sigma / (De * De); C.cq[c] = cs * qe;
     {   // state row: kept index kk = 3h + c (utils.py:129-133; rows with two infinite bounds are not kept)
       const int kk = 3 * R.h + c;
       const double Eo = R.act ? scal[96 + 6 * R.istep + kk] : 0.0;
@@ -786,7 +809,7 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
   gram_tiles(gw, N);                                         // A'WA -> workspace (every lane reads back what it wrote itself)
   SolveState st;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) { st.x[c] = 0.0; st.zA[c] = 0.0; st.yA[c] = 0.0; st.dyA[c] = 0.0; st.zB[c] = 0.0; st.yB[c] = 0.0; st.dyB[c] = 0.0; }
+  for (int c = 0; c < 3; ++c) { st.x[c] = 0.0; st.zA[c] = 0.0; st.yA[c] = 0.0; st.zB[c] = 0.0; st.yB[c] = 0.0; }
   st.rp = INFINITY; st.rd = INFINITY; st.it = 0; st.to_check = a.s.check_every > 0 ? a.s.check_every : 1;
   st.done = 0; st.converged = 0; st.infeasible = 0; st.rho = a.s.rho;
   double *const wm = a.warm ? a.warm + (size_t)b * MPC_WARM_DOUBLES + l : nullptr;      // [15][64]: x, zA, yA, zB, yB (unscaled)
@@ -808,6 +831,7 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
   o.alpha = a.s.alpha; o.eps_abs = a.s.eps_abs; o.eps_rel = a.s.eps_rel; o.eps_prim_inf = a.s.eps_prim_inf;
   o.max_iter = a.s.max_iter; o.check_every = a.s.check_every; o.rho_every = a.s.rho_every; o.adaptive_rho = a.s.adaptive_rho;
   bool ok = true, done = false;
+  const bool anyeq = __ballot((C.eqA | C.eqB) != 0) != 0;      // (wave-uniform)
   while (!done) {
     if (R.act && R.par == 0) {                               // sigma D^-2 for the KKT diagonal (natural order, behind the pad)
 #pragma unroll
@@ -816,7 +840,7 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
     wave_lds_sync();
     ok = factorise(Pg, gw, xt + XT_PAD, N, cs, st.rho) && ok;
     if (!ok) break;
-    if (!iterate(&st, &C, Pg, Gg, N, o)) done = true;
+    if (!(anyeq ? iterate<true>(&st, &C, Pg, Gg, exw, scal, N, o) : iterate<false>(&st, &C, Pg, Gg, exw, scal, N, o))) done = true;
   }
   const bool converged = st.converged != 0, infeasible = st.infeasible != 0;
   if (wm) {                                                  // keep the solution for the next warm start
