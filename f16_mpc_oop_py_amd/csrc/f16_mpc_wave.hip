@@ -66,6 +66,10 @@ __shared__ __attribute__((aligned(16))) double s_w[LDS_DOUBLES];
 
 __device__ __forceinline__ int tile_idx(int w, int J) { return w * (w + 1) / 2 + J; }
 
+// pointers into the workspace are GLOBAL memory: said so, the loads are global_load (one counter) instead of flat_load
+typedef const double __attribute__((address_space(1))) *gptr_t;
+__device__ __forceinline__ gptr_t as_global(const double *p) { return (gptr_t)p; }
+
 template <int CTRL>
 __device__ __forceinline__ double dpp(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -111,7 +115,7 @@ struct LaneConst {
   double cs, cinv;
 };
 struct SolveState {
-  double x[3], zA[3], yA[3], zB[3], yB[3];
+  double x[3], zA[3], yA[3], zB[3], yB[3], dyA[3], dyB[3];
   double rho, rp, rd;
   int it, to_check, done, converged, infeasible;
 };
@@ -122,20 +126,19 @@ struct IterSettings { double alpha, eps_abs, eps_rel, eps_prim_inf; int max_iter
 // rr' < 3 is kept row 3h + rr', rr' >= 3 kept row 3(1-h) + rr' - 3 (h = par ^ b2), so that the first halving step of stage 3
 // is free of selects.  Zero for lags beyond the horizon.
 __device__ __forceinline__ void load_G(double (&Gd)[4][6][3], const double *Gg, const Role &R, int N) {
-  constexpr int SR[6] = {2, 3, 4, 5, 6, 8};
+  // (unconditional loads from clamped addresses, the masks applied afterwards: a load under a lane condition becomes a
+  //  branch around it, and 72 of those in a row wait out 72 memory latencies -- 43 k cycles per call when measured)
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int d = 4 * R.t + u;
+    const gptr_t gp = as_global(Gg) + (d < N ? d : 0) * 27;
+    const double m = d < N ? 1.0 : 0.0;
 #pragma unroll
     for (int rr = 0; rr < 6; ++rr) {
-      const int lo3 = rr % 3;
-      // kept-row index of slot rr for h = 0 / h = 1
-      const int k0 = rr < 3 ? lo3 : 3 + lo3, k1 = rr < 3 ? 3 + lo3 : lo3;
+      const int kept = 3 * (R.h ^ (rr >= 3 ? 1 : 0)) + rr % 3;      // kept-row index of slot rr
+      const int row = kept < 5 ? kept + 2 : 8;                        // MPC state row (SROW)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double g0 = d < N ? Gg[d * 27 + SR[k0] * 3 + c] : 0.0, g1 = d < N ? Gg[d * 27 + SR[k1] * 3 + c] : 0.0;
-        Gd[u][rr][c] = R.h ? g1 : g0;
-      }
+      for (int c = 0; c < 3; ++c) Gd[u][rr][c] = gp[row * 3 + c] * m;
     }
   }
 }
@@ -240,13 +243,24 @@ __device__ __forceinline__ void sym_matvec(const double *Pg, int n, const double
   double A[6][6], Bk[6][6];
   const int lb = R.l < NL ? R.l : NL - 1;
   if (FROM_P) {
+    // three phases, each a batch of independent loads: the 72 table entries, then the 72 matrix elements (as one loop the
+    // compiler waited out every element's two memory round trips in turn: 70 k cycles per termination test)
+    const gptr_t Pgg = as_global(Pg);
+    unsigned ij[72];
+#pragma unroll
+    for (int e = 0; e < 72; ++e) ij[e] = F16_WAVE_PGATH[e * 64 + R.l];
+    __builtin_amdgcn_sched_barrier(0);
+    double pv[72];
 #pragma unroll
     for (int e = 0; e < 72; ++e) {
-      const unsigned ij = F16_WAVE_PGATH[e * 64 + R.l];
-      const int i = (int)(ij >> 8), j = (int)(ij & 255);
-      const bool in = i < n && j < n;                      // (i >= j)
-      const double pv = Pg[in ? i * (i + 1) / 2 + j : 0];
-      const double val = in ? pv : 0.0;
+      const int i = (int)(ij[e] >> 8), j = (int)(ij[e] & 255);
+      pv[e] = Pgg[(i < n && j < n) ? i * (i + 1) / 2 + j : 0];          // (i >= j)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 72; ++e) {
+      const int i = (int)(ij[e] >> 8), j = (int)(ij[e] & 255);
+      const double val = (i < n && j < n) ? pv[e] : 0.0;
       if (e < 36) A[e / 6][e % 6] = val; else Bk[(e - 36) / 6][(e - 36) % 6] = val;
     }
   } else {
@@ -475,20 +489,37 @@ __device__ __forceinline__ void sweep_tile_row(d4_t (&acc)[NTILES], double *c0, 
 __device__ __noinline__ bool factorise(const double *Pg, const double *gw, const double *sg2v, int N, double cs, double rho) {
   const int n = 3 * N, l = threadIdx.x, lc = l & 15, lq = l >> 4;
   d4_t acc[NTILES];
+  {
+    // one tile row at a time: all its loads (unconditional, clamped addresses) as one batch, then the arithmetic -- a load
+    // under a lane condition becomes a branch around it and every element then waits out its own memory round trip
+    const gptr_t Pgg = as_global(Pg), gwg = as_global(gw);
 #pragma unroll
-  for (int w = 0; w < NT; ++w)
+    for (int w = 0; w < NT; ++w) {
+      double pv[NT][4], gv[NT][4], dg[4];
 #pragma unroll
-    for (int J = 0; J <= w; ++J)
+      for (int J = 0; J <= w; ++J)
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
-        const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
-        const bool in = i < n && j < n;
-        const int hi_ = i >= j ? i : j, lo_ = i >= j ? j : i;
-        const double pv = Pg[in ? hi_ * (hi_ + 1) / 2 + lo_ : 0];
-        const double gv = gw[(tile_idx(w, J) * 4 + qq) * 64 + l];
-        const double dg = sg2v[i < n ? i : 0];
-        acc[tile_idx(w, J)][qq] = in ? cs * pv + rho * gv + (i == j ? dg : 0.0) : (i == j ? 1.0 : 0.0);
-      }
+        for (int qq = 0; qq < 4; ++qq) {
+          const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
+          const bool in = i < n && j < n;
+          const int hi_ = i >= j ? i : j, lo_ = i >= j ? j : i;
+          pv[J][qq] = Pgg[in ? hi_ * (hi_ + 1) / 2 + lo_ : 0];
+          gv[J][qq] = gwg[(tile_idx(w, J) * 4 + qq) * 64 + l];
+        }
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) { const int i = 16 * w + 4 * qq + lq; dg[qq] = sg2v[i < n ? i : 0]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int J = 0; J <= w; ++J)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
+          const bool in = i < n && j < n;
+          const double kin = cs * pv[J][qq] + rho * gv[J][qq] + (i == j ? dg[qq] : 0.0);
+          acc[tile_idx(w, J)][qq] = in ? kin : (i == j ? 1.0 : 0.0);
+        }
+    }
+  }
   double *c0 = s_w + PAN_OFF, *c1 = s_w + PAN_OFF + PAN_SIZE;
   bool ok = true;
   const double ndel = (lq == (lc & 3)) ? -1.0 : 0.0;
@@ -501,34 +532,81 @@ __device__ __noinline__ bool factorise(const double *Pg, const double *gw, const
   sweep_tile_row<4>(acc, c0, c1, lc, lq, l, ndel, ok);
   sweep_tile_row<5>(acc, c0, c1, lc, lq, l, ndel, ok);
   wave_lds_sync();
-  // acc = MINUS the inverse: scatter into the block image (the panels are dead)
+  // acc = MINUS the inverse: scatter into the block image (the panels are dead); the table entries of a tile row as one batch
 #pragma unroll
-  for (int t = 0; t < NTILES; ++t)
+  for (int w = 0; w < NT; ++w) {
+    unsigned dd[NT][4];
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-      const unsigned d = F16_WAVE_KSCAT[(t * 4 + qq) * 64 + l];
-      const unsigned d0 = d & 0xFFFFu, d1 = d >> 16;
-      const double v = -acc[t][qq];
-      if (d0 != 0xFFFFu) s_w[d0] = v;
-      if (d1 != 0xFFFFu) s_w[d1] = v;
-    }
+    for (int J = 0; J <= w; ++J)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) dd[J][qq] = F16_WAVE_KSCAT[(tile_idx(w, J) * 4 + qq) * 64 + l];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int J = 0; J <= w; ++J)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const unsigned d0 = dd[J][qq] & 0xFFFFu, d1 = dd[J][qq] >> 16;
+        const double v = -acc[tile_idx(w, J)][qq];
+        if (d0 != 0xFFFFu) s_w[d0] = v;
+        if (d1 != 0xFFFFu) s_w[d1] = v;
+      }
+  }
   wave_lds_sync();
   return __ballot(!ok) == 0;
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// The iterations between two factorisations (f16_mpc_solve.hip: admm_iterate, rule for rule).  Loop nest: the inner loop
-// runs the iterations up to the next termination test and holds nothing but what an iteration needs (the test sits in the
-// outer loop, so that its temporaries and its copies of the stage code do not weigh on the register allocation of the hot
-// loop); the last iteration before a test is peeled, because only it must keep the dual step dy (primal-infeasibility
-// certificate).  ANYEQ = false: no row of this aircraft carries the 1e3 rho of an equality row (the common case): rho and its
-// reciprocal are wave-uniform scalars.
+// The iterations (f16_mpc_solve.hip: admm_iterate, rule for rule) as THREE out-of-line pieces with register allocations of
+// their own: run_iterations (the hot loop: nothing but what an iteration needs is live in it), terminate_test (every
+// check_every iterations) and start_point (after a factorisation).  The state passes through the SolveState in memory; the
+// 72 Toeplitz doubles are (re)loaded by whoever needs them (L2-resident).  The last iteration before a test is peeled,
+// because only it must keep the dual step dy (primal-infeasibility certificate).  ANYEQ = false: no row of this aircraft
+// carries the 1e3 rho of an equality row (the common case): rho and its reciprocal are wave-uniform scalars.
 __device__ __forceinline__ double uniform_f64(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
+#ifdef F16_EXP_STAMPW
+__device__ unsigned long long g_wstamp[16];      // diagnostic build: cycles per phase of the iterations of workgroup 0, + counts
+#define WSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); tS[i] += t1_ - t0_; t0_ = t1_; }
+#else
+#define WSTAMP(i)
+#endif
+
 template <bool ANYEQ>
-__device__ __noinline__ int iterate(SolveState *st, const LaneConst *lcp, const double *Pg, const double *Gg, const double *qv,
-                                    const double *Dv, int N, IterSettings o) {
+struct RowOps {                                  // per-row rho and 1 / rho of a lane's six rows
+  double rho1, rhoE, rinv1, rinvE;
+  int eqA, eqB;
+  __device__ __forceinline__ RowOps(double rho, const LaneConst &C) {
+    rho1 = uniform_f64(rho); rhoE = rho1 * OSQP_RHO_EQ_OVER_RHO_INEQ;
+    rinv1 = uniform_f64(1.0 / rho1); rinvE = uniform_f64(1.0 / rhoE);
+    eqA = C.eqA; eqB = C.eqB;
+  }
+  __device__ __forceinline__ double roA(int c) const { return ANYEQ ? (((eqA >> c) & 1) ? rhoE : rho1) : rho1; }
+  __device__ __forceinline__ double riA(int c) const { return ANYEQ ? (((eqA >> c) & 1) ? rinvE : rinv1) : rinv1; }
+  __device__ __forceinline__ double roB(int c) const { return ANYEQ ? (((eqB >> c) & 1) ? rhoE : rho1) : rho1; }
+  __device__ __forceinline__ double riB(int c) const { return ANYEQ ? (((eqB >> c) & 1) ? rinvE : rinv1) : rinv1; }
+};
+struct RowSlots {                                // where a lane's rows live in the LDS vectors
+  double *wsn, *wsr, *wB;
+  bool act;
+  __device__ __forceinline__ RowSlots(const Role &R) {
+    double *const ws = s_w + WS_OFF;
+    wsn = ws + WS_REC * R.istep + 3 * R.h; wsr = ws + WS_REC * R.istep + 6 + 3 * (1 - R.h);
+    wB = s_w + (R.par ? WR_OFF : WC_OFF) + 3 * R.istep;
+    act = R.act;
+  }
+  __device__ __forceinline__ void put(const double (&vA)[3], const double (&vB)[3]) const {      // row vectors -> LDS
+    if (act) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { wsn[c] = vA[c]; wsr[c] = vA[c]; wB[c] = vB[c]; }
+    }
+  }
+};
+
+// nrun >= 1 iterations from the state in *st (w of that point is in LDS); leaves the state, the dual step of the last
+// iteration and w of the new point.
+template <bool ANYEQ>
+__device__ __noinline__ void run_iterations(SolveState *st, const LaneConst *lcp, const double *Gg, int N, double alpha, int nrun) {
   const Role R = role(N);
   const int n = 3 * N;
   const LaneConst C = *lcp;
@@ -537,37 +615,19 @@ __device__ __noinline__ int iterate(SolveState *st, const LaneConst *lcp, const 
   double x[3], zA[3], yA[3], zB[3], yB[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) { x[c] = st->x[c]; zA[c] = st->zA[c]; yA[c] = st->yA[c]; zB[c] = st->zB[c]; yB[c] = st->yB[c]; }
-  double rho = uniform_f64(st->rho), rp = st->rp, rd = st->rd;
-  int it = st->it, to_check = st->to_check;
-  bool done = false, converged = false, infeasible = false, refactor = false;
-  const double rho1 = rho, rhoE = rho * OSQP_RHO_EQ_OVER_RHO_INEQ, rinv1 = uniform_f64(1.0 / rho1), rinvE = uniform_f64(1.0 / rhoE);
-  auto roA = [&](int c) { return ANYEQ ? (((C.eqA >> c) & 1) ? rhoE : rho1) : rho1; };
-  auto riA = [&](int c) { return ANYEQ ? (((C.eqA >> c) & 1) ? rinvE : rinv1) : rinv1; };
-  auto roB = [&](int c) { return ANYEQ ? (((C.eqB >> c) & 1) ? rhoE : rho1) : rho1; };
-  auto riB = [&](int c) { return ANYEQ ? (((C.eqB >> c) & 1) ? rinvE : rinv1) : rinv1; };
+  const RowOps<ANYEQ> ro(st->rho, C);
+  const RowSlots slots(R);
   double *const ws = s_w + WS_OFF, *const wc = s_w + WC_OFF, *const wr = s_w + WR_OFF, *const xt = s_w + XT_OFF;
   double *const rhs = wc;                                   // (the owner of k reads wc[k] before it writes rhs[k])
-  const int kx = 3 * R.istep;                               // first owned variable / command / rate row
-  const int kxa = R.act ? kx : 0;
+  const int kx = 3 * R.istep, kxa = R.act ? kx : 0;         // first owned variable / command / rate row
   const bool wrx = R.act && R.par == 0;                     // one lane of the pair writes what both own
-  double *const wsn = ws + WS_REC * R.istep + 3 * R.h, *const wsr = ws + WS_REC * R.istep + 6 + 3 * (1 - R.h);
-  double *const wB = (R.par ? wr : wc) + kx;
-  auto put_rows = [&](const double (&vA)[3], const double (&vB)[3]) {      // row vectors -> LDS (stage-1 operand, adjoint terms)
-    if (R.act) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { wsn[c] = vA[c]; wsr[c] = vA[c]; wB[c] = vB[c]; }
-    }
-  };
-  auto put_w = [&]() {                                      // w = W (rho z - y)
-    double wA[3], wBv[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { wA[c] = C.WA[c] * (roA(c) * zA[c] - yA[c]); wBv[c] = C.WB[c] * (roB(c) * zB[c] - yB[c]); }
-    put_rows(wA, wBv);
-  };
   double dyA[3] = {0.0, 0.0, 0.0}, dyB[3] = {0.0, 0.0, 0.0};
-  // ---- one iteration (KEEP: the dual step survives it)
+#ifdef F16_EXP_STAMPW
+  unsigned long long tS[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime();
+#endif
   auto iteration = [&](auto keep) {
     constexpr bool KEEP = decltype(keep)::value;
+    WSTAMP(7)
     // A: rhs = sigma D^-2 x - c q + A' W (rho z - y)
     {
       double t1[3];
@@ -581,11 +641,14 @@ __device__ __noinline__ int iterate(SolveState *st, const LaneConst *lcp, const 
         for (int c = 0; c < 3; ++c) rhs[kx + c] = C.sg[c] * x[c] - C.cq[c] + (t1[c] + wce[c] + (wre[c] - wrn[c]));
       }
     }
+    WSTAMP(0)
     wave_lds_sync();
+    WSTAMP(1)
     // B: x~ = K^-1 rhs
     {
       double y6[6];
       sym_matvec<false>(nullptr, n, rhs, R, y6);
+      WSTAMP(2)
       wave_lds_sync();                                      // (every lane has read rhs / wc)
       if (R.s == 0 && R.r < NB) {
 #pragma unroll
@@ -593,165 +656,249 @@ __device__ __noinline__ int iterate(SolveState *st, const LaneConst *lcp, const 
       }
     }
     wave_lds_sync();
+    WSTAMP(3)
     // C: z~ = A x~, relaxation, projection, dual update (unscaled z, y = yb / E); w of the new point
     {
       double z3[3], xk[3], xkm[3];
       stage3(Gd, xt, R, z3);
+      WSTAMP(4)
 #pragma unroll
       for (int c = 0; c < 3; ++c) { xk[c] = xt[XT_PAD + kxa + c]; xkm[c] = xt[XT_PAD + kxa + c - 3]; }
       WAVE_LDS_PHASE();
+      double wA[3], wBv[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        x[c] = o.alpha * xk[c] + (1 - o.alpha) * x[c];
+        x[c] = alpha * xk[c] + (1 - alpha) * x[c];
         {
-          const double zr = o.alpha * z3[c] + (1 - o.alpha) * zA[c];
-          const double zn = fmin(fmax(fma(yA[c], riA(c), zr), C.loA[c]), C.hiA[c]);
-          const double d = roA(c) * (zr - zn);
+          const double zr = alpha * z3[c] + (1 - alpha) * zA[c];
+          const double zn = fmin(fmax(fma(yA[c], ro.riA(c), zr), C.loA[c]), C.hiA[c]);
+          const double d = ro.roA(c) * (zr - zn);
           if (KEEP) dyA[c] = d;
           yA[c] = yA[c] + d; zA[c] = zn;
+          wA[c] = C.WA[c] * (ro.roA(c) * zA[c] - yA[c]);
         }
         {
           const double zt = R.par ? xk[c] - xkm[c] : xk[c];
-          const double zr = o.alpha * zt + (1 - o.alpha) * zB[c];
-          const double zn = fmin(fmax(fma(yB[c], riB(c), zr), C.loB[c]), C.hiB[c]);
-          const double d = roB(c) * (zr - zn);
+          const double zr = alpha * zt + (1 - alpha) * zB[c];
+          const double zn = fmin(fmax(fma(yB[c], ro.riB(c), zr), C.loB[c]), C.hiB[c]);
+          const double d = ro.roB(c) * (zr - zn);
           if (KEEP) dyB[c] = d;
           yB[c] = yB[c] + d; zB[c] = zn;
+          wBv[c] = C.WB[c] * (ro.roB(c) * zB[c] - yB[c]);
         }
       }
+      WSTAMP(5)
+      slots.put(wA, wBv);                                   // w = W (rho z - y) of the new point
     }
-    if (!KEEP) { put_w(); wave_lds_sync(); }                // (after a test the outer loop writes w: the buffers carry the test's vectors)
+    wave_lds_sync();
+    WSTAMP(6)
   };
-  // zero what carries zero padding, then w of the current point
+  for (; nrun > 1; --nrun) iteration(std::false_type{});
+  iteration(std::true_type{});
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { st->x[c] = x[c]; st->zA[c] = zA[c]; st->yA[c] = yA[c]; st->zB[c] = zB[c]; st->yB[c] = yB[c];
+                                st->dyA[c] = dyA[c]; st->dyB[c] = dyB[c]; }
+#ifdef F16_EXP_STAMPW
+  if (blockIdx.x == 0 && R.l == 0)
+    for (int i = 0; i < 8; ++i) g_wstamp[i] += tS[i];
+#endif
+}
+
+// After a factorisation: zero what carries zero padding, then w = W (rho z - y) of the current point.
+template <bool ANYEQ>
+__device__ __noinline__ void start_point(const SolveState *st, const LaneConst *lcp, int N) {
+  const Role R = role(N);
+  const LaneConst C = *lcp;
+  const RowOps<ANYEQ> ro(st->rho, C);
+  const RowSlots slots(R);
   for (int i = R.l; i < WS_SIZE + WC_SIZE + WR_SIZE + XT_SIZE; i += 64) s_w[WS_OFF + i] = 0.0;
   wave_lds_sync();
-  put_w();
+  double wA[3], wBv[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { wA[c] = C.WA[c] * (ro.roA(c) * st->zA[c] - st->yA[c]); wBv[c] = C.WB[c] * (ro.roB(c) * st->zB[c] - st->yB[c]); }
+  slots.put(wA, wBv);
   wave_lds_sync();
-  while (!done && !refactor) {
-    int nrun = o.max_iter - it < to_check ? o.max_iter - it : to_check;       // iterations up to the next test (>= 1)
-    it += nrun; to_check -= nrun;
-    if (to_check == 0) to_check = o.check_every;
-    for (; nrun > 1; --nrun) iteration(std::false_type{});
-    iteration(std::true_type{});
-    {
-      // ---- residuals (OSQP termination test on the UNSCALED problem): A x, P x, A' W y / c
-      wave_lds_sync();
-      {
-        double eA[3], eB[3];
+}
+
+// The termination test of the point in *st (OSQP, on the UNSCALED problem: A x, P x, A' W y / c), the primal-infeasibility
+// certificate and, every rho_every iterations, the rho estimate on the scaled residuals.  Sets done / converged / infeasible,
+// returns 1 when rho left the 5x band (st->rho then holds the new value and the caller re-factorises); leaves w of the
+// current point in LDS for the next iteration otherwise.
+template <bool ANYEQ>
+__device__ __noinline__ int terminate_test(SolveState *st, const LaneConst *lcp, const double *Pg, const double *Gg, const double *qv,
+                                           const double *Dv, int N, IterSettings o) {
+  const Role R = role(N);
+  const int n = 3 * N;
+  const LaneConst C = *lcp;
+  double Gd[4][6][3];
+  load_G(Gd, Gg, R, N);
+  double x[3], zA[3], yA[3], zB[3], yB[3], dyA[3], dyB[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { eA[c] = C.WA[c] * yA[c]; eB[c] = C.WB[c] * yB[c]; }
-        put_rows(eA, eB);
-        if (wrx) {
+  for (int c = 0; c < 3; ++c) { x[c] = st->x[c]; zA[c] = st->zA[c]; yA[c] = st->yA[c]; zB[c] = st->zB[c]; yB[c] = st->yB[c];
+                                dyA[c] = st->dyA[c]; dyB[c] = st->dyB[c]; }
+  double rho = uniform_f64(st->rho);
+  const RowOps<ANYEQ> ro(rho, C);
+  const RowSlots slots(R);
+  const int it = st->it;
+  double *const ws = s_w + WS_OFF, *const wc = s_w + WC_OFF, *const wr = s_w + WR_OFF, *const xt = s_w + XT_OFF;
+  const int kx = 3 * R.istep, kxa = R.act ? kx : 0;
+  const bool wrx = R.act && R.par == 0;
+  bool done = false, converged = false, infeasible = false, refactor = false;
+  {
+    double eA[3], eB[3];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) xt[XT_PAD + kx + c] = x[c];
-        }
-      }
-      wave_lds_sync();
-      double qu[3], cD[3];
+    for (int c = 0; c < 3; ++c) { eA[c] = C.WA[c] * yA[c]; eB[c] = C.WB[c] * yB[c]; }
+    slots.put(eA, eB);
+    if (wrx) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { qu[c] = R.act ? qv[kx + c] : 0.0; cD[c] = C.cs * (R.act ? Dv[kx + c] : 1.0); }
-      double ax3[3], aty3[3], axB[3];
-      stage3(Gd, xt, R, ax3);
-      stage1(Gd, ws, R, N, aty3);
-      double aty[3];
+      for (int c = 0; c < 3; ++c) xt[XT_PAD + kx + c] = x[c];
+    }
+  }
+  wave_lds_sync();
+  double qu[3], cD[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int k = kxa + c;
-        aty[c] = C.cinv * (aty3[c] + wc[k] + (wr[k] - wr[k + 3]));
-        const double xkk = xt[XT_PAD + k], xkm = xt[XT_PAD + k - 3];
-        axB[c] = R.par ? xkk - xkm : xkk;
-      }
-      wave_lds_sync();
-      double px[3];
-      {
-        double p6[6];
-        sym_matvec<true>(Pg, n, xt + XT_PAD, R, p6);
-        wave_lds_sync();
-        if (R.s == 0 && R.r < NB) {
+  for (int c = 0; c < 3; ++c) { qu[c] = R.act ? qv[kx + c] : 0.0; cD[c] = C.cs * (R.act ? Dv[kx + c] : 1.0); }
+  double ax3[3], aty3[3], axB[3];
+  stage3(Gd, xt, R, ax3);
+  stage1(Gd, ws, R, N, aty3);
+  double aty[3];
 #pragma unroll
-          for (int j = 0; j < 6; ++j) wc[6 * R.r + j] = p6[j];              // (the command-row buffer is free now)
-        }
-        wave_lds_sync();
+  for (int c = 0; c < 3; ++c) {
+    const int k = kxa + c;
+    aty[c] = C.cinv * (aty3[c] + wc[k] + (wr[k] - wr[k + 3]));
+    const double xkk = xt[XT_PAD + k], xkm = xt[XT_PAD + k - 3];
+    axB[c] = R.par ? xkk - xkm : xkk;
+  }
+  wave_lds_sync();
+  double px[3];
+  {
+    double p6[6];
+    sym_matvec<true>(Pg, n, xt + XT_PAD, R, p6);
+    wave_lds_sync();
+    if (R.s == 0 && R.r < NB) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) px[c] = wc[kxa + c];
-      }
-      double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                // r1, |Ax|, |z|, r2, |Px|, |A'y|, |q|, |E dyb|, support(dyb)
-      if (R.act) {
+      for (int j = 0; j < 6; ++j) wc[6 * R.r + j] = p6[j];              // (the command-row buffer is free now)
+    }
+    wave_lds_sync();
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          v[0] = fmax(v[0], fmax(fabs(ax3[c] - zA[c]), fabs(axB[c] - zB[c])));
-          v[1] = fmax(v[1], fmax(fabs(ax3[c]), fabs(axB[c])));
-          v[2] = fmax(v[2], fmax(fabs(zA[c]), fabs(zB[c])));
-          v[7] = fmax(v[7], fmax(C.WA[c] * fabs(dyA[c]), C.WB[c] * fabs(dyB[c])));
-          v[8] += C.WA[c] * (C.hiA[c] * fmax(dyA[c], 0.0) + C.loA[c] * fmin(dyA[c], 0.0)) +
-                  C.WB[c] * (C.hiB[c] * fmax(dyB[c], 0.0) + C.loB[c] * fmin(dyB[c], 0.0));
-          v[3] = fmax(v[3], fabs(px[c] + qu[c] + aty[c]));
-          v[4] = fmax(v[4], fabs(px[c])); v[5] = fmax(v[5], fabs(aty[c])); v[6] = fmax(v[6], fabs(qu[c]));
-        }
-      }
+    for (int c = 0; c < 3; ++c) px[c] = wc[kxa + c];
+  }
+  double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                // r1, |Ax|, |z|, r2, |Px|, |A'y|, |q|, |E dyb|, support(dyb)
+  if (R.act) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = wave_reduce_dpp<false>(v[i]);
-      v[8] = wave_reduce_dpp<true>(v[8]);
-      rp = v[0]; rd = v[3];
-      const double np_ = fmax(v[1], v[2]), nd_ = fmax(fmax(v[4], v[5]), v[6]);
-      if (rp < o.eps_abs + o.eps_rel * np_ && rd < o.eps_abs + o.eps_rel * nd_) { done = true; converged = true; }
-      else {
-        // OSQP primal-infeasibility certificate on dy (auxil.c:is_primal_infeasible)
-        const double ndy = v[7], supp = v[8];
-        if (ndy > o.eps_prim_inf && supp < -o.eps_prim_inf * ndy) {
-          {
-            double eA[3], eB[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { eA[c] = C.WA[c] * dyA[c]; eB[c] = C.WB[c] * dyB[c]; }
-            put_rows(eA, eB);                                 // (the command-row buffer held P x: already consumed)
-          }
-          wave_lds_sync();
-          double t3[3];
-          stage1(Gd, ws, R, N, t3);
-          double wmax = 0.0;
-          if (R.act) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) wmax = fmax(wmax, fabs(t3[c] + wc[kx + c] + (wr[kx + c] - wr[kx + c + 3])));
-          }
-          wmax = wave_reduce_dpp<false>(wmax);
-          if (wmax < o.eps_prim_inf * ndy) { done = true; infeasible = true; }
-        }
-        if (!done) {
-          if (it >= o.max_iter) done = true;
-          else if (o.adaptive_rho && it % o.rho_every == 0) {
-            // auxil.c:compute_rho_estimate on the SCALED residuals
-            double sv[7] = {0, 0, 0, 0, 0, 0, 0};
-            if (R.act) {
-#pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                const double ErA = sqrt(C.WA[c]), ErB = sqrt(C.WB[c]);
-                sv[0] = fmax(sv[0], fmax(ErA * fabs(ax3[c] - zA[c]), ErB * fabs(axB[c] - zB[c])));
-                sv[1] = fmax(sv[1], fmax(ErA * fabs(ax3[c]), ErB * fabs(axB[c])));
-                sv[2] = fmax(sv[2], fmax(ErA * fabs(zA[c]), ErB * fabs(zB[c])));
-                sv[3] = fmax(sv[3], cD[c] * fabs(px[c] + qu[c] + aty[c]));
-                sv[4] = fmax(sv[4], cD[c] * fabs(px[c])); sv[5] = fmax(sv[5], cD[c] * fabs(aty[c]));
-                sv[6] = fmax(sv[6], cD[c] * fabs(qu[c]));
-              }
-            }
-#pragma unroll
-            for (int i = 0; i < 7; ++i) sv[i] = wave_reduce_dpp<false>(sv[i]);
-            const double pr = sv[0] / (fmax(sv[2], sv[1]) + 1e-10), dr = sv[3] / (fmax(fmax(sv[6], sv[5]), sv[4]) + 1e-10);
-            const double nw = fmin(fmax(rho * sqrt(pr / (dr + 1e-10)), OSQP_RHO_MIN), OSQP_RHO_MAX);
-            if (nw > OSQP_ADAPTIVE_RHO_TOLERANCE * rho || nw < rho / OSQP_ADAPTIVE_RHO_TOLERANCE) { rho = nw; refactor = true; }
-          }
-        }
-      }
-      wave_lds_sync();
-      // w of the current point for the next iteration (after a rho update the next call rewrites it with the new rho)
-      put_w();
-      wave_lds_sync();
+    for (int c = 0; c < 3; ++c) {
+      v[0] = fmax(v[0], fmax(fabs(ax3[c] - zA[c]), fabs(axB[c] - zB[c])));
+      v[1] = fmax(v[1], fmax(fabs(ax3[c]), fabs(axB[c])));
+      v[2] = fmax(v[2], fmax(fabs(zA[c]), fabs(zB[c])));
+      v[7] = fmax(v[7], fmax(C.WA[c] * fabs(dyA[c]), C.WB[c] * fabs(dyB[c])));
+      v[8] += C.WA[c] * (C.hiA[c] * fmax(dyA[c], 0.0) + C.loA[c] * fmin(dyA[c], 0.0)) +
+              C.WB[c] * (C.hiB[c] * fmax(dyB[c], 0.0) + C.loB[c] * fmin(dyB[c], 0.0));
+      v[3] = fmax(v[3], fabs(px[c] + qu[c] + aty[c]));
+      v[4] = fmax(v[4], fabs(px[c])); v[5] = fmax(v[5], fabs(aty[c])); v[6] = fmax(v[6], fabs(qu[c]));
     }
   }
 #pragma unroll
-  for (int c = 0; c < 3; ++c) { st->x[c] = x[c]; st->zA[c] = zA[c]; st->yA[c] = yA[c]; st->zB[c] = zB[c]; st->yB[c] = yB[c]; }
-  st->rho = rho; st->rp = rp; st->rd = rd; st->it = it; st->to_check = to_check;
+  for (int i = 0; i < 8; ++i) v[i] = wave_reduce_dpp<false>(v[i]);
+  v[8] = wave_reduce_dpp<true>(v[8]);
+  const double rp = v[0], rd = v[3];
+  const double np_ = fmax(v[1], v[2]), nd_ = fmax(fmax(v[4], v[5]), v[6]);
+  if (rp < o.eps_abs + o.eps_rel * np_ && rd < o.eps_abs + o.eps_rel * nd_) { done = true; converged = true; }
+  else {
+    // OSQP primal-infeasibility certificate on dy (auxil.c:is_primal_infeasible)
+    const double ndy = v[7], supp = v[8];
+    if (ndy > o.eps_prim_inf && supp < -o.eps_prim_inf * ndy) {
+      {
+        double eA[3], eB[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { eA[c] = C.WA[c] * dyA[c]; eB[c] = C.WB[c] * dyB[c]; }
+        slots.put(eA, eB);                                    // (the command-row buffer held P x: already consumed)
+      }
+      wave_lds_sync();
+      double t3[3];
+      stage1(Gd, ws, R, N, t3);
+      double wmax = 0.0;
+      if (R.act) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wmax = fmax(wmax, fabs(t3[c] + wc[kx + c] + (wr[kx + c] - wr[kx + c + 3])));
+      }
+      wmax = wave_reduce_dpp<false>(wmax);
+      if (wmax < o.eps_prim_inf * ndy) { done = true; infeasible = true; }
+    }
+    if (!done) {
+      if (it >= o.max_iter) done = true;
+      else if (o.adaptive_rho && it % o.rho_every == 0) {
+        // auxil.c:compute_rho_estimate on the SCALED residuals
+        double sv[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (R.act) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const double ErA = sqrt(C.WA[c]), ErB = sqrt(C.WB[c]);
+            sv[0] = fmax(sv[0], fmax(ErA * fabs(ax3[c] - zA[c]), ErB * fabs(axB[c] - zB[c])));
+            sv[1] = fmax(sv[1], fmax(ErA * fabs(ax3[c]), ErB * fabs(axB[c])));
+            sv[2] = fmax(sv[2], fmax(ErA * fabs(zA[c]), ErB * fabs(zB[c])));
+            sv[3] = fmax(sv[3], cD[c] * fabs(px[c] + qu[c] + aty[c]));
+            sv[4] = fmax(sv[4], cD[c] * fabs(px[c])); sv[5] = fmax(sv[5], cD[c] * fabs(aty[c]));
+            sv[6] = fmax(sv[6], cD[c] * fabs(qu[c]));
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) sv[i] = wave_reduce_dpp<false>(sv[i]);
+        const double pr = sv[0] / (fmax(sv[2], sv[1]) + 1e-10), dr = sv[3] / (fmax(fmax(sv[6], sv[5]), sv[4]) + 1e-10);
+        const double nw = fmin(fmax(rho * sqrt(pr / (dr + 1e-10)), OSQP_RHO_MIN), OSQP_RHO_MAX);
+        if (nw > OSQP_ADAPTIVE_RHO_TOLERANCE * rho || nw < rho / OSQP_ADAPTIVE_RHO_TOLERANCE) { rho = nw; refactor = true; }
+      }
+    }
+  }
+  wave_lds_sync();
+  if (!done && !refactor) {                                   // w of the current point for the next iteration
+    double wA[3], wBv[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { wA[c] = C.WA[c] * (ro.roA(c) * zA[c] - yA[c]); wBv[c] = C.WB[c] * (ro.roB(c) * zB[c] - yB[c]); }
+    slots.put(wA, wBv);
+    wave_lds_sync();
+  }
+  st->rho = rho; st->rp = rp; st->rd = rd;
   st->done = done; st->converged = converged; st->infeasible = infeasible;
   return refactor ? 1 : 0;
+}
+
+// factorise / iterate / test until done (st->done) for one ANYEQ flavour; returns whether every factorisation succeeded
+template <bool ANYEQ>
+__device__ __forceinline__ bool solve_loop(SolveState *st, const LaneConst *lcp, const double *Pg, const double *gw, const double *Gg,
+                                           const double *qv, const double *Dv, int N, double cs, IterSettings o, const Role &R) {
+  double *const xt = s_w + XT_OFF;
+  const int kx = 3 * R.istep;
+  bool ok = true;
+  while (!st->done) {
+    if (R.act && R.par == 0) {                               // sigma D^-2 for the KKT diagonal (natural order, behind the pad)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xt[XT_PAD + kx + c] = lcp->sg[c];
+    }
+    wave_lds_sync();
+#ifdef F16_EXP_STAMPW
+    unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+#define WSTAMPK(i, j) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long tq1 = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && R.l == 0) { g_wstamp[i] += tq1 - tq0; g_wstamp[j] += 1; } tq0 = tq1; }
+#else
+#define WSTAMPK(i, j)
+#endif
+    ok = factorise(Pg, gw, xt + XT_PAD, N, cs, st->rho) && ok;
+    WSTAMPK(10, 12)
+    if (!ok) break;
+    start_point<ANYEQ>(st, lcp, N);
+    bool refactor = false;
+    while (!st->done && !refactor) {
+      const int left = o.max_iter - st->it;
+      const int nrun = left < st->to_check ? left : st->to_check;       // iterations up to the next test (>= 1)
+      WSTAMPK(14, 15)
+      run_iterations<ANYEQ>(st, lcp, Gg, N, o.alpha, nrun);
+      WSTAMPK(13, 15)
+      st->it += nrun; st->to_check -= nrun;
+      if (st->to_check == 0) st->to_check = o.check_every;
+      refactor = terminate_test<ANYEQ>(st, lcp, Pg, Gg, qv, Dv, N, o) != 0;
+      WSTAMPK(9, 11)
+    }
+  }
+  return ok;
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -809,7 +956,7 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
   gram_tiles(gw, N);                                         // A'WA -> workspace (every lane reads back what it wrote itself)
   SolveState st;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) { st.x[c] = 0.0; st.zA[c] = 0.0; st.yA[c] = 0.0; st.zB[c] = 0.0; st.yB[c] = 0.0; }
+  for (int c = 0; c < 3; ++c) { st.x[c] = 0.0; st.zA[c] = 0.0; st.yA[c] = 0.0; st.zB[c] = 0.0; st.yB[c] = 0.0; st.dyA[c] = 0.0; st.dyB[c] = 0.0; }
   st.rp = INFINITY; st.rd = INFINITY; st.it = 0; st.to_check = a.s.check_every > 0 ? a.s.check_every : 1;
   st.done = 0; st.converged = 0; st.infeasible = 0; st.rho = a.s.rho;
   double *const wm = a.warm ? a.warm + (size_t)b * MPC_WARM_DOUBLES + l : nullptr;      // [15][64]: x, zA, yA, zB, yB (unscaled)
@@ -827,21 +974,16 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
       }
     }
   }
+#ifdef F16_EXP_STAMPW
+  if (blockIdx.x == 0 && l < 16) g_wstamp[l] = 0;
+  const unsigned long long tK0 = __builtin_amdgcn_s_memtime();
+#endif
   IterSettings o;
   o.alpha = a.s.alpha; o.eps_abs = a.s.eps_abs; o.eps_rel = a.s.eps_rel; o.eps_prim_inf = a.s.eps_prim_inf;
   o.max_iter = a.s.max_iter; o.check_every = a.s.check_every; o.rho_every = a.s.rho_every; o.adaptive_rho = a.s.adaptive_rho;
-  bool ok = true, done = false;
   const bool anyeq = __ballot((C.eqA | C.eqB) != 0) != 0;      // (wave-uniform)
-  while (!done) {
-    if (R.act && R.par == 0) {                               // sigma D^-2 for the KKT diagonal (natural order, behind the pad)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) xt[XT_PAD + kx + c] = C.sg[c];
-    }
-    wave_lds_sync();
-    ok = factorise(Pg, gw, xt + XT_PAD, N, cs, st.rho) && ok;
-    if (!ok) break;
-    if (!(anyeq ? iterate<true>(&st, &C, Pg, Gg, exw, scal, N, o) : iterate<false>(&st, &C, Pg, Gg, exw, scal, N, o))) done = true;
-  }
+  const bool ok = anyeq ? solve_loop<true>(&st, &C, Pg, gw, Gg, exw, scal, N, cs, o, R)
+                        : solve_loop<false>(&st, &C, Pg, gw, Gg, exw, scal, N, cs, o, R);
   const bool converged = st.converged != 0, infeasible = st.infeasible != 0;
   if (wm) {                                                  // keep the solution for the next warm start
     const bool good = converged && !infeasible;
@@ -859,6 +1001,14 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
       if (a.useq) a.useq[(kx + c) * a.ld + b] = infeasible ? NAN : st.x[c];
     }
   }
+#ifdef F16_EXP_STAMPW
+  if (blockIdx.x == 0 && l == 0 && a.useq) {      // diagnostic build: the stamps replace rows 60.. of this aircraft's u_seq column
+    for (int i = 0; i < 8; ++i) a.useq[(60 + i) * a.ld + b] = (double)g_wstamp[i];
+    a.useq[68 * a.ld + b] = (double)st.it;
+    for (int i = 9; i < 16; ++i) a.useq[(60 + 12 + i - 9) * a.ld + b] = (double)g_wstamp[i];
+    a.useq[71 * a.ld + b] = (double)(__builtin_amdgcn_s_memtime() - tK0);
+  }
+#endif
   if (l == 0) {
     if (a.iters_out) a.iters_out[b] = st.it;
     if (a.info) {
