@@ -567,9 +567,12 @@ __device__ __forceinline__ double uniform_f64(double v) {
 }
 #ifdef F16_EXP_STAMPW
 __device__ unsigned long long g_wstamp[16];      // diagnostic build: cycles per phase of the iterations of workgroup 0, + counts
+__device__ unsigned long long g_tstamp[8];       // phases of the termination test
+#define TSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && threadIdx.x == 0) g_tstamp[i] += t1_ - tt0_; tt0_ = t1_; }
 #define WSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); tS[i] += t1_ - t0_; t0_ = t1_; }
 #else
 #define WSTAMP(i)
+#define TSTAMP(i)
 #endif
 
 template <bool ANYEQ>
@@ -730,8 +733,6 @@ __device__ __noinline__ int terminate_test(SolveState *st, const LaneConst *lcp,
   const Role R = role(N);
   const int n = 3 * N;
   const LaneConst C = *lcp;
-  double Gd[4][6][3];
-  load_G(Gd, Gg, R, N);
   double x[3], zA[3], yA[3], zB[3], yB[3], dyA[3], dyB[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) { x[c] = st->x[c]; zA[c] = st->zA[c]; yA[c] = st->yA[c]; zB[c] = st->zB[c]; yB[c] = st->yB[c];
@@ -744,23 +745,48 @@ __device__ __noinline__ int terminate_test(SolveState *st, const LaneConst *lcp,
   const int kx = 3 * R.istep, kxa = R.act ? kx : 0;
   const bool wrx = R.act && R.par == 0;
   bool done = false, converged = false, infeasible = false, refactor = false;
+#ifdef F16_EXP_STAMPW
+  unsigned long long tt0_ = __builtin_amdgcn_s_memtime();
+#endif
+  // x behind the zero pad (operand of P x and A x); P x first, while the 72 Toeplitz doubles are not live yet: its 72 gathered
+  // matrix elements want the registers
+  if (wrx) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xt[XT_PAD + kx + c] = x[c];
+  }
+  wave_lds_sync();
+  double px[3];
+  {
+    double p6[6];
+    sym_matvec<true>(Pg, n, xt + XT_PAD, R, p6);
+    wave_lds_sync();                                          // (the command-row buffer still holds w: nobody reads it any more)
+    if (R.s == 0 && R.r < NB) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) wc[6 * R.r + j] = p6[j];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int c = 0; c < 3; ++c) px[c] = wc[kxa + c];
+  }
+  TSTAMP(0)
+  wave_lds_sync();
   {
     double eA[3], eB[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) { eA[c] = C.WA[c] * yA[c]; eB[c] = C.WB[c] * yB[c]; }
     slots.put(eA, eB);
-    if (wrx) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) xt[XT_PAD + kx + c] = x[c];
-    }
   }
   wave_lds_sync();
   double qu[3], cD[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) { qu[c] = R.act ? qv[kx + c] : 0.0; cD[c] = C.cs * (R.act ? Dv[kx + c] : 1.0); }
+  double Gd[4][6][3];
+  load_G(Gd, Gg, R, N);
+  TSTAMP(1)
   double ax3[3], aty3[3], axB[3];
   stage3(Gd, xt, R, ax3);
   stage1(Gd, ws, R, N, aty3);
+  TSTAMP(2)
   double aty[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -768,20 +794,6 @@ __device__ __noinline__ int terminate_test(SolveState *st, const LaneConst *lcp,
     aty[c] = C.cinv * (aty3[c] + wc[k] + (wr[k] - wr[k + 3]));
     const double xkk = xt[XT_PAD + k], xkm = xt[XT_PAD + k - 3];
     axB[c] = R.par ? xkk - xkm : xkk;
-  }
-  wave_lds_sync();
-  double px[3];
-  {
-    double p6[6];
-    sym_matvec<true>(Pg, n, xt + XT_PAD, R, p6);
-    wave_lds_sync();
-    if (R.s == 0 && R.r < NB) {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) wc[6 * R.r + j] = p6[j];              // (the command-row buffer is free now)
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int c = 0; c < 3; ++c) px[c] = wc[kxa + c];
   }
   double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                // r1, |Ax|, |z|, r2, |Px|, |A'y|, |q|, |E dyb|, support(dyb)
   if (R.act) {
@@ -800,6 +812,7 @@ __device__ __noinline__ int terminate_test(SolveState *st, const LaneConst *lcp,
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = wave_reduce_dpp<false>(v[i]);
   v[8] = wave_reduce_dpp<true>(v[8]);
+  TSTAMP(3)
   const double rp = v[0], rd = v[3];
   const double np_ = fmax(v[1], v[2]), nd_ = fmax(fmax(v[4], v[5]), v[6]);
   if (rp < o.eps_abs + o.eps_rel * np_ && rd < o.eps_abs + o.eps_rel * nd_) { done = true; converged = true; }
@@ -811,7 +824,7 @@ __device__ __noinline__ int terminate_test(SolveState *st, const LaneConst *lcp,
         double eA[3], eB[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) { eA[c] = C.WA[c] * dyA[c]; eB[c] = C.WB[c] * dyB[c]; }
-        slots.put(eA, eB);                                    // (the command-row buffer held P x: already consumed)
+        slots.put(eA, eB);
       }
       wave_lds_sync();
       double t3[3];
@@ -857,6 +870,7 @@ __device__ __noinline__ int terminate_test(SolveState *st, const LaneConst *lcp,
     slots.put(wA, wBv);
     wave_lds_sync();
   }
+  TSTAMP(4)
   st->rho = rho; st->rp = rp; st->rd = rd;
   st->done = done; st->converged = converged; st->infeasible = infeasible;
   return refactor ? 1 : 0;
@@ -976,6 +990,7 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
   }
 #ifdef F16_EXP_STAMPW
   if (blockIdx.x == 0 && l < 16) g_wstamp[l] = 0;
+  if (blockIdx.x == 0 && l < 8) g_tstamp[l] = 0;
   const unsigned long long tK0 = __builtin_amdgcn_s_memtime();
 #endif
   IterSettings o;
@@ -1006,6 +1021,7 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
     for (int i = 0; i < 8; ++i) a.useq[(60 + i) * a.ld + b] = (double)g_wstamp[i];
     a.useq[68 * a.ld + b] = (double)st.it;
     for (int i = 9; i < 16; ++i) a.useq[(60 + 12 + i - 9) * a.ld + b] = (double)g_wstamp[i];
+    for (int i = 0; i < 5; ++i) a.useq[(80 + i) * a.ld + b] = (double)g_tstamp[i];
     a.useq[71 * a.ld + b] = (double)(__builtin_amdgcn_s_memtime() - tK0);
   }
 #endif

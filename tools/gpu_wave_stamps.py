@@ -23,3 +23,5 @@ for n, v in zip(names, s[:8]):
     print(f"   {n:14s} {v / it:8.0f}")
 print(f"   total          {s[:8].sum() / it:8.0f}")
 print(f"tests: {e[2]:.0f} x {e[0] / max(e[2], 1):.0f} cycles; factorisations: {e[3]:.0f} x {e[1] / max(e[3], 1):.0f} cycles; run_iterations calls total {e[4]:.0f} cycles; other {e[5]:.0f}; whole kernel (workgroup 0) {s[11]:.0f} cycles")
+t = info["u_seq"][0, 80:85].cpu().numpy()
+print("termination test, cycles per test: P x %.0f | W y + G load %.0f | A x, A'y %.0f | norms + reductions %.0f | decision + w %.0f" % tuple(t / max(e[2], 1)))
