@@ -1020,11 +1020,12 @@ static int mpc_lds_opt_in() {
 }
 
 // Per-call QP workspace, stream-ordered (see f16_ctx.h): [B][np] P | [B][ext] extras | [B][tiles] A'WA of the fast solver.
-static int mpc_work_alloc(f16_ctx *ctx, MpcArgs &a, bool with_ext, void *stream, void **block, bool with_gram = false) {
+static int mpc_work_alloc(f16_ctx *ctx, MpcArgs &a, bool with_ext, void *stream, void **block, bool with_gram = false,
+                          bool with_pblk = false) {
   const size_t np = (size_t)(3 * a.N) * (3 * a.N + 1) / 2;
   const bool big = a.N > MAXN;
-  const size_t need = (np + (with_ext ? mpc_ext_doubles(a.N) : 0) + (with_gram ? MPC_TILE_DOUBLES : 0) + (big ? mpc_big_doubles(a.N) : 0)) *
-                      (size_t)a.B * sizeof(double);
+  const size_t need = (np + (with_ext ? mpc_ext_doubles(a.N) : 0) + (with_gram ? MPC_TILE_DOUBLES : 0) + (big ? mpc_big_doubles(a.N) : 0) +
+                       (with_pblk ? WAVE_PBLK_DOUBLES : 0)) * (size_t)a.B * sizeof(double);
   *block = nullptr;
   // Not under stream capture: replays of a graph holding these stream-ordered allocation / free nodes were measured to
   // return wrong results intermittently on ROCm 7.2 (the workspace is not stable across replays).  A prepared plan owns its
@@ -1037,6 +1038,8 @@ static int mpc_work_alloc(f16_ctx *ctx, MpcArgs &a, bool with_ext, void *stream,
   a.ext = with_ext ? a.Ppk + np * (size_t)a.B : nullptr;
   a.gramws = with_gram ? a.Ppk + (np + mpc_ext_doubles(a.N)) * (size_t)a.B : nullptr;
   a.bigws = big ? a.Ppk + (np + (with_ext ? mpc_ext_doubles(a.N) : 0) + (with_gram ? MPC_TILE_DOUBLES : 0)) * (size_t)a.B : nullptr;
+  a.pblk = with_pblk ? a.Ppk + (np + (with_ext ? mpc_ext_doubles(a.N) : 0) + (with_gram ? MPC_TILE_DOUBLES : 0) + (big ? mpc_big_doubles(a.N) : 0)) * (size_t)a.B
+                     : nullptr;
   return F16_OK;
 }
 static int mpc_work_free(void *block, void *stream) {
@@ -1063,10 +1066,15 @@ static f16_ctx::sched_entry *mpc_sched_entry(f16_ctx *ctx, void *stream, long B)
 // else the 512-lane workgroup per aircraft.  F16_MPC_WAVE=0 keeps the latter everywhere (A/B runs, cross-checks).
 static int mpc_solve_dispatch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
   if (a.mode == 0 && mpc_wave_enabled(a)) {
-    MpcArgs e = a;
-    e.mode = 3; e.order = nullptr; e.iters_out = nullptr; e.warm = nullptr;
-    if (int rc = mpc_fast_solve_launch(ctx, e, stream)) return rc;
-    return mpc_wave_solve_launch(ctx, a, stream);
+    static const bool ruiz_outside = [] { const char *e = getenv("F16_WAVE_RUIZ"); return e && e[0] == '0'; }();
+    MpcArgs w = a;
+    w.wave_ruiz = ruiz_outside ? 0 : 1;
+    if (ruiz_outside) {
+      MpcArgs e = a;
+      e.mode = 3; e.order = nullptr; e.iters_out = nullptr; e.warm = nullptr;
+      if (int rc = mpc_fast_solve_launch(ctx, e, stream)) return rc;
+    }
+    return mpc_wave_solve_launch(ctx, w, stream);
   }
   return mpc_fast_solve_launch(ctx, a, stream);
 }
@@ -1083,7 +1091,7 @@ static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream, int mode, void **k
   void *block = nullptr;
   // the wavefront solver (f16_mpc_wave.hip: N <= 30, equilibrated solves) keeps its per-aircraft workspace in the Gram block
   const bool wave_ok = mode == 2 && N <= WAVE_MAXN && a.s.scaling > 0 && a.s.max_iter > 0;
-  if (int rc = mpc_work_alloc(ctx, a, mode != 0, stream, &block, mode == 2 && (a.s.adaptive_rho || wave_ok))) return rc;
+  if (int rc = mpc_work_alloc(ctx, a, mode != 0, stream, &block, mode == 2 && (a.s.adaptive_rho || wave_ok), wave_ok)) return rc;
   int rc = F16_OK;
   if (mode == 0) {
     if (big) hipLaunchKernelGGL((k_mpc<false, true>), dim3(wave_grid(a.B)), dim3(64), lds, (hipStream_t)stream, a);
@@ -1187,6 +1195,7 @@ extern "C" int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const doub
   a.Ppk = p->buf; a.ext = a.Ppk + np * (size_t)B;
   a.tiles = a.ext + mpc_ext_doubles(hzn) * (size_t)B;
   a.gramws = a.tiles + MPC_TILE_DOUBLES * (size_t)B;
+  a.pblk = a.tiles;                                    // (equilibrated plans keep no inverse: the block is the wavefront solver's)
   a.mode = 1;
   int rc = plan_launch_build(p, a, stream);
   // Without equilibration the start value of rho and the KKT factorisation depend on the model only and are cached too.

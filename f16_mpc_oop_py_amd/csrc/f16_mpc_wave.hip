@@ -239,29 +239,20 @@ __device__ __forceinline__ void stage3(const double (&Gd)[4][6][3], const double
 // v: natural order, 6 r at v[6 r]; all four lanes of quad r receive y[6r..6r+5].
 template <bool FROM_P>
 __device__ __forceinline__ void sym_matvec(const double *Pg, int n, const double *v, const Role &R, double (&y)[6]) {
-  // (FROM_P: the operand sits at an odd double index -- 8-byte loads)
+  // (FROM_P: Pg = the block image of P in HBM; the operand sits at an odd double index -- 8-byte loads)
+  (void)n;
   double A[6][6], Bk[6][6];
   const int lb = R.l < NL ? R.l : NL - 1;
   if (FROM_P) {
-    // three phases, each a batch of independent loads: the 72 table entries, then the 72 matrix elements (as one loop the
-    // compiler waited out every element's two memory round trips in turn: 70 k cycles per termination test)
-    const gptr_t Pgg = as_global(Pg);
-    unsigned ij[72];
+    // the block image of P in the workspace (built once per solve by the prologue): 36 coalesced 16-byte loads
+    typedef double dbl2_t __attribute__((ext_vector_type(2)));
+    typedef const dbl2_t __attribute__((address_space(1))) *g2ptr_t;
+    const g2ptr_t pb = (g2ptr_t)Pg + R.l;
 #pragma unroll
-    for (int e = 0; e < 72; ++e) ij[e] = F16_WAVE_PGATH[e * 64 + R.l];
-    __builtin_amdgcn_sched_barrier(0);
-    double pv[72];
-#pragma unroll
-    for (int e = 0; e < 72; ++e) {
-      const int i = (int)(ij[e] >> 8), j = (int)(ij[e] & 255);
-      pv[e] = Pgg[(i < n && j < n) ? i * (i + 1) / 2 + j : 0];          // (i >= j)
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int e = 0; e < 72; ++e) {
-      const int i = (int)(ij[e] >> 8), j = (int)(ij[e] & 255);
-      const double val = (i < n && j < n) ? pv[e] : 0.0;
-      if (e < 36) A[e / 6][e % 6] = val; else Bk[(e - 36) / 6][(e - 36) % 6] = val;
+    for (int m = 0; m < 18; ++m) {
+      const dbl2_t a = pb[m * 64], b = pb[(18 + m) * 64];
+      A[(2 * m) / 6][(2 * m) % 6] = a.x; A[(2 * m + 1) / 6][(2 * m + 1) % 6] = a.y;
+      Bk[(2 * m) / 6][(2 * m) % 6] = b.x; Bk[(2 * m + 1) / 6][(2 * m + 1) % 6] = b.y;
     }
   } else {
     const double2 *ki = reinterpret_cast<const double2 *>(s_w) + lb;
@@ -652,8 +643,7 @@ __device__ __noinline__ void run_iterations(SolveState *st, const LaneConst *lcp
       double y6[6];
       sym_matvec<false>(nullptr, n, rhs, R, y6);
       WSTAMP(2)
-      wave_lds_sync();                                      // (every lane has read rhs / wc)
-      if (R.s == 0 && R.r < NB) {
+      if (R.s == 0 && R.r < NB) {                           // (x~ has a buffer of its own: nothing to wait for)
 #pragma unroll
         for (int j = 0; j < 6; ++j) xt[XT_PAD + 6 * R.r + j] = y6[j];
       }
@@ -878,7 +868,7 @@ __device__ __noinline__ int terminate_test(SolveState *st, const LaneConst *lcp,
 
 // factorise / iterate / test until done (st->done) for one ANYEQ flavour; returns whether every factorisation succeeded
 template <bool ANYEQ>
-__device__ __forceinline__ bool solve_loop(SolveState *st, const LaneConst *lcp, const double *Pg, const double *gw, const double *Gg,
+__device__ __forceinline__ bool solve_loop(SolveState *st, const LaneConst *lcp, const double *Pg, const double *pb, const double *gw, const double *Gg,
                                            const double *qv, const double *Dv, int N, double cs, IterSettings o, const Role &R) {
   double *const xt = s_w + XT_OFF;
   const int kx = 3 * R.istep;
@@ -908,11 +898,228 @@ __device__ __forceinline__ bool solve_loop(SolveState *st, const LaneConst *lcp,
       WSTAMPK(13, 15)
       st->it += nrun; st->to_check -= nrun;
       if (st->to_check == 0) st->to_check = o.check_every;
-      refactor = terminate_test<ANYEQ>(st, lcp, Pg, Gg, qv, Dv, N, o) != 0;
+      refactor = terminate_test<ANYEQ>(st, lcp, pb, Gg, qv, Dv, N, o) != 0;
       WSTAMPK(9, 11)
     }
   }
   return ok;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Ruiz equilibration (OSQP scaling.c:scale_data; f16_mpc_solve.hip: ruiz_equilibrate, rule for rule) in this one wavefront.
+// Norms of the scaled matrices are formed from the ORIGINAL entries and the running D, E, c:
+//   rows / columns of Pb = c D P D   the block image of P with (max, x) in place of (+, x): direct and transposed use of each block
+//   columns of Ab = E A D            the stage-1 pattern on |G_d| (all NINE state rows: rows without bounds are rows of A as OSQP
+//   rows of Ab                       sees it) and E;  the stage-3 pattern on |G_d| and D
+// Ownership as in the iterations (lane (o, t): step istep, variables 3 istep + c, kept rows 3h + c, command or rate rows), plus
+// the rows without bounds of that step: phi, theta on the even lane of a pair, lf1 on the odd one.
+// LDS: the nine-row G image at GL_OFF (prologue); D behind 7 zero steps in the x~ buffer; E of the state rows, 10 doubles per
+// step, in the state-row buffer; E of command / rate rows in theirs; row norms of P behind the G image.
+constexpr int NPM_OFF = 840, E9_REC = 10;
+struct RuizOut { double De[3], EA[3], EB[3], cs; };
+
+template <bool IS_MAX>
+__device__ __forceinline__ double octet_allreduce(double v) {
+  auto op = [](double a, double b) { return IS_MAX ? fmax(a, b) : a + b; };
+  v = op(v, dpp<DPP_XOR1>(v));
+  v = op(v, dpp<DPP_XOR2>(v));
+  v = op(v, dpp<DPP_HMIRROR>(v));
+  return v;
+}
+
+// npm[k] = D_k max_j |P_kj| D_j for every variable (natural order, LDS) from the block image of P in HBM and D in LDS
+__device__ __forceinline__ void p_row_norms(const double *pb, const double *Dn, double *npm, const Role &R) {
+  typedef double dbl2_t __attribute__((ext_vector_type(2)));
+  typedef const dbl2_t __attribute__((address_space(1))) *g2ptr_t;
+  const g2ptr_t pp = (g2ptr_t)pb + R.l;
+  const int rr = R.r < NB ? R.r : NB - 1;
+  double A[6][6], Bk[6][6];
+#pragma unroll
+  for (int m = 0; m < 18; ++m) {
+    const dbl2_t a = pp[m * 64], b = pp[(18 + m) * 64];
+    A[(2 * m) / 6][(2 * m) % 6] = fabs(a.x); A[(2 * m + 1) / 6][(2 * m + 1) % 6] = fabs(a.y);
+    Bk[(2 * m) / 6][(2 * m) % 6] = fabs(b.x); Bk[(2 * m + 1) / 6][(2 * m + 1) % 6] = fabs(b.y);
+  }
+  double dr[6], da[6], db[6];
+#pragma unroll
+  for (int m = 0; m < 6; ++m) { dr[m] = Dn[6 * rr + m]; da[m] = Dn[6 * R.cA + m]; db[m] = Dn[6 * R.cB + m]; }
+  double md[6], mtA[6], mtB[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double m0 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) m0 = fmax(m0, fmax(A[i][j] * da[j], Bk[i][j] * db[j]));
+    md[i] = m0;
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { m0 = fmax(m0, A[i][j] * dr[i]); m1 = fmax(m1, Bk[i][j] * dr[i]); }
+    mtA[j] = m0; mtB[j] = m1;
+  }
+  const int srcA = 4 * ((rr + 2 * R.s + 1) % NB) + R.s, srcB = 4 * ((rr + 2 * R.s + 2) % NB) + R.s;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const double pa = bperm(mtA[j], srcA), pb_ = bperm(mtB[j], srcB);
+    double m = fmax(md[j], fmax(pa, R.s < 3 ? pb_ : 0.0));
+    m = fmax(m, dpp<DPP_XOR1>(m));
+    m = fmax(m, dpp<DPP_XOR2>(m));
+    if (R.s == 0 && R.r < NB) npm[6 * R.r + j] = dr[j] * m;
+  }
+}
+
+__device__ __noinline__ void ruiz_wave(const double *pb, const double *qv, int N, int passes, RuizOut *out) {
+  const Role R = role(N);
+  const int n = 3 * N, kx = 3 * R.istep, kxa = R.act ? kx : 0;
+  const bool wrx = R.act && R.par == 0;
+  const double *Gl = s_w + GL_OFF;
+  double *const Dz = s_w + XT_OFF, *const Dn = Dz + XT_PAD;        // D: zero-padded / natural order views of one buffer
+  double *const E9 = s_w + WS_OFF, *const Ec = s_w + WC_OFF, *const Er = s_w + WR_OFF, *const npm = s_w + NPM_OFF;
+  double De[3] = {1.0, 1.0, 1.0}, EA[3] = {1.0, 1.0, 1.0}, EB[3] = {1.0, 1.0, 1.0}, EU[2] = {1.0, 1.0}, cs = 1.0;
+  double qa[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) qa[c] = fabs(as_global(qv)[kxa + c]);
+  // MPC state rows of the lane's slots: kept rows 3h + c; without bounds: phi, theta (even lane), lf1 (odd lane)
+  int rowA[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { const int kk = 3 * R.h + c; rowA[c] = kk < 5 ? kk + 2 : 8; }
+  const int rowU0 = R.par ? 7 : 0, rowU1 = R.par ? 7 : 1;
+  // D = E = 1 inside the problem, 0 outside (the buffers are zero)
+  if (R.act) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { E9[E9_REC * R.istep + rowA[c]] = 1.0; (R.par ? Er : Ec)[kx + c] = 1.0; }
+    E9[E9_REC * R.istep + rowU0] = 1.0; E9[E9_REC * R.istep + rowU1] = 1.0;
+    if (R.par == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Dn[kx + c] = 1.0;
+    }
+  }
+  wave_lds_sync();
+  p_row_norms(pb, Dn, npm, R);
+  wave_lds_sync();
+  const int base1 = 4 * (R.o + R.t), wb = base1 < N ? base1 : N;          // first operand step of the stage-1 pattern
+  const int s0 = 4 * (R.o - R.t) - 3, sb = s0 > -7 ? s0 : -7;              // ... of the stage-3 pattern
+  for (int pass = 0; pass < passes; ++pass) {
+    // column norms of the state block of Ab before the D of the column (col[e][c], step 4o + e) and row norms before the E of
+    // the row (row[e][r], all nine rows), this lane's four lags; then the maxima over the octet
+    double col[4][3], row[4][9];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) col[e][c] = 0.0;
+#pragma unroll
+      for (int r9 = 0; r9 < 9; ++r9) row[e][r9] = 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int d = 4 * R.t + u;
+      const double *gp = Gl + 27 * (d < N ? d : N);                         // (block N is zero)
+      double ag[9][3];
+#pragma unroll
+      for (int r9 = 0; r9 < 9; ++r9)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ag[r9][c] = fabs(gp[3 * r9 + c]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double *ep = E9 + E9_REC * (wb + e + u);                      // E of step 4(o + t) + e + u
+        const double *dp = Dz + 3 * (sb + 7 + e - u + 3);                   // D of step 4(o - t) + e - u
+        double ev[9], dv[3];
+#pragma unroll
+        for (int r9 = 0; r9 < 9; ++r9) ev[r9] = ep[r9];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dv[c] = dp[c];
+#pragma unroll
+        for (int r9 = 0; r9 < 9; ++r9)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            col[e][c] = fmax(col[e][c], ag[r9][c] * ev[r9]);
+            row[e][r9] = fmax(row[e][r9], ag[r9][c] * dv[c]);
+          }
+      }
+    }
+    double colS[3] = {0.0, 0.0, 0.0}, rowS[9];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { const double v = octet_allreduce<true>(col[e][c]); colS[c] = R.estar == e ? v : colS[c]; }
+#pragma unroll
+      for (int r9 = 0; r9 < 9; ++r9) { const double v = octet_allreduce<true>(row[e][r9]); rowS[r9] = (R.estar == e || e == 0) ? v : rowS[r9]; }
+    }
+    auto pick9 = [&](int r) { double v = rowS[0];
+#pragma unroll
+      for (int r9 = 1; r9 < 9; ++r9) v = r == r9 ? rowS[r9] : v;
+      return v; };
+    double Dt[3], EtA[3], EtB[3], EtU[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int k = kxa + c;
+      const double colA = De[c] * fmax(fmax(colS[c], Ec[k]), fmax(Er[k], Er[k + 3]));
+      Dt[c] = 1.0 / sqrt(osqp_limit_scaling(fmax(cs * npm[k], colA)));
+      EtA[c] = 1.0 / sqrt(osqp_limit_scaling(EA[c] * pick9(rowA[c])));
+      const double dk = Dz[XT_PAD + k], dkm = Dz[XT_PAD + k - 3];
+      EtB[c] = 1.0 / sqrt(osqp_limit_scaling(EB[c] * (R.par ? fmax(dk, dkm) : dk)));
+    }
+    EtU[0] = 1.0 / sqrt(osqp_limit_scaling(EU[0] * pick9(rowU0)));
+    EtU[1] = 1.0 / sqrt(osqp_limit_scaling(EU[1] * pick9(rowU1)));
+    wave_lds_sync();                                        // every lane has read the old D and E
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { De[c] *= Dt[c]; EA[c] *= EtA[c]; EB[c] *= EtB[c]; }
+    EU[0] *= EtU[0]; EU[1] *= EtU[1];
+    if (R.act) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { E9[E9_REC * R.istep + rowA[c]] = EA[c]; (R.par ? Er : Ec)[kx + c] = EB[c]; }
+      E9[E9_REC * R.istep + rowU0] = EU[0];
+      if (R.par == 0) {
+        E9[E9_REC * R.istep + rowU1] = EU[1];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Dn[kx + c] = De[c];
+      }
+    }
+    wave_lds_sync();
+    p_row_norms(pb, Dn, npm, R);                            // with the new D: cost scaling now, column norms of the next pass
+    wave_lds_sync();
+    double sm = 0.0, qn = 0.0;
+    if (wrx) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { sm += cs * npm[kx + c]; qn = fmax(qn, cs * De[c] * qa[c]); }
+    }
+    sm = wave_reduce_dpp<true>(sm);
+    qn = wave_reduce_dpp<false>(qn);
+    cs *= 1.0 / fmax(osqp_limit_scaling(sm / n), osqp_limit_scaling(qn));
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { out->De[c] = De[c]; out->EA[c] = EA[c]; out->EB[c] = EB[c]; }
+  out->cs = cs;
+  // leave the buffers as the prologue expects them: zero
+  wave_lds_sync();
+  for (int i = R.l; i < WS_SIZE + WC_SIZE + WR_SIZE + XT_SIZE; i += 64) s_w[WS_OFF + i] = 0.0;
+  for (int i = R.l; i < 96; i += 64) s_w[NPM_OFF + i] = 0.0;
+  wave_lds_sync();
+}
+
+// P (packed lower triangle, workspace of the build kernel) -> its symmetric block image [36][64] double2 (lane-major chunks, as the
+// LDS image of the KKT inverse): 72 gathered elements per lane, once per solve; zero outside the n x n matrix.
+__device__ __noinline__ void p_block_image(const double *Pg, double *pb, int n) {
+  const int l = threadIdx.x;
+  const gptr_t Pgg = as_global(Pg);
+  unsigned ij[72];
+#pragma unroll
+  for (int e = 0; e < 72; ++e) ij[e] = F16_WAVE_PGATH[e * 64 + l];
+  __builtin_amdgcn_sched_barrier(0);
+  double pv[72];
+#pragma unroll
+  for (int e = 0; e < 72; ++e) {
+    const int i = (int)(ij[e] >> 8), j = (int)(ij[e] & 255);
+    pv[e] = Pgg[(i < n && j < n) ? i * (i + 1) / 2 + j : 0];          // (i >= j)
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  double2 *dst = reinterpret_cast<double2 *>(pb) + l;
+#pragma unroll
+  for (int m = 0; m < 36; ++m) {
+    const int i0 = (int)(ij[2 * m] >> 8), j0 = (int)(ij[2 * m] & 255), i1 = (int)(ij[2 * m + 1] >> 8), j1 = (int)(ij[2 * m + 1] & 255);
+    dst[m * 64] = make_double2((i0 < n && j0 < n) ? pv[2 * m] : 0.0, (i1 < n && j1 < n) ? pv[2 * m + 1] : 0.0);
+  }
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -931,21 +1138,43 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
   for (int i = l; i < LDS_DOUBLES; i += 64) s_w[i] = 0.0;
   wave_lds_sync();
   for (int i = l; i < 27 * N; i += 64) s_w[GL_OFF + i] = Gg[i];          // (block N stays zero: what rows beyond 6N gather)
+  double *const pb = a.pblk + (size_t)b * WAVE_PBLK_DOUBLES;
+  p_block_image(Pg, pb, n);                                  // P as the symmetric block image (equilibration, termination test)
+  wave_lds_sync();
+  // ---- equilibration: in this wavefront (default), or D | E | c left in the workspace by k_mpc_fast (mode 3, F16_WAVE_RUIZ=0)
+  const int kx = 3 * R.istep;
+  double *const scalw = gw + GW_SCAL;
+  RuizOut rz;
+  if (a.wave_ruiz) {
+    ruiz_wave(pb, exw, N, a.s.scaling, &rz);
+    if (R.act && R.par == 0) {                               // D of the owned variables: the rho estimate reads it back
+#pragma unroll
+      for (int c = 0; c < 3; ++c) scalw[kx + c] = rz.De[c];
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int k = R.act ? kx + c : 0;
+      rz.De[c] = R.act ? scal[k] : 1.0;
+      rz.EA[c] = R.act ? scal[96 + 6 * R.istep + 3 * R.h + c] : 0.0;
+      rz.EB[c] = R.act ? scal[(R.par ? 384 : 288) + k] : 0.0;
+    }
+    rz.cs = scal[480];
+  }
   // ---- lane constants: owned variables, state rows (step istep, kept rows 3h..3h+2), command / rate rows of the same step
   LaneConst C;
-  const double cs = scal[480];
+  const double cs = rz.cs;
   C.cs = cs; C.cinv = 1.0 / cs;
   C.eqA = 0; C.eqB = 0;
-  const int kx = 3 * R.istep;
   double *const xt = s_w + XT_OFF;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const int k = R.act ? kx + c : 0;
-    const double De = R.act ? scal[k] : 1.0, qe = R.act ? exw[k] : 0.0;
+    const double De = R.act ? rz.De[c] : 1.0, qe = R.act ? exw[k] : 0.0;
     C.sg[c] = a.s.sigma / (De * De); C.cq[c] = cs * qe;
     {   // state row: kept index kk = 3h + c (utils.py:129-133; rows with two infinite bounds are not kept)
       const int kk = 3 * R.h + c;
-      const double Eo = R.act ? scal[96 + 6 * R.istep + kk] : 0.0;
+      const double Eo = R.act ? rz.EA[c] : 0.0;
       const double pm = R.act ? pred[R.istep * 9 + SROW[kk]] : 0.0;
       const double lo = R.act ? SLB[kk] - pm : 0.0, hi = R.act ? SUB[kk] - pm : 0.0;
       const bool eq = R.act && Eo * (hi - lo) < OSQP_RHO_TOL;
@@ -953,7 +1182,7 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
       if (R.act) s_w[WG_OFF + 6 * R.istep + kk] = Eo * Eo * (eq ? OSQP_RHO_EQ_OVER_RHO_INEQ : 1.0);
     }
     {   // command row (par = 0, utils.py:139-140) or rate row (par = 1, utils.py:148-152) of variable k
-      const double Eo = R.act ? scal[(R.par ? 384 : 288) + k] : 0.0;
+      const double Eo = R.act ? rz.EB[c] : 0.0;
       double lo, hi;
       if (R.par == 0) { lo = ULB[c]; hi = UUB[c]; }
       else if (R.istep == 0) {
@@ -997,8 +1226,8 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
   o.alpha = a.s.alpha; o.eps_abs = a.s.eps_abs; o.eps_rel = a.s.eps_rel; o.eps_prim_inf = a.s.eps_prim_inf;
   o.max_iter = a.s.max_iter; o.check_every = a.s.check_every; o.rho_every = a.s.rho_every; o.adaptive_rho = a.s.adaptive_rho;
   const bool anyeq = __ballot((C.eqA | C.eqB) != 0) != 0;      // (wave-uniform)
-  const bool ok = anyeq ? solve_loop<true>(&st, &C, Pg, gw, Gg, exw, scal, N, cs, o, R)
-                        : solve_loop<false>(&st, &C, Pg, gw, Gg, exw, scal, N, cs, o, R);
+  const bool ok = anyeq ? solve_loop<true>(&st, &C, Pg, pb, gw, Gg, exw, scal, N, cs, o, R)
+                        : solve_loop<false>(&st, &C, Pg, pb, gw, Gg, exw, scal, N, cs, o, R);
   const bool converged = st.converged != 0, infeasible = st.infeasible != 0;
   if (wm) {                                                  // keep the solution for the next warm start
     const bool good = converged && !infeasible;
@@ -1042,7 +1271,7 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
 
 bool mpc_wave_enabled(const MpcArgs &a) {
   static const bool off = [] { const char *e = getenv("F16_MPC_WAVE"); return e && e[0] == '0'; }();
-  return !off && a.N >= 1 && a.N <= WAVE_MAXN && a.s.scaling > 0 && a.s.max_iter > 0 && a.gramws != nullptr;
+  return !off && a.N >= 1 && a.N <= WAVE_MAXN && a.s.scaling > 0 && a.s.max_iter > 0 && a.gramws != nullptr && a.pblk != nullptr;
 }
 
 int mpc_wave_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
