@@ -84,9 +84,14 @@ __device__ __forceinline__ double bperm(double v, int src_lane) {
   return __hiloint2double(hi, lo);
 }
 #define WAVE_LDS_PHASE() __builtin_amdgcn_sched_barrier(0x7)      /* memory operations stay put, ALU may float */
-// producer lanes -> consumer lanes of the SAME wavefront through LDS: the LDS queue of a wave is in order; this keeps the
-// compiler from moving accesses across and drains the counter
+// producer lanes -> consumer lanes of the SAME wavefront through LDS: the LDS instructions of one wave execute in order, so a
+// later read sees an earlier write without any wait; all that is needed is that the COMPILER keeps the accesses in order
+// (a wavefront-scope fence: no s_waitcnt, unlike the workgroup-scope one, which drained both counters ~6 times per iteration)
+#ifdef F16_WAVE_SYNC_WORKGROUP
 __device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+#else
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+#endif
 
 struct Role {
   int l, o, t, estar, par, h, b1, b2, istep;   // octet layout: lane (o, t) owns step istep = 4 o + t / 2
