@@ -686,3 +686,45 @@ def test_constraint_checking_horizon_sweep_surface():
     assert tuple(sw.shape) == (4, 3, 42)
     for N in (1, 10, 30, 33, 41, 42):
         assert torch.equal(sw[:, :, N - 1], env._calc_MPC_action(0, 0, 0, N), ), N
+
+
+def test_wavefront_solver_vs_the_512_lane_solver_and_its_equilibration(tmp_path):
+    """The one-wavefront-per-aircraft solver (k_mpc_wave, the default for equilibrated solves up to N = 30) against the
+    512-lane solver (F16_MPC_WAVE=0) on the same QPs: same iteration counts, status words and final rho, input sequences to
+    1e-8 -- the two follow the same rules in different summation orders.  Also with the equilibration done by the 512-lane
+    kernel instead of the wavefront itself (F16_WAVE_RUIZ=0): the wavefront's own Ruiz passes must give the same D, E, c."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    code = r'''
+import json, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from f16_mpc_oop_py_amd import F16Batch
+from f16_mpc_oop_py_amd.workload import config4_states, config2_states
+out = {}
+for name, (x0, u0) in (("c4", config4_states(384)), ("c2", config2_states(192, seed=4))):
+    env = F16Batch(x0, u0, xcg=0.35)
+    env.build_ssr()
+    for N in (30, 29, 17, 6, 1):
+        for st in (None, dict(rho_every=25), dict(adaptive_rho=0, max_iter=300)):
+            u, info = env._calc_MPC_action(0.02, -0.01, 0.0, N, settings=st, return_info=True)
+            out[f"{name}_{N}_{json.dumps(st)}"] = dict(it=info["iters"].cpu().numpy().tolist(), st=info["status"].cpu().numpy().tolist(),
+                                                      rho=info["rho"].cpu().numpy().tolist(), us=info["u_seq"].cpu().numpy().tolist())
+json.dump(out, open(sys.argv[1], "w"))
+''' % REPO
+    res = {}
+    for tag, extra in (("wave", {}), ("fast", {"F16_MPC_WAVE": "0"}), ("wave_ruiz_outside", {"F16_WAVE_RUIZ": "0"})):
+        f = tmp_path / (tag + ".json")
+        r = subprocess.run([sys.executable, "-c", code, str(f)], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[tag] = json.load(open(f))
+    for key, w in res["wave"].items():
+        for other in ("fast", "wave_ruiz_outside"):
+            o = res[other][key]
+            assert w["it"] == o["it"] and w["st"] == o["st"], (key, other)
+            us_w, us_o = np.array(w["us"], dtype=float), np.array(o["us"], dtype=float)
+            assert np.array_equal(np.isnan(us_w), np.isnan(us_o)), (key, other)
+            assert np.nanmax(np.abs(us_w - us_o), initial=0.0) < 1e-8, (key, other, np.nanmax(np.abs(us_w - us_o)))
+            assert np.allclose(w["rho"], o["rho"], rtol=1e-6, atol=0), (key, other)

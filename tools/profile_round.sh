@@ -2,22 +2,27 @@
 # Round profile on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh
 # Separate rocprofv3 passes, as MI355X_MICROARCH.md prescribes: --kernel-trace --stats alone; each --pmc set alone.
 # Output under gpurun_out/prof_*; tools/*_summary.py (run in the build container) turn it into profiles/<tag>_*.
+# The library must be built BEFORE the first rocprofv3 line (load() never compiles: the profiler's preload would make the
+# compiler chain an exec hop of a GPU-initialised process); here only its presence is checked.
 set -e
 export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
+python3 -c 'from f16_mpc_oop_py_amd import lib; lib.load(); print("library ok:", lib.SO_PATH)'
 step() { echo "== $1 ($(date +%T))"; }
 step "kernel-trace + stats of the default bench command"
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_stats -o st -- python3 bench.py --steps 10 --warmup 2 > $O/bench_under_rocprof.json 2> $O/prof_stats.err
+step "kernel-trace + stats of the MPC leg ALONE, headline settings only (B = 4096, N = 30, osqp defaults)"
+rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_stats_mpc -o stm -- python3 tools/gpu_mpc_only.py > $O/prof_stats_mpc.log 2> $O/prof_stats_mpc.err
 step "HBM traffic: FETCH_SIZE, WRITE_SIZE (separate passes), B = 4096 and B = 262,144 rollouts"
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/prof_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mpc --no-config5 > /dev/null 2> $O/prof_fetch.err
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/prof_write -o w -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mpc --no-config5 > /dev/null 2> $O/prof_write.err
-step "MPC kernels: matrix-core and issue counters (osqp-default settings)"
-rocprofv3 --output-format csv --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU \
+step "MPC kernels (headline settings only): matrix-core and issue counters, then LDS pipe + fp64 instruction mix"
+rocprofv3 --output-format csv --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE \
   -d $O/prof_mfma -o m -- python3 tools/gpu_mpc_only.py > $O/prof_mfma.log 2> $O/prof_mfma.err
-rocprofv3 --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 \
+rocprofv3 --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_LDS \
   -d $O/prof_lds -o l -- python3 tools/gpu_mpc_only.py > $O/prof_lds.log 2> $O/prof_lds.err
 step "dynamics kernels: issue counters, then LDS pipe + fp64 instruction mix"
 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT \
