@@ -42,7 +42,8 @@ struct MpcArgs {
   double *bigws;              // horizons beyond MAXN: [B][mpc_big_doubles(N)] seven per-row vectors | packed KKT inverse
   double *gramws;             // [B][MPC_TILE_DOUBLES] A'WA as matrix-core tiles, written by a solve's first factorisation and
                               // re-read by its rho updates (the Gram product does not depend on rho); may be null (recomputed)
-  double *pblk;               // wavefront solver: [B][WAVE_PBLK_DOUBLES] P as the symmetric block image (termination test); plans: the
+  double *pblk;               // wavefront solver: [B][WAVE_PBLK_DOUBLES] P as the symmetric block image (termination test) | the lanes'
+                              // Toeplitz operands [36][64] double2; plans: the
                               // `tiles` block (unused with equilibration)
   int wave_ruiz;              // wavefront solver: equilibrate in the solver itself (else: k_mpc_fast mode 3 went before it)
   int mode;                   // 0 one-shot; 1 prepare (build + factor, keep everything, no iterations); 2 solve from a plan;
@@ -72,7 +73,7 @@ constexpr int MPC_TILE_DOUBLES = 6 * 6 * 4 * 64;   // six tile rows x six tiles 
 // block: A'WA tiles in front, D | E | c of the equilibration (written by k_mpc_fast in mode 3) at WAVE_SCAL_OFF
 constexpr int WAVE_MAXN = 30;
 constexpr int WAVE_SCAL_OFF = 7936;
-constexpr int WAVE_PBLK_DOUBLES = 36 * 64 * 2;
+constexpr int WAVE_PBLK_DOUBLES = 2 * 36 * 64 * 2;      // P block image | per-lane image of the Toeplitz operands
 bool mpc_wave_enabled(const MpcArgs &a);
 int mpc_wave_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream);
 

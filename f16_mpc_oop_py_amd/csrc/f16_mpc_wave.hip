@@ -148,6 +148,32 @@ __device__ __forceinline__ void load_G(double (&Gd)[4][6][3], const double *Gg, 
   }
 }
 
+// The same 72 doubles from the per-lane image the prologue leaves in the workspace ([36][64] double2, lane-major: 36 fully
+// coalesced 16-byte loads instead of 24 strided ones per lane) -- the hot loop and the termination test reload them at every
+// call (~4 k cycles each from the strided layout).
+__device__ __forceinline__ void load_G_image(double (&Gd)[4][6][3], const double *gimg, int l) {
+  typedef double dbl2_t __attribute__((ext_vector_type(2)));
+  typedef const dbl2_t __attribute__((address_space(1))) *g2ptr_t;
+  const g2ptr_t gp = (g2ptr_t)gimg + l;
+  double f[72];
+#pragma unroll
+  for (int m = 0; m < 36; ++m) { const dbl2_t a = gp[m * 64]; f[2 * m] = a.x; f[2 * m + 1] = a.y; }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Gd[u][rr][c] = f[(u * 6 + rr) * 3 + c];
+}
+__device__ __forceinline__ void store_G_image(const double (&Gd)[4][6][3], double *gimg, int l) {
+  double2 *gp = reinterpret_cast<double2 *>(gimg) + l;
+#pragma unroll
+  for (int m = 0; m < 36; ++m) {
+    const int e0 = 2 * m, e1 = 2 * m + 1;
+    gp[m * 64] = make_double2(Gd[e0 / 18][(e0 % 18) / 3][e0 % 3], Gd[e1 / 18][(e1 % 18) / 3][e1 % 3]);
+  }
+}
+
 // stage 1: (CCs' v)_j, j = 4o + e, from the state-row vector in LDS (record of 12 per step); returns the three totals of step
 // istep in BOTH lanes of the pair (t, t ^ 1).  The seven operand steps are a sliding window over the lag u: step m + 4 is
 // fetched under the products of lag m (memory operations keep their order, the arithmetic may float).
@@ -610,7 +636,7 @@ __device__ __noinline__ void run_iterations(SolveState *st, const LaneConst *lcp
   const int n = 3 * N;
   const LaneConst C = *lcp;
   double Gd[4][6][3];
-  load_G(Gd, Gg, R, N);
+  load_G_image(Gd, Gg, R.l);                                // (Gg: the per-lane image)
   double x[3], zA[3], yA[3], zB[3], yB[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) { x[c] = st->x[c]; zA[c] = st->zA[c]; yA[c] = st->yA[c]; zB[c] = st->zB[c]; yB[c] = st->yB[c]; }
@@ -776,7 +802,7 @@ __device__ __noinline__ int terminate_test(SolveState *st, const LaneConst *lcp,
 #pragma unroll
   for (int c = 0; c < 3; ++c) { qu[c] = R.act ? qv[kx + c] : 0.0; cD[c] = C.cs * (R.act ? Dv[kx + c] : 1.0); }
   double Gd[4][6][3];
-  load_G(Gd, Gg, R, N);
+  load_G_image(Gd, Gg, R.l);                                // (Gg: the per-lane image)
   TSTAMP(1)
   double ax3[3], aty3[3], axB[3];
   stage3(Gd, xt, R, ax3);
@@ -1145,6 +1171,12 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
   for (int i = l; i < 27 * N; i += 64) s_w[GL_OFF + i] = Gg[i];          // (block N stays zero: what rows beyond 6N gather)
   double *const pb = a.pblk + (size_t)b * WAVE_PBLK_DOUBLES;
   p_block_image(Pg, pb, n);                                  // P as the symmetric block image (equilibration, termination test)
+  double *const gimg = pb + WAVE_PBLK_DOUBLES / 2;            // the lanes' Toeplitz operands, lane-major
+  {
+    double Gd[4][6][3];
+    load_G(Gd, Gg, R, N);
+    store_G_image(Gd, gimg, l);
+  }
   wave_lds_sync();
   // ---- equilibration: in this wavefront (default), or D | E | c left in the workspace by k_mpc_fast (mode 3, F16_WAVE_RUIZ=0)
   const int kx = 3 * R.istep;
@@ -1231,8 +1263,8 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
   o.alpha = a.s.alpha; o.eps_abs = a.s.eps_abs; o.eps_rel = a.s.eps_rel; o.eps_prim_inf = a.s.eps_prim_inf;
   o.max_iter = a.s.max_iter; o.check_every = a.s.check_every; o.rho_every = a.s.rho_every; o.adaptive_rho = a.s.adaptive_rho;
   const bool anyeq = __ballot((C.eqA | C.eqB) != 0) != 0;      // (wave-uniform)
-  const bool ok = anyeq ? solve_loop<true>(&st, &C, Pg, pb, gw, Gg, exw, scal, N, cs, o, R)
-                        : solve_loop<false>(&st, &C, Pg, pb, gw, Gg, exw, scal, N, cs, o, R);
+  const bool ok = anyeq ? solve_loop<true>(&st, &C, Pg, pb, gw, gimg, exw, scal, N, cs, o, R)
+                        : solve_loop<false>(&st, &C, Pg, pb, gw, gimg, exw, scal, N, cs, o, R);
   const bool converged = st.converged != 0, infeasible = st.infeasible != 0;
   if (wm) {                                                  // keep the solution for the next warm start
     const bool good = converged && !infeasible;
