@@ -15,6 +15,7 @@
 // latencies (~0.15 s) instead of the ~350,000 of the one-evaluation-per-trip form this replaces.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "../../include/f16_hip.h"
 #include "f16_ctx.h"
@@ -31,6 +32,7 @@ struct TrimArgs {
   int fi;
   unsigned flags;
   int maxiter;
+  int fast_forward;     // stop at a fixed point of the iteration and account for the remaining iterations (F16_TRIM_FASTFORWARD=0: run them)
   double xatol, fatol;
   double x0[5];
 };
@@ -185,6 +187,14 @@ __global__ __launch_bounds__(256) void k_trim(TrimArgs a) {
       for (int j = 1; j < 6; ++j) fsh[j] = row_get(fq, 3 + j);
       if (done) continue;
       // ---- scipy _minimize_neldermead, one iteration (nfev: the evaluations the sequential algorithm makes)
+      const int nfev_in = nfev;
+      double sim_in[6][5], fs_in[6];                            // (for the fixed-point test below)
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        fs_in[p] = fs[p];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) sim_in[p][k] = sim[p][k];
+      }
       bool accept = false, shrink = false;
       double xa[5], fa = fxr;
 #pragma unroll
@@ -242,6 +252,24 @@ __global__ __launch_bounds__(256) void k_trim(TrimArgs a) {
         }
         sort_simplex(sim, fs);
       }
+      // A FIXED POINT of the iteration: the simplex and its costs come out bit for bit as they went in.  The iteration is a
+      // deterministic function of (simplex, costs), so every remaining iteration repeats this one: scipy would run them all
+      // to maxiter (env.py:273) and arrive at the same simplex, the same iteration count and nfev + the same increment each
+      // time -- fast-forward instead of spending 50,000 plant evaluations of latency on them.  (Seen where the thrust
+      // command saturates: the cost is flat in P3, the simplex drifts beyond |P3| ~ 4.5e5 where neighbouring doubles are
+      // more than xatol = 1e-10 apart, and a shrink step x0 + 0.5 (xj - x0) of a one-ulp gap rounds back to xj.)
+      bool same = true;
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        same = same && (__double_as_longlong(fs[p]) == __double_as_longlong(fs_in[p]));
+#pragma unroll
+        for (int k = 0; k < 5; ++k) same = same && (__double_as_longlong(sim[p][k]) == __double_as_longlong(sim_in[p][k]));
+      }
+      if (same && a.fast_forward) {
+        const int left = a.maxiter - iters;                   // (the termination test did not fire for this simplex and never will)
+        nfev += left * (nfev - nfev_in);
+        iters = a.maxiter;
+      }
     }
     if (valid && s == 0) {
       // x_trim of env.py:275-290 (unclipped optimiser output; lef from the formula)
@@ -274,6 +302,7 @@ extern "C" int f16_trim_batch(f16_ctx *ctx, const double *h, const double *v, do
   a.status = status; a.B = B; a.ld = ld; a.xcg = xcg; a.fi = fi_flag; a.flags = flags;
   a.maxiter = maxiter > 0 ? maxiter : 50000;        // env.py:273
   a.xatol = 1e-10; a.fatol = 1e-10;                 // tol=1e-10
+  { const char *e = getenv("F16_TRIM_FASTFORWARD"); a.fast_forward = !(e && e[0] == '0'); }
   static const double x0_ref[5] = {5000, -0.09, 8.49, -0.01, 0.01};   // env.py:265-271 (order as passed to minimize)
   for (int k = 0; k < 5; ++k) a.x0[k] = h_x0 ? h_x0[k] : x0_ref[k];
   const long blocks = (B + 15) / 16;       // 16 conditions (16 lanes each) per 256-lane workgroup, one workgroup per CU

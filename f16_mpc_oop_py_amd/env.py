@@ -38,10 +38,13 @@ class F16Batch:
         self.fi_flag = int(fi_flag)
         self.dt = float(dt)
         self.flags = int(flags)
-        x0 = torch.as_tensor(np.atleast_2d(np.asarray(x0, dtype=np.float64)))
+        # host arrays, or tensors already on the device (from_trim: the trim states never leave HBM)
+        as2d = lambda a: (a if a.dim() == 2 else a.unsqueeze(0)).to(torch.float64) if isinstance(a, torch.Tensor) \
+            else torch.as_tensor(np.atleast_2d(np.asarray(a, dtype=np.float64)))
+        x0 = as2d(x0)
         self.B = x0.shape[0]
         assert x0.shape[1] == 18
-        u0 = x0[:, 12:16] if u0 is None else torch.as_tensor(np.atleast_2d(np.asarray(u0, dtype=np.float64)))
+        u0 = x0[:, 12:16] if u0 is None else as2d(u0)
         self._x_init = self._soa(x0)            # x.initial_condition
         self._u_init = self._soa(u0)            # u.initial_condition
         self._x = self._x_init.clone()          # x.values  [18,B]
@@ -78,8 +81,8 @@ class F16Batch:
     def from_trim(cls, h_t, v_t, **kw):
         """env.py:42-44: construct the batch at its trim points (x.initial_condition = trim, u = x[12:16])."""
         tk = {k: kw[k] for k in ("stab_flag", "xcg", "fi_flag", "device", "flags") if k in kw}
-        x, info = cls.trim(h_t, v_t, **tk)
-        env = cls(x.cpu().numpy(), None, context=info["context"], **{k: v for k, v in kw.items() if k != "maxiter"})
+        x, info = cls.trim(h_t, v_t, **tk)            # [B,18] view of the device-resident [18,B] result
+        env = cls(x, None, context=info["context"], **{k: v for k, v in kw.items() if k != "maxiter"})
         env.trim_info = info
         return env
 

@@ -70,3 +70,50 @@ def test_trim_batch_of_flight_conditions_vs_restated_scipy(oracle):
     good = (x[:8, 12] >= 1000) & (x[:8, 12] <= 19000) & (cost[:8] < 1e-4)   # condition 0 cannot be trimmed (idle thrust too high)
     assert good.sum() >= 5
     assert np.abs(xd[good][:, 6:12]).max() < 1e-2          # trimmed: accelerations ~ 0
+
+
+def test_fixed_point_fast_forward_gives_the_results_of_running_to_maxiter(monkeypatch):
+    """A condition whose Nelder-Mead iteration reaches a FIXED POINT (simplex and costs bit for bit unchanged by an
+    iteration) would repeat it until scipy's maxiter = 50,000 (env.py:273); the kernel accounts for the remaining iterations
+    instead of running them.  Same trim states, costs, iteration counts, evaluation counts and status words as the full run
+    (F16_TRIM_FASTFORWARD=0), bit for bit, on the bench's 4096 random flight conditions (19 of them cannot be trimmed)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    code = r'''
+import sys, time, numpy as np, torch
+sys.path.insert(0, %r)
+from f16_mpc_oop_py_amd import F16Batch
+rng = np.random.default_rng(7)
+h = rng.uniform(5e3, 3e4, 4096); v = rng.uniform(450.0, 800.0, 4096)
+F16Batch.trim(h[:64], v[:64])
+torch.cuda.synchronize(); t0 = time.perf_counter()
+x, info = F16Batch.trim(h, v)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+np.savez(sys.argv[1], x=x.cpu().numpy(), cost=info["cost"].cpu().numpy(), iters=info["iters"].cpu().numpy(),
+         nfev=info["nfev"].cpu().numpy(), status=info["status"].cpu().numpy(), dt=dt)
+''' % REPO
+    import tempfile
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for tag, ff in (("ff", "1"), ("full", "0")):
+            f = os.path.join(d, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, F16_TRIM_FASTFORWARD=ff), capture_output=True,
+                               text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            out[tag] = dict(np.load(f))
+    for k in ("x", "cost", "iters", "nfev", "status"):
+        assert np.array_equal(out["ff"][k], out["full"][k], equal_nan=True), k
+    assert int((out["full"]["iters"] >= 50000).sum()) >= 10          # the workload does contain conditions that run to maxiter
+    assert float(out["ff"]["dt"]) < 0.5 * float(out["full"]["dt"]), (float(out["ff"]["dt"]), float(out["full"]["dt"]))
+
+
+def test_from_trim_keeps_the_trim_states_on_the_device():
+    import torch
+    from f16_mpc_oop_py_amd import F16Batch
+    h, v = np.array([10000.0, 15000.0, 20000.0]), np.array([700.0, 600.0, 650.0])
+    env = F16Batch.from_trim(h, v)
+    x, _ = F16Batch.trim(h, v)
+    assert env._x.is_cuda and torch.equal(env.x_values, x) and torch.equal(env.u_values, x[:, 12:16])
