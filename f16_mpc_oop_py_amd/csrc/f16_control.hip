@@ -1027,11 +1027,17 @@ static int mpc_work_alloc(f16_ctx *ctx, MpcArgs &a, bool with_ext, void *stream,
   const size_t need = (np + (with_ext ? mpc_ext_doubles(a.N) : 0) + (with_gram ? MPC_TILE_DOUBLES : 0) + (big ? mpc_big_doubles(a.N) : 0) +
                        (with_pblk ? WAVE_PBLK_DOUBLES : 0)) * (size_t)a.B * sizeof(double);
   *block = nullptr;
-  // Not under stream capture: replays of a graph holding these stream-ordered allocation / free nodes were measured to
-  // return wrong results intermittently on ROCm 7.2 (the workspace is not stable across replays).  A prepared plan owns its
-  // workspace for its lifetime and IS capturable (f16_mpc_plan_solve; tests).
+  // Not under stream capture.  Root cause established in round 3 (profiles/r03_capture_pool.log, r03_capture_probe.log): on
+  // ROCm 7.2 a graph that holds a stream-ordered allocation (mem-alloc node ... mem-free node) is not safe beside EAGER
+  // allocations from the same pool -- tools/micro/capture_pool.hip, plain HIP with none of this library's kernels, sees its
+  // graph-owned block overwritten by an eager block of another stream; tools/gpu_capture_probe.py replays the one-shot call
+  // with no host state in the capture (F16_MPC_DISPATCH_ORDER=0): every replay is bit-identical to the eager call EXCEPT the
+  // ones with an eager call of the same context enqueued behind them (NaN in 20-200 of 256 aircraft), with either solver.
+  // The fault is the runtime's, not in what the capture bakes in; the refusal stays.  A prepared plan owns its workspace for
+  // its lifetime and IS capturable (f16_mpc_plan_solve; tests).
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+  static const bool allow_capture = [] { const char *e = getenv("F16_MPC_ALLOW_CAPTURE"); return e && e[0] == '1'; }();   // (diagnosis only: tools/gpu_capture_probe.py)
+  if (!allow_capture && stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
     return set_error(F16_EINVAL, "one-shot MPC calls cannot be captured into a HIP graph (per-call workspace): use f16_mpc_plan_solve");
   if (int rc = hip_check(hipMallocFromPoolAsync(block, need, ctx->pool, (hipStream_t)stream), "hipMallocFromPoolAsync QP workspace")) return rc;
   a.Ppk = (double *)*block;
