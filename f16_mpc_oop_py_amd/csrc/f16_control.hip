@@ -1023,8 +1023,9 @@ static int mpc_lds_opt_in() {
 static int mpc_work_alloc(f16_ctx *ctx, MpcArgs &a, bool with_ext, void *stream, void **block, bool with_gram = false,
                           bool with_pblk = false) {
   const size_t np = (size_t)(3 * a.N) * (3 * a.N + 1) / 2;
-  const bool big = a.N > MAXN;
-  const size_t need = (np + (with_ext ? mpc_ext_doubles(a.N) : 0) + (with_gram ? MPC_TILE_DOUBLES : 0) + (big ? mpc_big_doubles(a.N) : 0) +
+  const bool big = a.N > FAST_MAXN;                    // long horizons: operands in HBM (the workgroup solver; beyond MAXN also the one-wave slow path)
+  const size_t bigd = big ? (mpc_big_ws_doubles(a.N) > mpc_big_doubles(a.N) ? mpc_big_ws_doubles(a.N) : mpc_big_doubles(a.N)) : 0;
+  const size_t need = (np + (with_ext ? mpc_ext_doubles(a.N) : 0) + (with_gram ? MPC_TILE_DOUBLES : 0) + bigd +
                        (with_pblk ? WAVE_PBLK_DOUBLES : 0)) * (size_t)a.B * sizeof(double);
   *block = nullptr;
   // Not under stream capture.  Root cause established in round 3 (profiles/r03_capture_pool.log, r03_capture_probe.log): on
@@ -1044,8 +1045,7 @@ static int mpc_work_alloc(f16_ctx *ctx, MpcArgs &a, bool with_ext, void *stream,
   a.ext = with_ext ? a.Ppk + np * (size_t)a.B : nullptr;
   a.gramws = with_gram ? a.Ppk + (np + mpc_ext_doubles(a.N)) * (size_t)a.B : nullptr;
   a.bigws = big ? a.Ppk + (np + (with_ext ? mpc_ext_doubles(a.N) : 0) + (with_gram ? MPC_TILE_DOUBLES : 0)) * (size_t)a.B : nullptr;
-  a.pblk = with_pblk ? a.Ppk + (np + (with_ext ? mpc_ext_doubles(a.N) : 0) + (with_gram ? MPC_TILE_DOUBLES : 0) + (big ? mpc_big_doubles(a.N) : 0)) * (size_t)a.B
-                     : nullptr;
+  a.pblk = with_pblk ? a.Ppk + (np + (with_ext ? mpc_ext_doubles(a.N) : 0) + (with_gram ? MPC_TILE_DOUBLES : 0) + bigd) * (size_t)a.B : nullptr;
   return F16_OK;
 }
 static int mpc_work_free(void *block, void *stream) {
@@ -1086,11 +1086,12 @@ static int mpc_solve_dispatch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
 }
 
 // mode 0: generic one-wave kernel (build + ADMM); 1: build only (workspace P, A'A, q|G|pred; *keep receives the block,
-// the caller frees it); 2: build, then the register-resident 512-thread solver (N <= 32).
+// the caller frees it); 2: build, then the register-resident 512-thread solver (N <= 32); 3: build, then the 1024-lane workgroup
+// solver for long horizons (N > 32, f16_mpc_big.hip).
 static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream, int mode, void **keep = nullptr) {
   const int N = a.N;
   const bool big = N > MAXN;
-  if (N < 1 || N > BIG_MAXN || (big && mode == 2)) return set_error(F16_EINVAL, "horizon must be 1..150 (plans: 1..32)");
+  if (N < 1 || N > BIG_MAXN || (N > FAST_MAXN && mode == 2)) return set_error(F16_EINVAL, "horizon must be 1..150 (plans: 1..40)");
   const size_t lds = mpc_lds_doubles(N, mode != 0, big) * sizeof(double);
   if (lds > 160 * 1024) return set_error(F16_EINVAL, "horizon too large for LDS");
   if (int rc = mpc_lds_opt_in()) return rc;
@@ -1110,6 +1111,11 @@ static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream, int mode, void **k
 #ifdef F16_EXP_STAMPB
     mode = 1;
 #endif
+    if (!rc && mode == 3) {
+      MpcArgs w = a;
+      w.mode = 0;
+      rc = mpc_big_solve_launch(ctx, w, stream);
+    }
     if (!rc && mode == 2) {
       // Dispatch order (see k_plan_order): the reference's closed loops call calc_MPC_action once per step on states that
       // move little, so the iteration counts of the previous call of the same batch size ON THE SAME STREAM predict this
@@ -1146,10 +1152,11 @@ extern "C" int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, c
   // least common multiple)
   if (a.s.adaptive_rho && a.s.rho_every % a.s.check_every != 0)
     return set_error(F16_EINVAL, "bad QP settings: rho_every must be a multiple of check_every");
-  // solver selection: the register-resident solver covers N <= 32; a negative max_iter forces the generic kernel (tests)
-  const bool generic = hzn > FAST_MAXN || a.s.max_iter < 0;
+  // solver selection: N <= 32 the register-resident / one-wavefront solvers, longer horizons the workgroup solver with its
+  // operands in HBM; a negative max_iter forces the generic one-wave kernel (tests: the cross-check of every other solver)
+  const bool generic = a.s.max_iter < 0;
   if (a.s.max_iter < 0) a.s.max_iter = -a.s.max_iter;
-  return mpc_launch(ctx, a, stream, generic ? 0 : 2);
+  return mpc_launch(ctx, a, stream, generic ? 0 : (hzn > FAST_MAXN ? 3 : 2));
 }
 
 // ---- prepared plans: everything of calc_MPC_action that depends on the model only (the reference freezes the model at
@@ -1181,7 +1188,7 @@ static int plan_launch_build(f16_mpc_plan *p, MpcArgs &a, void *stream) {
 extern "C" int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const double *Ad, const double *Bd, const double *Cd,
                                    long B, long ld, int hzn, double dt, const f16_qp_settings *s, void *stream) {
   if (!ctx || !plan || !Ad || !Bd || !Cd || B < 1 || ld < B) return set_error(F16_EINVAL, "bad argument to f16_mpc_plan_create");
-  if (hzn < 1 || hzn > FAST_MAXN) return set_error(F16_EINVAL, "prepared plans need 1 <= hzn <= 32");
+  if (hzn < 1 || hzn > MAXN) return set_error(F16_EINVAL, "prepared plans need 1 <= hzn <= 40");
   f16_mpc_plan *p = new f16_mpc_plan();
   p->ctx = ctx; p->B = B; p->ld = ld; p->N = hzn; p->dt = dt;
   p->warm = nullptr; p->warm_on = false; p->have_prev = false; p->sched = nullptr; p->have_order = false;
@@ -1192,7 +1199,8 @@ extern "C" int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const doub
     return set_error(F16_EINVAL, "bad QP settings (rho_every must be a multiple of check_every)");
   }
   const size_t np = (size_t)(3 * hzn) * (3 * hzn + 1) / 2;
-  const size_t per = np + mpc_ext_doubles(hzn) + 2 * MPC_TILE_DOUBLES;      // P | extras | inverse (scaling = 0) | A'WA
+  const bool wide = hzn > FAST_MAXN;                   // horizons 33..40: the model part is kept, every solve runs the workgroup solver
+  const size_t per = np + mpc_ext_doubles(hzn) + 2 * MPC_TILE_DOUBLES + (wide ? mpc_big_ws_doubles(hzn) : 0);      // P | extras | inverse (scaling = 0) | A'WA | long-horizon operands
   if (int rc = hip_check(hipMalloc(&p->buf, per * (size_t)B * sizeof(double)), "hipMalloc MPC plan")) { delete p; return rc; }
   if (int rc = hip_check(hipMalloc(&p->sched, 2 * (size_t)B * sizeof(int32_t)), "hipMalloc MPC plan")) { (void)hipFree(p->buf); delete p; return rc; }
   MpcArgs &a = p->a;
@@ -1202,12 +1210,13 @@ extern "C" int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const doub
   a.tiles = a.ext + mpc_ext_doubles(hzn) * (size_t)B;
   a.gramws = a.tiles + MPC_TILE_DOUBLES * (size_t)B;
   a.pblk = a.tiles;                                    // (equilibrated plans keep no inverse: the block is the wavefront solver's)
+  a.bigws = wide ? a.gramws + MPC_TILE_DOUBLES * (size_t)B : nullptr;
   a.mode = 1;
   int rc = plan_launch_build(p, a, stream);
   // Without equilibration the start value of rho and the KKT factorisation depend on the model only and are cached too.
   // OSQP's equilibration depends on q (the cost scaling c looks at ||q||, and D, E at c), i.e. on the state of the call:
   // a plan with scaling > 0 keeps the model part (DARE, G_k, P) and redoes equilibration + factorisation per solve.
-  if (!rc && p->s.scaling == 0) rc = mpc_fast_solve_launch(ctx, a, stream);
+  if (!rc && p->s.scaling == 0 && !wide) rc = mpc_fast_solve_launch(ctx, a, stream);
   a.Ad = a.Bd = a.Cd = nullptr;                        // not retained
   if (rc) { (void)hipFree(p->buf); (void)hipFree(p->sched); delete p; return rc; }
   *plan = p;
@@ -1225,8 +1234,11 @@ extern "C" int f16_mpc_plan_solve(f16_mpc_plan *p, const double *x, const double
   a.iters_out = p->sched;
   a.order = p->have_order ? p->sched + p->B : nullptr;
   if (int rc = plan_launch_build(p, a, stream)) return rc;
-  if (p->s.scaling > 0) a.mode = 0;                    // nothing cached beyond the model part: full solver prologue
-  if (int rc = mpc_solve_dispatch(p->ctx, a, stream)) return rc;
+  if (p->s.scaling > 0 || p->N > FAST_MAXN) a.mode = 0;   // nothing cached beyond the model part: full solver prologue
+  if (p->N > FAST_MAXN) {
+    a.warm = nullptr;
+    if (int rc = mpc_big_solve_launch(p->ctx, a, stream)) return rc;
+  } else if (int rc = mpc_solve_dispatch(p->ctx, a, stream)) return rc;
   if (int rc = mpc_plan_order_launch(p->sched, p->sched + p->B, p->B, p->s.check_every, stream)) return rc;
   p->have_order = true;
   p->have_prev = p->warm_on;
@@ -1235,6 +1247,7 @@ extern "C" int f16_mpc_plan_solve(f16_mpc_plan *p, const double *x, const double
 
 extern "C" int f16_mpc_plan_warm_start(f16_mpc_plan *p, int on) {
   if (!p) return set_error(F16_EINVAL, "bad argument to f16_mpc_plan_warm_start");
+  if (on && p->N > FAST_MAXN) return set_error(F16_EINVAL, "warm start needs hzn <= 32 (the long-horizon solver starts cold)");
   if (on && !p->warm) {
     if (int rc = hip_check(hipMalloc(&p->warm, (size_t)p->B * MPC_WARM_DOUBLES * sizeof(double)), "hipMalloc warm start")) return rc;
   }

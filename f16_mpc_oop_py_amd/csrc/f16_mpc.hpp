@@ -77,6 +77,10 @@ constexpr int WAVE_PBLK_DOUBLES = 2 * 36 * 64 * 2;      // P block image | per-l
 bool mpc_wave_enabled(const MpcArgs &a);
 int mpc_wave_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream);
 
+// f16_mpc_big.hip: one 1024-lane workgroup per aircraft, 33 <= N <= 150 (operands in the HBM workspace `bigws`)
+size_t mpc_big_ws_doubles(int N);
+int mpc_big_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream);
+
 // f16_mpc_solve.hip
 constexpr int FAST_MAXN = 32;
 int mpc_fast_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream);

@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.environ.get("F16HIP_SO", os.path.join(HERE, "libf16hip.so"))   # override only for A/B experiments
-SOURCES = ["f16_api.hip", "f16_dynamics.hip", "f16_control.hip", "f16_mpc_solve.hip", "f16_mpc_wave.hip", "f16_trim.hip", "f16_debug.hip", "f16_tables.cpp"]
+SOURCES = ["f16_api.hip", "f16_dynamics.hip", "f16_control.hip", "f16_mpc_solve.hip", "f16_mpc_wave.hip", "f16_mpc_big.hip", "f16_trim.hip", "f16_debug.hip", "f16_tables.cpp"]
 # the expression-exact (F16_STRICT) build of the plant alone: checker-side evidence that the device lookups and the plant
 # reproduce the reference bit for bit where no libm call is involved (tests/test_gpu_dynamics.py); never used by the product
 STRICT_SO_PATH = os.path.join(HERE, "libf16hip_strict.so")

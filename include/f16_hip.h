@@ -144,8 +144,9 @@ int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double
  * equilibration and are then left out of the iteration (OSQP carries them with rho_min = 1e-6; they never bind).
  * Opt-in alternative (the builder's rule, faster on this family of QPs): scaling = 0, rho = 0 -> no equilibration and
  * the start value rho = 2 sqrt(tr P / tr A'A); scaling = 0, rho > 0 -> no equilibration, fixed start value.
- * Horizons: 1 <= hzn <= 150.  hzn <= 32 runs the register-resident solver, hzn <= 40 the LDS-resident one, larger horizons
- * (the reference's own sweep goes to 150, env.py:426-436) a slow path of the same algorithm with its operands in HBM.
+ * Horizons: 1 <= hzn <= 150.  hzn <= 30 (equilibrated solves) runs one wavefront per aircraft, hzn <= 32 the 512-lane
+ * register-resident solver, larger horizons (the reference's own sweep goes to 150, env.py:426-436) one 1024-lane workgroup
+ * per aircraft with the KKT inverse in the HBM workspace (its row stream, 1.6 MB per iteration at hzn = 150, sets the pace).
  * u_seq (may be NULL) gets the full [3*hzn][ld] sequence, info (may be NULL) gets [4][ld] = iterations, r_prim, r_dual
  * (unscaled), rho.
  * Nothing the results depend on is retained between calls: the QP workspace is allocated and freed per call, stream-ordered
@@ -168,7 +169,8 @@ int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double
  * terminal weight, prediction blocks, P; with scaling = 0 also the start value of rho and the inverse of the KKT matrix
  * (73.7 KB per aircraft) -- and f16_mpc_plan_solve does what is left per call: the state-dependent vectors, the
  * iterations and, with OSQP's defaults, equilibration + factorisation (OSQP's scaling looks at q, i.e. at the state of the
- * call).  Results are bit-identical to f16_mpc_batch with the same settings.  hzn <= 32.  (Ad,Bd,Cd) are read during
+ * call).  Results are bit-identical to f16_mpc_batch with the same settings.  hzn <= 40 (33..40: the model part is kept, every solve runs the
+ * long-horizon solver; no warm start there).  (Ad,Bd,Cd) are read during
  * f16_mpc_plan_create only. */
 typedef struct f16_mpc_plan f16_mpc_plan;
 int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const double *Ad, const double *Bd, const double *Cd,

@@ -404,6 +404,25 @@ def test_prepared_plan_is_bit_identical_and_closed_loop(N):
     assert torch.equal(ta, tb)
 
 
+def test_prepared_plan_beyond_the_register_resident_horizons():
+    """Plans accept horizons up to 40: for 33..40 they keep the model part (DARE, prediction blocks, P) and every solve runs the
+    long-horizon workgroup solver -- bit-identical to the one-shot call; warm start is refused there."""
+    from f16_mpc_oop_py_amd import lib
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(48, seed=3)
+    env = make_env(x0, u0, xcg=0.35)
+    env.build_ssr()
+    for N in (33, 36, 40):
+        u1 = env._calc_MPC_action(0.01, 0.0, -0.01, N).clone()
+        env.prepare_MPC(N)
+        u2 = env._calc_MPC_action(0.01, 0.0, -0.01, N, use_plan=True)
+        assert torch.equal(u1, u2, ) or (torch.isnan(u1) == torch.isnan(u2)).all() and torch.equal(torch.nan_to_num(u1), torch.nan_to_num(u2)), N
+    with pytest.raises(lib.F16HipError):
+        env.prepare_MPC(36, warm_start=True)
+    with pytest.raises(lib.F16HipError):
+        env.prepare_MPC(41)
+
+
 def test_plan_warm_start_closed_loop():
     """Opt-in warm start of a prepared plan (OSQP's in-object default; the reference always starts cold): the closed
     loop stays within solver tolerance of the cold-started one and needs fewer iterations per step."""
