@@ -1159,6 +1159,76 @@ extern "C" int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, c
   return mpc_launch(ctx, a, stream, generic ? 0 : (hzn > FAST_MAXN ? 3 : 2));
 }
 
+// The reference's horizon sweep (env.py:426-436: calc_MPC_action(0, 0, 0, N) of the SAME states for N = 1..150) as a
+// throughput call.  Horizons up to FAST_MAXN go through the one-shot path one after the other (milliseconds each); the long
+// ones are built per horizon and then solved by ONE launch of the workgroup solver over every (horizon, aircraft) pair: the
+// iteration counts of this family grow with N and spread widely (N = 150: mean 2,100, max 26,850), so a launch per horizon
+// lasts as long as its slowest aircraft on B of the 256 CUs, while the pairs of all horizons together keep every CU busy.
+// Outputs: u_cmd [hi - lo + 1][3][ld], info [..][4][ld] (may be null), status [..][ld] (may be null; OR-ed into).
+extern "C" int f16_mpc_hzn_sweep(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
+                                 const double *dem, double *u_cmd, double *info, int32_t *status, long B, long ld, int hzn_lo,
+                                 int hzn_hi, double dt, const f16_qp_settings *s, void *stream) {
+  if (!ctx || !Ad || !Bd || !Cd || !x || !dem || !u_cmd || B < 0 || ld < B || hzn_lo < 1 || hzn_hi < hzn_lo || hzn_hi > BIG_MAXN)
+    return set_error(F16_EINVAL, "bad argument to f16_mpc_hzn_sweep (horizons 1..150)");
+  if (B == 0) return F16_OK;
+  f16_qp_settings st;
+  if (s) st = *s; else f16_qp_default_settings(&st);
+  int N = hzn_lo;
+  for (; N <= hzn_hi && (N <= FAST_MAXN || st.max_iter < 0); ++N) {
+    const size_t k = (size_t)(N - hzn_lo);
+    if (int rc = f16_mpc_batch(ctx, Ad, Bd, Cd, x, dem, u_cmd + k * 3 * ld, nullptr, info ? info + k * 4 * ld : nullptr,
+                               status ? status + k * ld : nullptr, B, ld, N, dt, &st, stream)) return rc;
+  }
+  if (N > hzn_hi) return F16_OK;
+  MpcArgs a{};
+  a.Ad = Ad; a.Bd = Bd; a.Cd = Cd; a.x = x; a.dem = dem; a.B = B; a.ld = ld; a.dt = dt; a.s = st;
+  if (a.s.check_every < 1 || a.s.rho_every < 1 || !(a.s.rho >= 0) || !(a.s.sigma > 0) || a.s.scaling < 0 || a.s.scaling > 100 ||
+      (a.s.scaling > 0 && !(a.s.rho > 0)) || (a.s.adaptive_rho && a.s.rho_every % a.s.check_every != 0))
+    return set_error(F16_EINVAL, "bad QP settings");
+  if (int rc = mpc_lds_opt_in()) return rc;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+    return set_error(F16_EINVAL, "f16_mpc_hzn_sweep cannot be captured into a HIP graph (per-call workspace)");
+  // groups of horizons, longest first, each within the workspace budget (N = 150: 3.3 MB per aircraft)
+  static const size_t budget = [] { const char *e = getenv("F16_SWEEP_WS_GB"); const double g = e ? atof(e) : 0; return (size_t)((g > 0 ? g : 32.0) * (1ull << 30)); }();
+  int hi = hzn_hi;
+  while (hi >= N) {
+    int lo = hi;
+    size_t doubles = mpc_big_sweep_job_doubles(hi);
+    while (lo - 1 >= N && (doubles + mpc_big_sweep_job_doubles(lo - 1)) * (size_t)B * sizeof(double) <= budget) doubles += mpc_big_sweep_job_doubles(--lo);
+    void *block = nullptr;
+    const size_t wbytes = doubles * (size_t)B * sizeof(double);
+    if (int rc = hip_check(hipMallocFromPoolAsync(&block, wbytes + 256, ctx->pool, (hipStream_t)stream),
+                           "hipMallocFromPoolAsync sweep workspace")) return rc;
+    unsigned int *next = (unsigned int *)((char *)block + wbytes);      // work-queue counter of the solve launch
+    int rc = hip_check(hipMemsetAsync(next, 0, 256, (hipStream_t)stream), "hipMemsetAsync sweep queue");
+    size_t off = 0;
+    for (int Nn = hi; Nn >= lo && !rc; --Nn) {           // the builds (one wavefront per aircraft each)
+      MpcArgs b = a;
+      const size_t np = (size_t)(3 * Nn) * (3 * Nn + 1) / 2, k = (size_t)(Nn - hzn_lo);
+      b.N = Nn;
+      b.Ppk = (double *)block + off * (size_t)B;
+      b.ext = b.Ppk + np * (size_t)B;
+      b.bigws = b.ext + mpc_ext_doubles(Nn) * (size_t)B;
+      b.ucmd = u_cmd + k * 3 * ld;
+      b.status = status ? status + k * ld : nullptr;
+      const bool big = Nn > MAXN;
+      const size_t lds = mpc_lds_doubles(Nn, true, big) * sizeof(double);
+      if (big) hipLaunchKernelGGL((k_mpc<true, true>), dim3(wave_grid(B)), dim3(64), lds, (hipStream_t)stream, b);
+      else hipLaunchKernelGGL(k_mpc<true>, dim3(wave_grid(B)), dim3(64), lds, (hipStream_t)stream, b);
+      rc = hip_check(hipGetLastError(), "f16_mpc_hzn_sweep build launch");
+      off += mpc_big_sweep_job_doubles(Nn);
+    }
+    if (!rc) rc = mpc_big_sweep_launch(ctx, a, lo, hi, (double *)block, u_cmd + (size_t)(lo - hzn_lo) * 3 * ld,
+                                       info ? info + (size_t)(lo - hzn_lo) * 4 * ld : nullptr,
+                                       status ? status + (size_t)(lo - hzn_lo) * ld : nullptr, next, stream);
+    const int rf = mpc_work_free(block, stream);
+    if (rc || rf) return rc ? rc : rf;
+    hi = lo - 1;
+  }
+  return F16_OK;
+}
+
 // ---- prepared plans: everything of calc_MPC_action that depends on the model only (the reference freezes the model at
 // construction, env.py:49-60, but rebuilds the whole QP on every call) is computed once; a solve then costs the
 // state-dependent vectors + the ADMM iterations.

@@ -80,6 +80,10 @@ int mpc_wave_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream);
 // f16_mpc_big.hip: one 1024-lane workgroup per aircraft, 33 <= N <= 150 (operands in the HBM workspace `bigws`)
 size_t mpc_big_ws_doubles(int N);
 int mpc_big_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream);
+// the same states at every horizon lo..hi in one launch (longest first); per horizon [B][mpc_big_sweep_job_doubles(N)] behind base
+size_t mpc_big_sweep_job_doubles(int N);
+int mpc_big_sweep_launch(f16_ctx *ctx, const MpcArgs &a, int lo, int hi, double *base, double *ucmd, double *info, int32_t *status,
+                         unsigned int *next, void *stream);      // next: the work-queue counter, zero at the launch
 
 // f16_mpc_solve.hip
 constexpr int FAST_MAXN = 32;

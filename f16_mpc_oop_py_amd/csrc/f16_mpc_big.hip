@@ -25,7 +25,10 @@
 namespace f16 {
 namespace big {
 
-constexpr int BLK = 1024, NW = BLK / 64;
+#ifndef F16_BIG_BLK
+#define F16_BIG_BLK 512
+#endif
+constexpr int BLK = F16_BIG_BLK, NW = BLK / 64;
 constexpr int TM = (12 * BIG_MAXN + BLK - 1) / BLK;          // constraint rows per lane (2)
 
 // block-wide reduction of one value (sum, or max of non-negative values); every lane receives the result
@@ -41,13 +44,21 @@ __device__ __forceinline__ double block_reduce(double v, double *red) {
   return r;
 }
 
+// LDS scratch shared by the three products of an iteration: [NW][n] column sums of the symmetric product, or the partial sums of
+// a Toeplitz stage (at most NW + 2 wavefront segments x 64 steps x 6 rows)
+constexpr int TP_SLOTS = NW + 2, TP_FWD = 6 * 64, TP_ADJ = 3 * 64;
+constexpr int SWB = 8;                                   // pivots per block step of the KKT sweep
+__host__ __device__ inline size_t part_doubles(int N) {
+  const size_t a = (size_t)(NW > 2 * SWB ? NW : 2 * SWB) * 3 * N, b = (size_t)TP_SLOTS * TP_FWD;
+  return a > b ? a : b;
+}
 struct Lds {
-  double *G, *qv, *pred, *wbuf, *xs, *xt, *rhs, *tv, *Dg, *E9, *Ec, *Er, *cvec, *red;
+  double *G, *qv, *pred, *wbuf, *xs, *xt, *rhs, *tv, *Dg, *E9, *Ec, *Er, *cvec, *red, *part, *zpad;
 };
 __host__ __device__ inline size_t lds_doubles(int N) {
   const size_t n = 3 * (size_t)N, m = 12 * (size_t)N;
   auto ev = [](size_t v) { return (v + 1) & ~(size_t)1; };
-  return ev(27 * N) + ev(n) + ev(9 * N) + ev(m) + 5 * ev(n) + ev(9 * N) + ev(n) + ev(n + 3) + ev(n) + ev(NW);
+  return ev(27 * N) + ev(n) + ev(9 * N) + ev(m) + 5 * ev(n) + ev(9 * N) + ev(n) + ev(n + 3) + ev(n) + ev(NW) + ev(part_doubles(N)) + 8;
 }
 __device__ __forceinline__ Lds carve(double *p, int N) {
   const int n = 3 * N, m = 12 * N;
@@ -55,79 +66,175 @@ __device__ __forceinline__ Lds carve(double *p, int N) {
   Lds L;
   L.G = take(27 * N); L.qv = take(n); L.pred = take(9 * N); L.wbuf = take(m);
   L.xs = take(n); L.xt = take(n); L.rhs = take(n); L.tv = take(n); L.Dg = take(n);
-  L.E9 = take(9 * N); L.Ec = take(n); L.Er = take(n + 3); L.cvec = take(n); L.red = take(NW);
+  L.E9 = take(9 * N); L.Ec = take(n); L.Er = take(n + 3); L.cvec = take(n); L.red = take(NW); L.part = take((int)part_doubles(N)); L.zpad = take(8);
   return L;
 }
 
-// out[3j+c] = sum_{i>=j} sum_{r in kept rows} G_{i-j}[r][c] * v[i*6 + rr]   (CCs' v); two lanes per output (the steps i of even /
-// odd distance), combined over the DPP network
-__device__ __forceinline__ void conv_adjoint6(double *out, const double *G, const double *v, int N) {
-  for (int e2 = threadIdx.x; e2 < 2 * ((3 * N + 31) & ~31); e2 += BLK) {      // (whole wavefronts: the DPP exchange below)
-    const int e = e2 >> 1, half = e2 & 1;
-    double s = 0.0;
-    if (e < 3 * N) {
-      const int j = e / 3, c = e - 3 * j;
-      for (int i = j + half; i < N; i += 2) {
-        const double *g = G + (i - j) * 27 + c;
-        const double *vi = v + i * 6;
-        double t = 0.0;
+// ---- The two block-Toeplitz products of an iteration, z_i = sum_{j<=i} G_{i-j} u_j (rows SROW) and its adjoint, with LANES
+// ACROSS THE STEPS: at lag d every lane of a wavefront needs the same block G_d -- it comes through the SCALAR cache from the
+// QP workspace (constant address space, uniform address: s_load into SGPRs, which v_fma_f64 reads directly) -- and its own
+// operand step, one LDS read of 3 (forward) or 6 (adjoint) doubles.  The (step block of 64, lag) pairs of the triangle are dealt
+// to the NW wavefronts in equal contiguous shares (a share spans at most two step blocks: TP_SLOTS partial-sum slots); the
+// partial sums go to LDS and are added in slot order by whoever consumes them.  (The first version read both operands of every
+// product from LDS: 18 N^2 eight-byte reads per stage, 3.2 MB at N = 150 -- 27 k + 49 k cycles of a 185 k-cycle iteration.)
+typedef const double __attribute__((address_space(4))) *cgptr_t;
+struct TpPlan { int lo[3], hi[3]; };                     // slots holding the partial sums of step block sb: lo[sb] .. hi[sb]
+template <bool ADJ>
+__device__ __forceinline__ int tp_count(int sb, int N) { return ADJ ? N - 64 * sb : (N < 64 * sb + 64 ? N : 64 * sb + 64); }
+template <bool ADJ>
+__device__ __forceinline__ TpPlan tp_plan(int N) {
+  TpPlan P;
+  const int nb = (N + 63) >> 6;
+  int U = 0;
+  for (int sb = 0; sb < nb; ++sb) U += tp_count<ADJ>(sb, N);
+  int off = 0;
 #pragma unroll
-        for (int rr = 0; rr < 6; ++rr) t += g[SROW[rr] * 3] * vi[rr];
-        s += t;
+  for (int sb = 0; sb < 3; ++sb) {
+    P.lo[sb] = 0; P.hi[sb] = -1;
+    if (sb < nb) {
+      const int c = tp_count<ADJ>(sb, N);
+      int first = -1, last = -1;
+      for (int w = 0; w < NW; ++w) {
+        const int a0 = w * U / NW, a1 = (w + 1) * U / NW;
+        if ((a0 > off ? a0 : off) < (a1 < off + c ? a1 : off + c)) { if (first < 0) first = w; last = w; }
+      }
+      P.lo[sb] = first + sb; P.hi[sb] = last + sb;
+      off += c;
+    }
+  }
+  return P;
+}
+template <bool ADJ>
+__device__ __forceinline__ void tp_partials(double *part, cgptr_t Gc, const double *vec, const double *zpad, int N) {
+  constexpr int SR[6] = {2, 3, 4, 5, 6, 8};               // SROW
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
+  const int nb = (N + 63) >> 6;
+  int U = 0;
+  for (int sb = 0; sb < nb; ++sb) U += tp_count<ADJ>(sb, N);
+  const int u0 = w * U / NW, u1 = (w + 1) * U / NW;
+  int off = 0;
+  for (int sb = 0; sb < nb; ++sb) {
+    const int c = tp_count<ADJ>(sb, N);
+    const int d0 = (u0 > off ? u0 : off) - off, d1 = (u1 < off + c ? u1 : off + c) - off;
+    off += c;
+    if (d0 >= d1) continue;
+    const int i = 64 * sb + l;
+    double acc[ADJ ? 3 : 6];
+#pragma unroll
+    for (int k = 0; k < (ADJ ? 3 : 6); ++k) acc[k] = 0.0;
+    for (int d = d0; d < d1; ++d) {
+      cgptr_t g = Gc + 27 * d;
+      if (ADJ) {
+        const int ii = i + d;
+        const double2 *vp = reinterpret_cast<const double2 *>(ii < N ? vec + 6 * ii : zpad);
+        const double2 a = vp[0], b = vp[1], e = vp[2];
+        const double v[6] = {a.x, a.y, b.x, b.y, e.x, e.y};
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) acc[k] = fma(g[SR[rr] * 3 + k], v[rr], acc[k]);
+      } else {
+        const int idx = i - d;
+        const double *up = (idx >= 0 && i < N) ? vec + 3 * idx : zpad;
+        const double x0 = up[0], x1 = up[1], x2 = up[2];
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) acc[rr] = fma(g[SR[rr] * 3 + 2], x2, fma(g[SR[rr] * 3 + 1], x1, fma(g[SR[rr] * 3], x0, acc[rr])));
       }
     }
-    s += dpp_all_f64<0xB1>(s);                             // quad_perm [1,0,3,2]: the partner lane
-    if (e < 3 * N && half == 0) out[e] = s;
+    double *out = part + (w + sb) * (ADJ ? TP_ADJ : TP_FWD) + l;
+#pragma unroll
+    for (int k = 0; k < (ADJ ? 3 : 6); ++k) out[64 * k] = acc[k];
   }
 }
-// (CC U)[i][r] = sum_{j<=i} sum_c G_{i-j}[r][c] U[3j+c]
-__device__ __forceinline__ double conv_forward_row(const double *G, const double *U, int i, int r) {
+// element (step i, slot k) of a stage's result: the partial sums in slot order
+template <bool ADJ>
+__device__ __forceinline__ double tp_get(const double *part, const TpPlan &P, int i, int k) {
+  const int sb = i >> 6;
+  const int lo = sb == 0 ? P.lo[0] : (sb == 1 ? P.lo[1] : P.lo[2]), hi = sb == 0 ? P.hi[0] : (sb == 1 ? P.hi[1] : P.hi[2]);
+  const double *p = part + k * 64 + (i & 63);
   double s = 0.0;
-  for (int j = 0; j <= i; ++j) {
-    const double *g = G + (i - j) * 27 + r * 3;
-    s += g[0] * U[3 * j] + g[1] * U[3 * j + 1] + g[2] * U[3 * j + 2];
-  }
+  for (int sl = lo; sl <= hi; ++sl) s += p[sl * (ADJ ? TP_ADJ : TP_FWD)];
   return s;
 }
-// y = F v for the full symmetric n x n matrix F in HBM: one wavefront per row, lanes across the columns; FOUR rows per trip,
-// so that 4 x ceil(n / 64) independent loads are in flight instead of one row's (the matrix streams from L2 / HBM: 1.6 MB
-// per product at N = 150 -- with one aircraft per CU this stream, not the arithmetic, is the floor of an iteration)
-__device__ __forceinline__ void full_symv(double *y, const double *F, const double *v, int n) {
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  for (int i0 = w; i0 < n; i0 += 4 * NW) {
-    const int i1 = i0 + NW, i2 = i0 + 2 * NW, i3 = i0 + 3 * NW;
-    const double *r0 = F + (size_t)i0 * n, *r1 = F + (size_t)(i1 < n ? i1 : i0) * n, *r2 = F + (size_t)(i2 < n ? i2 : i0) * n,
-                 *r3 = F + (size_t)(i3 < n ? i3 : i0) * n;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int j = l; j < n; j += 64) {
-      const double vj = v[j];
-      s0 = fma(r0[j], vj, s0); s1 = fma(r1[j], vj, s1); s2 = fma(r2[j], vj, s2); s3 = fma(r3[j], vj, s3);
-    }
-    s0 = wave_reduce_dpp<true>(s0); s1 = wave_reduce_dpp<true>(s1); s2 = wave_reduce_dpp<true>(s2); s3 = wave_reduce_dpp<true>(s3);
-    if (l == 0) {
-      y[i0] = s0;
-      if (i1 < n) y[i1] = s1;
-      if (i2 < n) y[i2] = s2;
-      if (i3 < n) y[i3] = s3;
-    }
-  }
+
+// ---- The symmetric HALF of a matrix as the iteration streams it (the inverse of the KKT matrix for x~ = K^-1 rhs, P for the
+// termination test): row i of the lower triangle padded with zeros to whole 64-column trips (512-byte aligned rows), the
+// diagonal entry HALVED, one 64-double block of zeros behind the last row.  A row then serves y_i += sum_j a_ij v_j and
+// y_j += a_ij v_i with the same unmasked products (the diagonal contributes a_ii v_i / 2 to each), i.e. every entry is read
+// ONCE per product: n^2 / 2 + 32 n doubles instead of n^2 (0.93 MB instead of 1.62 MB at N = 150).
+__host__ __device__ inline size_t hoff(int i) {          // offset of row i
+  const size_t q = (size_t)(i >> 6);
+  return 2048 * q * (q + 1) + ((size_t)i - 64 * q) * (q + 1) * 64;
 }
-// y = S v for a packed symmetric matrix in HBM (termination test: P x): row part contiguous, column part strided
-__device__ __forceinline__ void packed_symv(double *y, const double *S, const double *v, int n) {
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+__host__ __device__ inline size_t half_doubles(int n) { return hoff(n) + 64; }
+// H <- padded half of the packed symmetric matrix S (both in HBM); one wavefront per row
+__device__ __forceinline__ void half_from_packed(double *H, const double *S, int n) {
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
   for (int i = w; i < n; i += NW) {
     const double *row = S + tri(i, 0);
-    double s = 0.0;
-    for (int j = l; j <= i; j += 64) s = fma(row[j], v[j], s);
-    for (int j = i + 1 + l; j < n; j += 64) s = fma(S[tri(j, i)], v[j], s);
-    s = wave_reduce_dpp<true>(s);
-    if (l == 0) y[i] = s;
+    double *out = H + hoff(i);
+    for (int j = l; j < 64 * ((i >> 6) + 1); j += 64) out[j] = j < i ? row[j] : (j == i ? 0.5 * row[j] : 0.0);
+  }
+  if (threadIdx.x < 64) H[hoff(n) + threadIdx.x] = 0.0;
+}
+// y = S v from the padded half H; v, y: LDS [n]; part: LDS [NW][n].  Wavefront w takes rows w, w + NW, ..., R at a time with
+// every load of the R rows issued before the first product (R x KT independent 512-byte loads per wavefront in flight: the
+// stream comes from the Infinity Cache or HBM at 1-3 us of latency); the column part accumulates in registers (lane l: columns
+// l + 64 k) and is summed over the wavefronts in a fixed order at the end.  Ends with y complete and a barrier behind it.
+template <int KT, int R>
+__device__ __forceinline__ void half_symv_t(double *y, const double *H, const double *v, int n, double *part) {
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
+  const double *zeros = H + hoff(n) + l;
+  double vj[KT], acc[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) { const int j = l + 64 * k; vj[k] = j < n ? v[j] : 0.0; acc[k] = 0.0; }
+  for (int i0 = w; i0 < n; i0 += NW * R) {
+    double a[R][KT];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int ir = i0 + NW * r, irc = ir < n ? ir : i0, kr = irc >> 6;
+      const double *row = H + hoff(irc) + l;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) { const double *p = k <= kr ? row + 64 * k : zeros; a[r][k] = *p; }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int ir = i0 + NW * r;
+      const double vi = ir < n ? v[ir] : 0.0;
+      double dot = 0.0;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) { dot = fma(a[r][k], vj[k], dot); acc[k] = fma(a[r][k], vi, acc[k]); }
+      dot = wave_reduce_dpp<true>(dot);
+      if (l == 0 && ir < n) y[ir] = dot;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KT; ++k) { const int j = l + 64 * k; if (j < n) part[w * n + j] = acc[k]; }
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += BLK) {
+    double s = y[j];
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) s += part[ww * n + j];
+    y[j] = s;
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void half_symv(double *y, const double *H, const double *v, int n, double *part) {
+  switch ((n + 63) >> 6) {
+    case 1: half_symv_t<1, 4>(y, H, v, n, part); break;
+    case 2: half_symv_t<2, 4>(y, H, v, n, part); break;
+    case 3: half_symv_t<3, 4>(y, H, v, n, part); break;
+    case 4: half_symv_t<4, 4>(y, H, v, n, part); break;
+    case 5: half_symv_t<5, 4>(y, H, v, n, part); break;
+    case 6: half_symv_t<6, 4>(y, H, v, n, part); break;
+    case 7: half_symv_t<7, 4>(y, H, v, n, part); break;
+    default: half_symv_t<8, 4>(y, H, v, n, part); break;
   }
 }
 // In-place inverse of the packed SPD matrix S (HBM) by the symmetric sweep; c: LDS scratch [n].  Afterwards S = S^-1.
 // One wavefront per row (lanes across the columns j <= i), the pivot column in LDS; returns false on a non-positive pivot.
 __device__ __forceinline__ bool sweep_inverse_packed(double *S, int n, double *c) {
-  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
   bool ok = true;
   for (int k = 0; k < n; ++k) {
     __syncthreads();                                      // the previous step's updates are done (block scope: also visible)
@@ -156,24 +263,179 @@ __device__ __forceinline__ bool sweep_inverse_packed(double *S, int n, double *c
   return ok;
 }
 
-// per-aircraft HBM workspace of this solver (MpcArgs.bigws): Gram packed | K / inverse packed | inverse full
-__host__ __device__ inline size_t ws_doubles(int N) {
-  const size_t n = 3 * (size_t)N;
-  return n * (n + 1) + n * n;
+// In-place inverse of the packed SPD matrix S (HBM) by the symmetric sweep, SWB pivots per step.  Sweeping the pivot set K of a
+// symmetric matrix [[A, B'], [B, C]] (A = S_KK) gives [[-A^-1, A^-1 B'], [B A^-1, C - B A^-1 B']] -- the composition of the
+// scalar sweeps on its members -- so a step reads and writes the matrix ONCE for SWB pivots (the scalar version, one pass per
+// pivot, spent 25 ms per factorisation at N = 150: 450 read-modify-write passes over 0.8 MB through one CU):
+//   1. panel c_i = S_iK for every row i (LDS, p-major);  2. A^-1 by every wavefront for itself in registers (lane = entry of the
+//   8 x 8 block, scalar sweeps over ds_bpermute / readlane);  3. T = c A^-1 (LDS, q-major);  4. S_ij -= T_i . c_j for i, j outside
+//   K: one wavefront per row, lanes across the columns, the lane's c_j in registers for all rows of a column trip, four rows per
+//   trip in flight;  5. S_iK = T_i, S_KK = -A^-1.
+// cp, tp: LDS [SWB][n] each.  Afterwards S = S^-1; returns false on a non-positive pivot.
+__device__ __forceinline__ bool sweep_inverse_blocked(double *S, int n, double *cp, double *tp) {
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
+  bool ok = true;
+  for (int k0 = 0; k0 < n; k0 += SWB) {
+    const int nb = n - k0 < SWB ? n - k0 : SWB;
+    __syncthreads();                                      // the previous step's stores are done (block scope: also visible)
+    // 1. the panel: rows above the block from the block's own rows (contiguous), rows from the block on from theirs (nb each)
+    for (int e = threadIdx.x; e < nb * k0; e += BLK) {
+      const int p = e / k0, i = e - p * k0;
+      cp[p * n + i] = S[tri(k0 + p, i)];
+    }
+    for (int e = threadIdx.x; e < (n - k0) * nb; e += BLK) {
+      const int i = k0 + e / nb, p = e - (i - k0) * nb, k = k0 + p;
+      cp[p * n + i] = i >= k ? S[tri(i, k)] : S[tri(k, i)];
+    }
+    __syncthreads();
+    // 2. A^-1 (every wavefront the same arithmetic): lane (r, c) of the 8 x 8 block, identity outside nb
+    const int r = l >> 3, c = l & 7;
+    double v = (r < nb && c < nb) ? cp[c * n + k0 + r] : (r == c ? 1.0 : 0.0);
+    for (int p = 0; p < nb; ++p) {
+      const double app = __shfl(v, 9 * p), arp = __shfl(v, 8 * r + p), apc = __shfl(v, 8 * p + c);
+      if (!(app > 0.0)) ok = false;
+      const double d = 1.0 / app;
+      v = r == p ? (c == p ? -d : apc * d) : (c == p ? arp * d : v - arp * d * apc);
+    }
+    v = -v;                                               // A^-1 (rows / columns beyond nb: identity, never used)
+    // 3. T = c A^-1
+    for (int ib = 0; ib < n; ib += BLK) {                 // (whole wavefronts: the shuffles read lanes 0..63)
+      const int ii = ib + threadIdx.x, i = ii < n ? ii : n - 1;
+      double ci[SWB], ti[SWB];
+#pragma unroll
+      for (int p = 0; p < SWB; ++p) { ci[p] = p < nb ? cp[p * n + i] : 0.0; ti[p] = 0.0; }
+#pragma unroll
+      for (int p = 0; p < SWB; ++p)
+#pragma unroll
+        for (int q = 0; q < SWB; ++q) ti[q] = fma(ci[p], __shfl(v, 8 * p + q), ti[q]);
+      if (ii < n) {
+#pragma unroll
+        for (int q = 0; q < SWB; ++q) tp[q * n + i] = ti[q];
+      }
+    }
+    __syncthreads();
+    // 4. the rows outside K
+    for (int kt = 0; 64 * kt < n; ++kt) {
+      const int j = l + 64 * kt;
+      const bool jout = j < n && !(j >= k0 && j < k0 + nb);
+      double cj[SWB];
+#pragma unroll
+      for (int p = 0; p < SWB; ++p) cj[p] = j < n ? cp[p * n + j] : 0.0;
+      static_assert(64 % NW == 0, "rows w, w + NW, ... of a wavefront: the first one from 64 kt on is 64 kt + w");
+      for (int i0 = 64 * kt + w; i0 < n; i0 += 4 * NW) {
+        double val[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * NW;
+          on[u] = i < n && !(i >= k0 && i < k0 + nb) && jout && j <= i;
+          val[u] = S[on[u] ? tri(i, j) : 0];                 // (unconditional: a load under a lane condition becomes a branch)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * NW < n ? i0 + u * NW : i0;
+#pragma unroll
+          for (int q = 0; q < SWB; ++q) val[u] = fma(-tp[q * n + i], cj[q], val[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (on[u]) S[tri(i0 + u * NW, j)] = val[u];
+      }
+    }
+    // 5. the block's rows and columns
+    for (int e = threadIdx.x; e < nb * k0; e += BLK) {
+      const int p = e / k0, i = e - p * k0;
+      S[tri(k0 + p, i)] = tp[p * n + i];
+    }
+    for (int e = threadIdx.x; e < (n - k0 - nb) * nb; e += BLK) {
+      const int i = k0 + nb + e / nb, q = e - (i - k0 - nb) * nb;
+      S[tri(i, k0 + q)] = tp[q * n + i];
+    }
+    if (w == 0 && r < nb && c <= r) S[tri(k0 + r, k0 + c)] = -v;
+    __threadfence_block();
+  }
+  __syncthreads();
+  const int np = n * (n + 1) / 2;
+  for (int e = threadIdx.x; e < np; e += BLK) S[e] = -S[e];
+  __threadfence_block();
+  __syncthreads();
+  return __syncthreads_and(ok) != 0;
 }
 
-__global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a) {
+// per-aircraft HBM workspace of this solver (MpcArgs.bigws): Gram packed | K / inverse packed | padded half of the inverse |
+// padded half of P
+__host__ __device__ inline size_t ws_doubles(int N) {
+  const size_t n = 3 * (size_t)N;
+  return n * (n + 1) + 2 * half_doubles((int)n);
+}
+
+// A sweep over horizons lo..hi in ONE launch (env.py:426-436 solves the same states for every N): workgroup w solves aircraft
+// w % B at horizon hi - w / B -- longest horizons first, so that the hardware's in-order dispatch packs the short solves
+// behind the long ones.  Every horizon has its own workspace [B][np] P | [B][ext] | [B][ws] behind `base` (written by its build
+// launch) and its own slice of the outputs ([hi - lo + 1][3][ld] commands, [..][4][ld] info, [..][ld] status words).
+struct SweepArgs {
+  int lo, hi;                 // hi = 0: not a sweep
+  double *base;
+  double *ucmd, *info;
+  int32_t *status;
+  unsigned int *next;         // work queue: the next (horizon, aircraft) pair not yet taken (zeroed before the launch)
+};
+__host__ __device__ inline size_t sweep_job_doubles(int N) {      // per aircraft
+  const size_t n = 3 * (size_t)N;
+  return n * (n + 1) / 2 + mpc_ext_doubles(N) + ws_doubles(N);
+}
+
+__global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int N = a.N, n = 3 * N, np = n * (n + 1) / 2, ms = 6 * N, m = 12 * N;
   const int l = threadIdx.x;
-  const Lds L = carve(smem, N);
-  double *G = L.G, *qv = L.qv, *pred = L.pred, *wbuf = L.wbuf, *xs = L.xs, *xt = L.xt, *rhs = L.rhs, *tv = L.tv, *Dg = L.Dg,
-         *E9 = L.E9, *Ec = L.Ec, *Er = L.Er;
-  for (long b = blockIdx.x; b < a.B; b += gridDim.x) {
+  const long total = sw.hi ? (long)(sw.hi - sw.lo + 1) * a.B : a.B;
+  __shared__ unsigned int s_next;
+  for (long w = blockIdx.x;; w += gridDim.x) {
+    if (sw.hi) {
+      // The pairs of a sweep are TAKEN from a queue by as many workgroups as the chip holds, not dealt out by the launch: workgroup
+      // ids go to the XCDs round-robin and are dispatched in order, so one XCD full of long solves stalls the dispatch for all
+      // (measured: 200 of 256 CUs busy on average, the XCD of the hard aircraft 3 x longer than the rest before the rotation below)
+      __syncthreads();
+      if (l == 0) s_next = atomicAdd(sw.next, 1u);
+      __syncthreads();
+      w = s_next;
+    }
+    if (w >= total) break;
+    long b = w;
+    if (sw.hi) {
+      const int j = (int)(w / a.B);
+      b = (w - (long)j * a.B + j) % a.B;                   // rotated per horizon: workgroup ids map to XCDs round-robin, and
+                                                           // how hard an aircraft is repeats from horizon to horizon -- without
+                                                           // the rotation the XCD of the hard ones worked 3 x longer than the rest
+      a.N = sw.hi - j;
+      size_t off = 0;
+      for (int Nn = sw.hi; Nn > a.N; --Nn) off += sweep_job_doubles(Nn);
+      const size_t npj = (size_t)(3 * a.N) * (3 * a.N + 1) / 2;
+      a.Ppk = sw.base + off * (size_t)a.B;
+      a.ext = a.Ppk + npj * (size_t)a.B;
+      a.bigws = a.ext + mpc_ext_doubles(a.N) * (size_t)a.B;
+      const size_t k = (size_t)(a.N - sw.lo);
+      a.ucmd = sw.ucmd + k * 3 * (size_t)a.ld;
+      a.info = sw.info ? sw.info + k * 4 * (size_t)a.ld : nullptr;
+      a.status = sw.status ? sw.status + k * (size_t)a.ld : nullptr;
+      a.useq = nullptr; a.iters_out = nullptr;
+    }
+#ifdef F16_EXP_STAMPG
+    const unsigned long long wc0 = wall_clock64();
+#endif
+    const int N = a.N, n = 3 * N, np = n * (n + 1) / 2, ms = 6 * N, m = 12 * N;
+    const Lds L = carve(smem, N);
+    double *G = L.G, *qv = L.qv, *pred = L.pred, *wbuf = L.wbuf, *xs = L.xs, *xt = L.xt, *rhs = L.rhs, *tv = L.tv, *Dg = L.Dg,
+           *E9 = L.E9, *Ec = L.Ec, *Er = L.Er;
     const double *exw = a.ext + (size_t)b * mpc_ext_doubles(N);
     const double *Pg = a.Ppk + (size_t)b * np;
-    double *const gram = a.bigws + (size_t)b * ws_doubles(N), *const Minv = gram + np, *const Full = Minv + np;
+    double *const gram = a.bigws + (size_t)b * ws_doubles(N), *const Minv = gram + np, *const Hinv = Minv + np,
+                 *const HP = Hinv + half_doubles(n);
     __syncthreads();
+    if (l < 8) L.zpad[l] = 0.0;
+    const cgptr_t Gc = (cgptr_t)(exw + n);                  // G_k of the workspace through the scalar cache
+    const TpPlan planF = tp_plan<false>(N), planA = tp_plan<true>(N);
+    double *const part = L.part;
     for (int e = l; e < n; e += BLK) qv[e] = exw[e];
     for (int e = l; e < 27 * N; e += BLK) G[e] = exw[n + e];
     for (int e = l; e < 9 * N; e += BLK) pred[e] = exw[n + 27 * N + e];
@@ -265,7 +527,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a) {
     const double cinv = 1.0 / cs;
     // ---------------- A'WA, packed, once (it does not depend on rho): one wavefront per row of the lower triangle
     {
-      const int w = l >> 6, ll = l & 63;
+      const int w = __builtin_amdgcn_readfirstlane(l >> 6), ll = l & 63;
       for (int ia = w; ia < n; ia += NW) {
         const int ja = ia / 3, ca = ia - 3 * ja;
         for (int ib = ll; ib <= ia; ib += 64) {
@@ -294,7 +556,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a) {
     auto build_minv = [&](double r) {                     // Full <- (c P + sigma D^-2 + r A'WA)^-1
       __syncthreads();
       {
-        const int w = l >> 6, ll = l & 63;
+        const int w = __builtin_amdgcn_readfirstlane(l >> 6), ll = l & 63;
         for (int ia = w; ia < n; ia += NW)
           for (int ib = ll; ib <= ia; ib += 64) {
             const int e = tri(ia, ib);
@@ -302,16 +564,17 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a) {
           }
       }
       __threadfence_block();
+#ifdef F16_BIG_SCALAR_SWEEP
       const bool good = sweep_inverse_packed(Minv, n, L.cvec);
-      {
-        const int w = l >> 6, ll = l & 63;
-        for (int i = w; i < n; i += NW)
-          for (int j = ll; j < n; j += 64) Full[(size_t)i * n + j] = i >= j ? Minv[tri(i, j)] : Minv[tri(j, i)];
-      }
+#else
+      const bool good = sweep_inverse_blocked(Minv, n, L.part, L.part + SWB * n);
+#endif
+      half_from_packed(Hinv, Minv, n);
       __threadfence_block();
       __syncthreads();
       return __syncthreads_and(good) != 0;
     };
+    half_from_packed(HP, Pg, n);
     bool ok = build_minv(rho);
     for (int e = l; e < n; e += BLK) xs[e] = 0.0;
     __syncthreads();
@@ -319,11 +582,18 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a) {
     double rp = INFINITY, rd = INFINITY;
     bool converged = false, infeasible = false;
     bool done = !ok || a.s.max_iter <= 0;
-    auto adjoint = [&](const double *wv_, int e) {        // (A' w)_e for w in the [6N | 3N | 3N] layout, tv = CCs' w_s
-      return tv[e] + wv_[ms + e] + (wv_[ms + n + e] - (e + 3 < n ? wv_[ms + n + e + 3] : 0.0));
+    auto adjoint = [&](const double *wv_, int e) {        // (A' w)_e for w in the [6N | 3N | 3N] layout; CCs' w_s: partial sums
+      return tp_get<true>(part, planA, e / 3, e % 3) + wv_[ms + e] + (wv_[ms + n + e] - (e + 3 < n ? wv_[ms + n + e + 3] : 0.0));
     };
+#ifdef F16_EXP_STAMPG
+    unsigned long long tS[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq0 = __builtin_amdgcn_s_memtime();
+#define GSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long tq1 = __builtin_amdgcn_s_memtime(); tS[i] += tq1 - tq0; tq0 = tq1; }
+#else
+#define GSTAMP(i)
+#endif
     while (!done) {
       ++it;
+      GSTAMP(7)
       // w = E (rho zb - yb) -> t = A' w ; rhs = sigma D^-2 x - c q + t
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
@@ -331,19 +601,25 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a) {
         if (row < m) wbuf[row] = Eo[t] * (rho * eqf[t] * z[t] - y[t]);
       }
       __syncthreads();
-      conv_adjoint6(tv, G, wbuf, N);
+      GSTAMP(0)
+      tp_partials<true>(part, Gc, wbuf, L.zpad, N);
       __syncthreads();
+      GSTAMP(1)
       for (int e = l; e < n; e += BLK) rhs[e] = Dg[e] * xs[e] - cs * qv[e] + adjoint(wbuf, e);
       __syncthreads();
-      full_symv(xt, Full, rhs, n);                         // x~
+      GSTAMP(2)
+      half_symv(xt, Hinv, rhs, n, L.part);                 // x~ (ends with a barrier)
+      GSTAMP(3)
+      tp_partials<false>(part, Gc, xt, L.zpad, N);
       __syncthreads();
+      GSTAMP(5)
       // zb~ = E A x~ ; relaxation, projection, dual update
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
         const int row = l + BLK * t;
         if (row < m) {
           double zt;
-          if (row < ms) zt = conv_forward_row(G, xt, row / 6, SROW[row % 6]);
+          if (row < ms) zt = tp_get<false>(part, planF, row / 6, row % 6);
           else if (row < ms + n) zt = xt[row - ms];
           else { const int k = row - ms - n; zt = xt[k] - (k >= 3 ? xt[k - 3] : 0.0); }
           zt *= Eo[t];
@@ -357,15 +633,18 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a) {
       }
       for (int e = l; e < n; e += BLK) xs[e] = alpha * xt[e] + (1 - alpha) * xs[e];
       __syncthreads();
+      GSTAMP(4)
       if (it % a.s.check_every == 0 || it >= a.s.max_iter) {
         // residuals of the UNSCALED problem (OSQP termination test) + the scaled ones for the rho estimate
         double r1 = 0.0, nAx = 0.0, nz = 0.0, r1s = 0.0, nAxs = 0.0, nzs = 0.0;
+        tp_partials<false>(part, Gc, xs, L.zpad, N);
+        __syncthreads();
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
           const int row = l + BLK * t;
           if (row < m) {
             double ax;
-            if (row < ms) ax = conv_forward_row(G, xs, row / 6, SROW[row % 6]);
+            if (row < ms) ax = tp_get<false>(part, planF, row / 6, row % 6);
             else if (row < ms + n) ax = xs[row - ms];
             else { const int k = row - ms - n; ax = xs[k] - (k >= 3 ? xs[k - 3] : 0.0); }
             const double zu = z[t] / Eo[t];
@@ -375,8 +654,8 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a) {
           }
         }
         __syncthreads();
-        packed_symv(xt, Pg, xs, n);                        // P x (packed P from the workspace)
-        conv_adjoint6(tv, G, wbuf, N);
+        half_symv(xt, HP, xs, n, L.part);                  // P x
+        tp_partials<true>(part, Gc, wbuf, L.zpad, N);
         __syncthreads();
         double r2 = 0.0, nPx = 0.0, nAty = 0.0, nq = 0.0, r2s = 0.0, nPxs = 0.0, nAtys = 0.0, nqs = 0.0;
         for (int e = l; e < n; e += BLK) {
@@ -406,7 +685,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a) {
           supp = block_reduce<true>(supp, L.red);
           __syncthreads();
           if (ndy > a.s.eps_prim_inf && supp < -a.s.eps_prim_inf * ndy) {
-            conv_adjoint6(tv, G, wbuf, N);
+            tp_partials<true>(part, Gc, wbuf, L.zpad, N);
             __syncthreads();
             double nat = 0.0;
             for (int e = l; e < n; e += BLK) nat = fmax(nat, fabs(adjoint(wbuf, e)));
@@ -432,6 +711,10 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a) {
     // res.x[0:3] (env.py:424); OSQP hands back NaN for a problem it certifies infeasible
     for (int e = l; e < 3; e += BLK) a.ucmd[e * a.ld + b] = infeasible ? NAN : xs[e];
     if (a.useq) for (int e = l; e < n; e += BLK) a.useq[e * a.ld + b] = infeasible ? NAN : xs[e];
+#ifdef F16_EXP_STAMPG
+    __syncthreads();
+    if (a.useq && l == 0) for (int e = 0; e < 8; ++e) a.useq[e * a.ld + b] = (double)tS[e];     // diagnostic build: cycles per phase (s_memtime)
+#endif
     if (l == 0) {
       if (a.iters_out) a.iters_out[b] = it;
       if (a.info) {
@@ -439,6 +722,10 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a) {
         a.info[1 * a.ld + b] = rp;
         a.info[2 * a.ld + b] = rd;
         a.info[3 * a.ld + b] = rho;
+#ifdef F16_EXP_STAMPG
+        a.info[1 * a.ld + b] = (double)wc0;                // diagnostic build: start / end of this solve on the 100 MHz clock
+        a.info[2 * a.ld + b] = (double)wall_clock64();
+#endif
       }
       if (a.status && infeasible) a.status[b] |= F16_ST_QP_INFEASIBLE;
       else if (a.status && a.s.max_iter > 0 && (!converged || !ok)) a.status[b] |= F16_ST_QP_MAXITER;
@@ -451,9 +738,9 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a) {
 
 size_t mpc_big_ws_doubles(int N) { return big::ws_doubles(N); }
 
-int mpc_big_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
+static int big_launch(f16_ctx *ctx, const MpcArgs &a, void *stream, int sw_lo, int sw_hi, double *sw_base, double *sw_ucmd,
+                      double *sw_info, int32_t *sw_status, unsigned int *sw_next) {
   (void)ctx;
-  if (a.N < 1 || a.N > BIG_MAXN || !a.bigws || !a.ext || !a.Ppk) return set_error(F16_EINVAL, "long-horizon MPC solver: bad arguments");
   static std::mutex mu;
   static bool ready[64] = {};
   int dev = 0;
@@ -466,10 +753,31 @@ int mpc_big_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
       ready[dev] = true;
     }
   }
-  const size_t lds = big::lds_doubles(a.N) * sizeof(double);
-  const long grid = a.B < 4096 ? a.B : 4096;
-  hipLaunchKernelGGL(big::k_mpc_big, dim3((unsigned)grid), dim3(big::BLK), lds, (hipStream_t)stream, a);
+  const bool sweep = sw_hi > 0;
+  if (sweep && (sw_lo < 1 || sw_hi < sw_lo || sw_hi > BIG_MAXN || !sw_base || !sw_ucmd || !sw_next)) return set_error(F16_EINVAL, "horizon sweep: bad arguments");
+  big::SweepArgs sw{};
+  sw.lo = sw_lo; sw.hi = sweep ? sw_hi : 0; sw.base = sw_base; sw.ucmd = sw_ucmd; sw.info = sw_info; sw.status = sw_status;
+  sw.next = sw_next;
+  const size_t lds = big::lds_doubles(sweep ? sw_hi : a.N) * sizeof(double);
+  const long total = sweep ? (long)(sw_hi - sw_lo + 1) * a.B : a.B;
+  long grid = total < 65536 ? total : 65536;
+  if (sweep) {                                            // resident workgroups only (two per CU at most: LDS)
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (grid > 2L * cus) grid = 2L * cus;
+  }
+  hipLaunchKernelGGL(big::k_mpc_big, dim3((unsigned)grid), dim3(big::BLK), lds, (hipStream_t)stream, a, sw);
   return hip_check(hipGetLastError(), "f16_mpc_batch long-horizon solve launch");
+}
+
+int mpc_big_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
+  if (a.N < 1 || a.N > BIG_MAXN || !a.bigws || !a.ext || !a.Ppk) return set_error(F16_EINVAL, "long-horizon MPC solver: bad arguments");
+  return big_launch(ctx, a, stream, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+size_t mpc_big_sweep_job_doubles(int N) { return big::sweep_job_doubles(N); }
+int mpc_big_sweep_launch(f16_ctx *ctx, const MpcArgs &a, int lo, int hi, double *base, double *ucmd, double *info, int32_t *status,
+                         unsigned int *next, void *stream) {
+  return big_launch(ctx, a, stream, lo, hi, base, ucmd, info, status, next);
 }
 
 }  // namespace f16

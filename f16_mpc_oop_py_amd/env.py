@@ -430,11 +430,25 @@ class F16Batch:
 
     calc_MPC_action = _calc_MPC_action
 
-    def _calc_constr_checking_hzn(self, max_hzn=150, settings=None):
+    def _calc_constr_checking_hzn(self, max_hzn=150, settings=None, return_info=False):
         """env.py:426-436: the first move of calc_MPC_action(0, 0, 0, N) for every horizon N = 1..max_hzn (the reference
-        fills u[:, N-1] for one aircraft; here [B, 3, max_hzn]).  Horizons beyond 40 take the slow HBM-resident solver."""
-        import torch
-        out = torch.empty((self.B, 3, max_hzn), dtype=torch.float64, device=self.device)
-        for i in range(max_hzn):
-            out[:, :, i] = self._calc_MPC_action(0, 0, 0, i + 1, settings=settings)
+        fills u[:, N-1] for one aircraft; here [B, 3, max_hzn]).  One library call (f16_mpc_hzn_sweep): the long horizons
+        are solved by a single launch over every (horizon, aircraft) pair; each slice equals _calc_MPC_action(0, 0, 0, N)."""
+        if self.ssr is None:
+            self.build_ssr()
+        Ad, Bd, Cd = self.ssr
+        dem = torch.zeros((3, self.B), dtype=torch.float64, device=self.device)
+        ucmd = torch.empty((max_hzn, 3, self.B), dtype=torch.float64, device=self.device)
+        info = torch.empty((max_hzn, 4, self.B), dtype=torch.float64, device=self.device)
+        st = torch.zeros((max_hzn, self.B), dtype=torch.int32, device=self.device)
+        s = _lib.QPSettings()
+        self.lib.f16_qp_default_settings(ctypes.byref(s))
+        for k, v in (settings or {}).items():
+            setattr(s, k, v)
+        self._check(self.lib.f16_mpc_hzn_sweep(self.ctx.handle, _vp(Ad), _vp(Bd), _vp(Cd), _vp(self._x), _vp(dem), _vp(ucmd),
+                                               _vp(info), _vp(st), self.B, self.B, 1, int(max_hzn), self.dt, ctypes.byref(s),
+                                               self._stream))
+        out = ucmd.permute(2, 1, 0)
+        if return_info:
+            return out, dict(iters=info[:, 0], r_prim=info[:, 1], r_dual=info[:, 2], rho=info[:, 3], status=st)
         return out

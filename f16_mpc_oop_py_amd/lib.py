@@ -205,6 +205,7 @@ def load():
         L.f16_qp_default_settings.argtypes = [ctypes.POINTER(QPSettings)]
         L.f16_qp_default_settings.restype = None
         L.f16_mpc_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, l, l, i, d, ctypes.POINTER(QPSettings), vp]
+        L.f16_mpc_hzn_sweep.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, l, l, i, i, d, ctypes.POINTER(QPSettings), vp]
         L.f16_mpc_qp_debug.argtypes = [vp, vp, vp, vp, vp, vp, l, l, i, d, vp, vp, vp, vp, vp]
         L.f16_debug_spd_inverse.argtypes = [vp, vp, vp, i, l, vp]
         L.f16_mpc_plan_create.argtypes = [vp, ctypes.POINTER(vp), vp, vp, vp, l, l, i, d, ctypes.POINTER(QPSettings), vp]

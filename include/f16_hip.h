@@ -164,6 +164,16 @@ void f16_qp_default_settings(f16_qp_settings *s);
 int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
                   const double *dem, double *u_cmd, double *u_seq, double *info, int32_t *status,
                   long B, long ld, int hzn, double dt, const f16_qp_settings *s, void *stream);
+/* env.py:426-436 `_calc_constr_checking_hzn`: the first move of calc_MPC_action for the SAME states, demands and model at
+ * every horizon hzn_lo..hzn_hi (1 <= hzn_lo <= hzn_hi <= 150) as one call.  u_cmd [hzn_hi - hzn_lo + 1][3][ld], info (may be
+ * NULL) [..][4][ld], status (may be NULL, OR-ed into) [..][ld]; slice k = hzn - hzn_lo holds exactly what f16_mpc_batch returns
+ * for that horizon (bit-identical: same kernels).  Horizons <= 32 run one after the other; the longer ones are built per
+ * horizon and solved by ONE launch over every (horizon, aircraft) pair, longest horizon first, so that the few solves that
+ * need tens of thousands of iterations do not hold a launch of their own.  Workspace: stream-ordered, in groups of horizons
+ * of at most F16_SWEEP_WS_GB (default 32) GB (3.3 MB per aircraft at N = 150).  Not capturable. */
+int f16_mpc_hzn_sweep(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
+                      const double *dem, double *u_cmd, double *info, int32_t *status, long B, long ld, int hzn_lo,
+                      int hzn_hi, double dt, const f16_qp_settings *s, void *stream);
 /* Prepared plans.  The reference freezes (Ad,Bd,Cd) at construction (env.py:49-60) yet rebuilds the whole QP on every
  * _calc_MPC_action call (utils.py:21-167 inside env.py:373-424).  A plan computes the model-only part once -- DARE,
  * terminal weight, prediction blocks, P; with scaling = 0 also the start value of rho and the inverse of the KKT matrix

@@ -1,0 +1,23 @@
+"""Diagnostic: per-phase s_memtime ticks of k_mpc_big from a -DF16_EXP_STAMPG build (run on the GPU box).
+usage: F16HIP_SO=build/libf16hip_stampg.so python tools/gpu_big_stamps.py [B] [N ...]"""
+import sys, time
+sys.path.insert(0, ".")
+import torch
+from f16_mpc_oop_py_amd import F16Batch
+from f16_mpc_oop_py_amd.workload import config4_states
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+Ns = [int(v) for v in sys.argv[2:]] or [41, 100, 150]
+x0, u0 = config4_states(B)
+env = F16Batch(x0, u0, xcg=0.35)
+env.build_ssr()
+names = ["w + sync", "A'w (stage 1)", "rhs", "x~ = K^-1 rhs", "projection + dual update", "A x~ (stage 3)", "-", "test + rest"]
+for N in Ns:
+    env._calc_MPC_action(0, 0, 0, N); torch.cuda.synchronize()
+    t0 = time.perf_counter(); u, info = env._calc_MPC_action(0, 0, 0, N, return_info=True); torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0)
+    it = info["iters"].cpu().numpy(); s = info["u_seq"][:, :8].cpu().numpy()
+    b = int(it.argmax())
+    print(f"N={N}: {ms:.1f} ms, slowest aircraft {b}: {it[b]:.0f} iterations = {1e3 * ms / it[b]:.1f} us per iteration; ticks per iteration:")
+    for k, nm in enumerate(names):
+        if nm != "-":
+            print(f"   {nm:30s} {s[b, k] / it[b]:9.1f}  ({100 * s[b, k] / s[b].sum():.0f} %)")

@@ -17,6 +17,16 @@ for N in (30, 33, 40, 41, 57, 100, 150):
     t0 = time.perf_counter(); u, info = env._calc_MPC_action(0, 0, 0, N, return_info=True); torch.cuda.synchronize()
     print(f"N={N}: {1e3 * (time.perf_counter() - t0):.1f} ms for {B} aircraft, iterations mean {float(info['iters'].mean()):.0f} max {float(info['iters'].max()):.0f}, status {sorted(set(info['status'].cpu().numpy().tolist()))}", flush=True)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-sw = env._calc_constr_checking_hzn(max_hzn=H)
+sw, inf = env._calc_constr_checking_hzn(max_hzn=H, return_info=True)
 torch.cuda.synchronize()
-print(f"_calc_constr_checking_hzn({H}) for B = {B}: {time.perf_counter() - t0:.2f} s, finite {bool(torch.isfinite(sw).all())}")
+dt = time.perf_counter() - t0
+it = inf["iters"]
+print(f"_calc_constr_checking_hzn({H}) for B = {B}: {dt:.2f} s; aircraft-iterations in total {float(it.sum()):.3e}, "
+      f"largest {float(it.max()):.0f}; infeasible (NaN command) {int((inf['status'] & 128).ne(0).sum())} of {it.numel()}", flush=True)
+for N in (1, 30, 33, 41, 57, 100, 150):
+    if N > H:
+        continue
+    u, i1 = env._calc_MPC_action(0, 0, 0, N, return_info=True)
+    same = torch.equal(torch.nan_to_num(sw[:, :, N - 1], nan=1e300), torch.nan_to_num(u, nan=1e300))
+    print(f"N={N}: slice == direct call {same}; iterations equal {bool(torch.equal(it[N - 1], i1['iters']))}; status equal "
+          f"{bool(torch.equal(inf['status'][N - 1], i1['status']))}", flush=True)
