@@ -281,6 +281,7 @@ def run(args):
         out["mpc"] = bench_mpc(args, dev, rank, world, fdist, barrier)
         if rank == 0:
             out["trim"] = bench_trim(dev)
+            out["hzn_sweep"] = bench_hzn_sweep(dev)
     if not args.no_config5:
         out["config5_closed_loop"] = bench_closed_loop(args, dev, rank, world, fdist, barrier)
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -487,6 +488,30 @@ def bench_trim(dev, B=4096):
                     "evaluation of latency per iteration; a condition whose iteration reaches a fixed point (the ones that cannot be "
                     "trimmed: they would repeat it to the reference's maxiter = 50,000) is accounted for instead of run -- same "
                     "results bit for bit (tests)"}
+
+
+def bench_hzn_sweep(dev, B=64, max_hzn=150):
+    """The reference's horizon sweep (env.py:426-436: calc_MPC_action(0, 0, 0, N) for N = 1..150 on the same states), for B
+    aircraft, as one library call (f16_mpc_hzn_sweep); first call on these states (no scheduling history is used)."""
+    import torch
+    from f16_mpc_oop_py_amd import F16Batch
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(B)
+    env = F16Batch(x0, u0, xcg=0.35, device=dev)
+    env.build_ssr()
+    env._calc_MPC_action(0, 0, 0, 33)                      # (library warm-up: kernel attributes, pool)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sw, inf = env._calc_constr_checking_hzn(max_hzn=max_hzn, return_info=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    it = inf["iters"]
+    return {"aircraft": B, "max_hzn": max_hzn, "seconds": dt, "solves": int(it.numel()), "solves_per_s": it.numel() / dt,
+            "aircraft_iterations": float(it.sum()), "iterations_max": int(it.max()),
+            "certified_infeasible": int((inf["status"] & 128).ne(0).sum()), "settings": "osqp_defaults",
+            "note": "horizons <= 32 one call after the other; 33..150: one build launch per horizon, then ONE launch of the "
+                    "long-horizon solver over every (horizon, aircraft) pair taken from a work queue, longest horizons first; the "
+                    "call lasts as long as its slowest pair started late (here N = 103 at max_iter = 40,000); with a launch per horizon: 61 s"}
 
 
 def bench_closed_loop(args, dev, rank, world, fdist, barrier):

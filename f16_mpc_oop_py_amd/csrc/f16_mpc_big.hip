@@ -1,19 +1,23 @@
 // f16_mpc_big.hip -- the OSQP solve of the condensed MPC QP (env.py:420-424) for LONG horizons, 33 <= N <= 150 (the reference
-// sweeps N = 1..150, env.py:426-436): one 1024-lane WORKGROUP per aircraft.
+// sweeps N = 1..150 on the same states, env.py:426-436): one 512-lane WORKGROUP per aircraft.
 //
 // Same rules as the other solvers (f16_control.hip: k_mpc; f16_mpc_solve.hip; f16_mpc_wave.hip): Ruiz equilibration on the
 // original entries and the running D, E, c; rho vector; x unscaled, zb / yb scaled; termination on the unscaled residuals; rho
 // estimate on the scaled ones; primal-infeasibility certificate.  What changes is where things live: at N = 150 the KKT
 // matrix is 450 x 450 (1.6 MB), far beyond registers and LDS, so
 //   * the Gram matrix A'WA (it does not depend on rho) and the KKT matrix / its inverse are PACKED lower triangles in the
-//     per-aircraft HBM workspace (L2 / Infinity-Cache resident: 64 aircraft x 3.3 MB), the inverse is then mirrored into a full
-//     n x n matrix so that x~ = K^-1 rhs reads rows contiguously (one wavefront per row group, lanes across the columns);
-//   * the inverse is the symmetric sweep (Gauss-Jordan without pivoting, SPD) with one wavefront per row and the pivot column
-//     in LDS: n barriers per factorisation;
-//   * vectors (G_k, q, pred, x, rhs, E, D, the row vector w) live in LDS (102 KB at N = 150), the per-row values of a lane's
-//     (up to two) constraint rows in registers.
-// The one-wavefront kernel this replaces for N > 32 (k_mpc<false>, k_mpc<false, true>) ran every loop of the solve on 64
-// lanes: four aircraft at N = 150 took 2.2 s.
+//     per-aircraft HBM workspace; the inverse is then re-laid as a padded HALF (rows padded to whole 64-column trips, the
+//     diagonal halved) that serves x~ = K^-1 rhs with every entry read once: 0.93 MB per product at N = 150 -- a CU takes in
+//     ~33 GB/s from the Infinity Cache (MI355X_MICROARCH.md, gather table), and that stream is the floor of an iteration;
+//   * the inverse is the symmetric sweep, eight pivots per pass over the matrix (sweep_inverse_blocked), in its own function;
+//   * the two block-Toeplitz products of an iteration run with lanes across the horizon steps and the blocks G_d through the
+//     scalar cache (tp_partials);
+//   * vectors (q, pred, x, rhs, E, D, the row vector w) live in LDS, the per-row values of a lane's (up to four) constraint
+//     rows in registers.
+// A sweep over horizons is ONE launch: resident workgroups take (horizon, aircraft) pairs from a work queue, longest horizons
+// first (SweepArgs).  History: the one-wavefront kernel this replaced for N > 32 (k_mpc<false, true>) took 2.2 s for four
+// aircraft at N = 150; the first workgroup version 2.15 s for 64 (80 us per iteration: full inverse streamed, both Toeplitz
+// operands from LDS, one pass over the matrix per pivot) and 61 s for the reference's sweep at B = 64, a launch per horizon.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -188,8 +192,9 @@ __device__ __forceinline__ void half_symv_t(double *y, const double *H, const do
   double vj[KT], acc[KT];
 #pragma unroll
   for (int k = 0; k < KT; ++k) { const int j = l + 64 * k; vj[k] = j < n ? v[j] : 0.0; acc[k] = 0.0; }
-  for (int i0 = w; i0 < n; i0 += NW * R) {
-    double a[R][KT];
+  // two row groups in flight: the loads of the next group are issued before the products of this one (a group per memory
+  // round trip otherwise: 2-3 k cycles each from the Infinity Cache, ten of them per wavefront at N = 100)
+  auto load = [&](double (&a)[R][KT], int i0) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int ir = i0 + NW * r, irc = ir < n ? ir : i0, kr = irc >> 6;
@@ -197,6 +202,8 @@ __device__ __forceinline__ void half_symv_t(double *y, const double *H, const do
 #pragma unroll
       for (int k = 0; k < KT; ++k) { const double *p = k <= kr ? row + 64 * k : zeros; a[r][k] = *p; }
     }
+  };
+  auto products = [&](const double (&a)[R][KT], int i0) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int ir = i0 + NW * r;
@@ -206,6 +213,18 @@ __device__ __forceinline__ void half_symv_t(double *y, const double *H, const do
       for (int k = 0; k < KT; ++k) { dot = fma(a[r][k], vj[k], dot); acc[k] = fma(a[r][k], vi, acc[k]); }
       dot = wave_reduce_dpp<true>(dot);
       if (l == 0 && ir < n) y[ir] = dot;
+    }
+  };
+  constexpr int STEP = NW * R;
+  double bufA[R][KT], bufB[R][KT];
+  if (w < n) load(bufA, w);
+  for (int i0 = w; i0 < n; i0 += 2 * STEP) {
+    const bool second = i0 + STEP < n;
+    if (second) load(bufB, i0 + STEP);
+    products(bufA, i0);
+    if (second) {
+      if (i0 + 2 * STEP < n) load(bufA, i0 + 2 * STEP);
+      products(bufB, i0 + STEP);
     }
   }
 #pragma unroll
@@ -221,14 +240,14 @@ __device__ __forceinline__ void half_symv_t(double *y, const double *H, const do
 }
 __device__ __forceinline__ void half_symv(double *y, const double *H, const double *v, int n, double *part) {
   switch ((n + 63) >> 6) {
-    case 1: half_symv_t<1, 4>(y, H, v, n, part); break;
-    case 2: half_symv_t<2, 4>(y, H, v, n, part); break;
-    case 3: half_symv_t<3, 4>(y, H, v, n, part); break;
-    case 4: half_symv_t<4, 4>(y, H, v, n, part); break;
-    case 5: half_symv_t<5, 4>(y, H, v, n, part); break;
-    case 6: half_symv_t<6, 4>(y, H, v, n, part); break;
-    case 7: half_symv_t<7, 4>(y, H, v, n, part); break;
-    default: half_symv_t<8, 4>(y, H, v, n, part); break;
+    case 1: half_symv_t<1, 2>(y, H, v, n, part); break;
+    case 2: half_symv_t<2, 2>(y, H, v, n, part); break;
+    case 3: half_symv_t<3, 2>(y, H, v, n, part); break;
+    case 4: half_symv_t<4, 2>(y, H, v, n, part); break;
+    case 5: half_symv_t<5, 2>(y, H, v, n, part); break;
+    case 6: half_symv_t<6, 2>(y, H, v, n, part); break;
+    case 7: half_symv_t<7, 2>(y, H, v, n, part); break;
+    default: half_symv_t<8, 2>(y, H, v, n, part); break;
   }
 }
 // In-place inverse of the packed SPD matrix S (HBM) by the symmetric sweep; c: LDS scratch [n].  Afterwards S = S^-1.
@@ -272,7 +291,18 @@ __device__ __forceinline__ bool sweep_inverse_packed(double *S, int n, double *c
 //   K: one wavefront per row, lanes across the columns, the lane's c_j in registers for all rows of a column trip, four rows per
 //   trip in flight;  5. S_iK = T_i, S_KK = -A^-1.
 // cp, tp: LDS [SWB][n] each.  Afterwards S = S^-1; returns false on a non-positive pivot.
-__device__ __forceinline__ bool sweep_inverse_blocked(double *S, int n, double *cp, double *tp) {
+#ifdef F16_BIG_INLINE_SWEEP
+#define F16_SWEEP_INLINE __forceinline__
+#else
+#define F16_SWEEP_INLINE __noinline__       // (its own register allocation: inlined, it pushed 180 spill reloads into every iteration)
+#endif
+__device__ F16_SWEEP_INLINE bool sweep_inverse_blocked(double *S_, int n, double *cp_, double *tp_) {
+  // (a function of its own sees generic pointers: say where they point, or every LDS access becomes a flat one)
+  typedef double __attribute__((address_space(3))) *lds_ptr_t;
+  typedef double __attribute__((address_space(1))) *glb_ptr_t;
+  const lds_ptr_t cp = (lds_ptr_t)cp_, tp = (lds_ptr_t)tp_;
+  const glb_ptr_t S = (glb_ptr_t)S_;
+  constexpr int RU = 8;                                   // rows of a wavefront in flight per column trip
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
   bool ok = true;
   for (int k0 = 0; k0 < n; k0 += SWB) {
@@ -322,23 +352,23 @@ __device__ __forceinline__ bool sweep_inverse_blocked(double *S, int n, double *
 #pragma unroll
       for (int p = 0; p < SWB; ++p) cj[p] = j < n ? cp[p * n + j] : 0.0;
       static_assert(64 % NW == 0, "rows w, w + NW, ... of a wavefront: the first one from 64 kt on is 64 kt + w");
-      for (int i0 = 64 * kt + w; i0 < n; i0 += 4 * NW) {
-        double val[4];
-        bool on[4];
+      for (int i0 = 64 * kt + w; i0 < n; i0 += RU * NW) {
+        double val[RU];
+        bool on[RU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < RU; ++u) {
           const int i = i0 + u * NW;
           on[u] = i < n && !(i >= k0 && i < k0 + nb) && jout && j <= i;
           val[u] = S[on[u] ? tri(i, j) : 0];                 // (unconditional: a load under a lane condition becomes a branch)
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < RU; ++u) {
           const int i = i0 + u * NW < n ? i0 + u * NW : i0;
 #pragma unroll
           for (int q = 0; q < SWB; ++q) val[u] = fma(-tp[q * n + i], cj[q], val[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < RU; ++u)
           if (on[u]) S[tri(i0 + u * NW, j)] = val[u];
       }
     }
@@ -421,7 +451,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
       a.useq = nullptr; a.iters_out = nullptr;
     }
 #ifdef F16_EXP_STAMPG
-    const unsigned long long wc0 = wall_clock64();
+    const unsigned long long wc0 = wall_clock64(), tjob0 = __builtin_amdgcn_s_memtime();
 #endif
     const int N = a.N, n = 3 * N, np = n * (n + 1) / 2, ms = 6 * N, m = 12 * N;
     const Lds L = carve(smem, N);
@@ -553,7 +583,14 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
       tp = block_reduce<true>(tp, L.red); ta = block_reduce<true>(ta, L.red);
       rho = fmin(fmax(RHO_AUTO_SCALE * sqrt(tp / ta), OSQP_RHO_MIN), OSQP_RHO_MAX);
     }
+#ifdef F16_EXP_STAMPG
+    unsigned long long tS[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    tS[10] = __builtin_amdgcn_s_memtime() - tjob0;        // set-up: equilibration, Gram product
+#endif
     auto build_minv = [&](double r) {                     // Full <- (c P + sigma D^-2 + r A'WA)^-1
+#ifdef F16_EXP_STAMPG
+      const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+#endif
       __syncthreads();
       {
         const int w = __builtin_amdgcn_readfirstlane(l >> 6), ll = l & 63;
@@ -572,6 +609,9 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
       half_from_packed(Hinv, Minv, n);
       __threadfence_block();
       __syncthreads();
+#ifdef F16_EXP_STAMPG
+      tS[8] += __builtin_amdgcn_s_memtime() - tb0; tS[9] += 1;
+#endif
       return __syncthreads_and(good) != 0;
     };
     half_from_packed(HP, Pg, n);
@@ -586,7 +626,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
       return tp_get<true>(part, planA, e / 3, e % 3) + wv_[ms + e] + (wv_[ms + n + e] - (e + 3 < n ? wv_[ms + n + e + 3] : 0.0));
     };
 #ifdef F16_EXP_STAMPG
-    unsigned long long tS[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq0 = __builtin_amdgcn_s_memtime();
+    unsigned long long tq0 = __builtin_amdgcn_s_memtime();
 #define GSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long tq1 = __builtin_amdgcn_s_memtime(); tS[i] += tq1 - tq0; tq0 = tq1; }
 #else
 #define GSTAMP(i)
@@ -713,7 +753,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
     if (a.useq) for (int e = l; e < n; e += BLK) a.useq[e * a.ld + b] = infeasible ? NAN : xs[e];
 #ifdef F16_EXP_STAMPG
     __syncthreads();
-    if (a.useq && l == 0) for (int e = 0; e < 8; ++e) a.useq[e * a.ld + b] = (double)tS[e];     // diagnostic build: cycles per phase (s_memtime)
+    if (a.useq && l == 0) for (int e = 0; e < 12; ++e) a.useq[e * a.ld + b] = (double)tS[e];     // diagnostic build: cycles per phase (s_memtime)
 #endif
     if (l == 0) {
       if (a.iters_out) a.iters_out[b] = it;

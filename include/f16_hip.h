@@ -145,8 +145,9 @@ int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double
  * Opt-in alternative (the builder's rule, faster on this family of QPs): scaling = 0, rho = 0 -> no equilibration and
  * the start value rho = 2 sqrt(tr P / tr A'A); scaling = 0, rho > 0 -> no equilibration, fixed start value.
  * Horizons: 1 <= hzn <= 150.  hzn <= 30 (equilibrated solves) runs one wavefront per aircraft, hzn <= 32 the 512-lane
- * register-resident solver, larger horizons (the reference's own sweep goes to 150, env.py:426-436) one 1024-lane workgroup
- * per aircraft with the KKT inverse in the HBM workspace (its row stream, 1.6 MB per iteration at hzn = 150, sets the pace).
+ * register-resident solver, larger horizons (the reference's own sweep goes to 150, env.py:426-436) one 512-lane workgroup
+ * per aircraft with the KKT inverse in the HBM workspace (the stream of its symmetric half, 0.93 MB per iteration at hzn = 150,
+ * sets the pace; f16_mpc_hzn_sweep below solves all horizons of a sweep in one launch).
  * u_seq (may be NULL) gets the full [3*hzn][ld] sequence, info (may be NULL) gets [4][ld] = iterations, r_prim, r_dual
  * (unscaled), rho.
  * Nothing the results depend on is retained between calls: the QP workspace is allocated and freed per call, stream-ordered

@@ -694,17 +694,46 @@ def test_horizons_beyond_the_on_chip_solvers_vs_same_algorithm_oracle(mode):
             assert np.abs(u[b].cpu().numpy() - ref["x"][:3]).max() < 1e-8
 
 
-def test_constraint_checking_horizon_sweep_surface():
-    """F16._calc_constr_checking_hzn (env.py:426-436): first moves for N = 1..max_hzn, here for a batch; every column equals
-    the direct call at that horizon (incl. two horizons on the slow path)."""
+def test_constraint_checking_horizon_sweep_surface(tmp_path):
+    """F16._calc_constr_checking_hzn (env.py:426-436): first moves for N = 1..max_hzn, here for a batch, as ONE library call
+    (f16_mpc_hzn_sweep: the long horizons solved by a single launch over every (horizon, aircraft) pair, taken from a work
+    queue).  Every slice equals the direct call at that horizon bit for bit -- commands, iteration counts, residuals, rho, status
+    words -- whatever the order the pairs were solved in, and also when the workspace budget cuts the sweep into groups of horizons
+    (F16_SWEEP_WS_GB, read once per process: a child process)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
     from f16_mpc_oop_py_amd.workload import config4_states
-    x0, u0 = config4_states(4, seed=9)
+    x0, u0 = config4_states(5, seed=9)
     env = make_env(x0, u0, xcg=0.35)
     env.build_ssr()
-    sw = env._calc_constr_checking_hzn(max_hzn=42)
-    assert tuple(sw.shape) == (4, 3, 42)
-    for N in (1, 10, 30, 33, 41, 42):
-        assert torch.equal(sw[:, :, N - 1], env._calc_MPC_action(0, 0, 0, N), ), N
+    sw, inf = env._calc_constr_checking_hzn(max_hzn=58, return_info=True)
+    assert tuple(sw.shape) == (5, 3, 58)
+    for N in (1, 10, 30, 31, 32, 33, 34, 41, 42, 57, 58):
+        u, i1 = env._calc_MPC_action(0, 0, 0, N, return_info=True)
+        assert torch.equal(torch.nan_to_num(sw[:, :, N - 1], nan=1e300), torch.nan_to_num(u, nan=1e300)), N
+        for k in ("iters", "r_prim", "r_dual", "rho"):
+            assert torch.equal(inf[k][N - 1], i1[k]), (N, k)
+        assert torch.equal(inf["status"][N - 1], i1["status"]), N
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from f16_mpc_oop_py_amd import F16Batch
+from f16_mpc_oop_py_amd.workload import config4_states
+x0, u0 = config4_states(5, seed=9)
+env = F16Batch(x0, u0, xcg=0.35)
+env.build_ssr()
+sw, inf = env._calc_constr_checking_hzn(max_hzn=58, return_info=True)
+np.savez(sys.argv[1], u=sw.cpu().numpy(), iters=inf["iters"].cpu().numpy(), status=inf["status"].cpu().numpy())
+''' % REPO
+    f = str(tmp_path / "groups.npz")
+    r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, F16_SWEEP_WS_GB="0.002"), capture_output=True, text=True,
+                       timeout=600)          # 2 MB: a group per horizon or two (N = 58: 0.46 MB per aircraft)
+    assert r.returncode == 0, r.stderr[-2000:]
+    g = np.load(f)
+    assert np.array_equal(g["u"], sw.cpu().numpy(), equal_nan=True)
+    assert np.array_equal(g["iters"], inf["iters"].cpu().numpy()) and np.array_equal(g["status"], inf["status"].cpu().numpy())
 
 
 def test_wavefront_solver_vs_the_512_lane_solver_and_its_equilibration(tmp_path):

@@ -2,6 +2,7 @@
 usage: F16HIP_SO=build/libf16hip_stampg.so python tools/gpu_big_stamps.py [B] [N ...]"""
 import sys, time
 sys.path.insert(0, ".")
+import numpy as np
 import torch
 from f16_mpc_oop_py_amd import F16Batch
 from f16_mpc_oop_py_amd.workload import config4_states
@@ -15,9 +16,10 @@ for N in Ns:
     env._calc_MPC_action(0, 0, 0, N); torch.cuda.synchronize()
     t0 = time.perf_counter(); u, info = env._calc_MPC_action(0, 0, 0, N, return_info=True); torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0)
-    it = info["iters"].cpu().numpy(); s = info["u_seq"][:, :8].cpu().numpy()
+    it = info["iters"].cpu().numpy(); sa = info["u_seq"][:, :12].cpu().numpy(); s = sa[:, :8]
     b = int(it.argmax())
     print(f"N={N}: {ms:.1f} ms, slowest aircraft {b}: {it[b]:.0f} iterations = {1e3 * ms / it[b]:.1f} us per iteration; ticks per iteration:")
     for k, nm in enumerate(names):
         if nm != "-":
             print(f"   {nm:30s} {s[b, k] / it[b]:9.1f}  ({100 * s[b, k] / s[b].sum():.0f} %)")
+    print(f"   set-up (equilibration, Gram product): {sa[b, 10]:.3e} ticks; KKT factorisations: {sa[b, 9]:.0f} x {sa[b, 8] / max(sa[b, 9], 1):.3e} ticks;  batch medians: set-up {np.median(sa[:, 10]):.3e}, factorisations {np.median(sa[:, 9]):.0f} x {np.median(sa[:, 8] / np.maximum(sa[:, 9], 1)):.3e}, iterations {np.median(it):.0f} x {np.median(s[:, :7].sum(1) / it):.0f}")
