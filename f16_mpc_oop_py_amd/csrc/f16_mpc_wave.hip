@@ -1157,10 +1157,18 @@ __device__ __noinline__ void p_block_image(const double *Pg, double *pb, int n) 
 // The solve of one aircraft per wavefront-workgroup (grid = B).  D, E, c of the equilibration come from the workspace
 // (k_mpc_fast, scale-only mode), P / q / G_k / pred from the build kernel (k_mpc<true>).
 __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
+#ifdef F16_EXP_STAMPW
+  const unsigned long long wc0_ = wall_clock64();
+#endif
   const int N = a.N, n = 3 * N;
   const Role R = role(N);
   const int l = R.l;
-  const long b = a.order ? (long)__builtin_amdgcn_readfirstlane(a.order[blockIdx.x]) : (long)blockIdx.x;
+  // No order from a previous call (first call on this stream / batch size): NOT the caller's order either -- workgroup ids go to
+  // the XCDs round-robin, and how hard an aircraft is tends to follow its index (the config-4 workload: every aircraft = 0, 3, 6
+  // mod 8 needs twice the iterations), so the identity gives three XCDs twice the work of the others.  A fixed stride coprime to
+  // B spreads any such pattern; the results do not depend on the map.
+  const long b = a.order ? (long)__builtin_amdgcn_readfirstlane(a.order[blockIdx.x])
+                         : (a.wave_stride ? (long)(((unsigned long long)blockIdx.x * a.wave_stride) % (unsigned long long)a.B) : (long)blockIdx.x);
   double *const exw = a.ext + (size_t)b * mpc_ext_doubles(N);
   const double *Pg = a.Ppk + (size_t)b * (n * (n + 1) / 2);
   const double *Gg = exw + n, *pred = exw + n + 27 * N;
@@ -1298,6 +1306,10 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
       a.info[1 * a.ld + b] = st.rp;
       a.info[2 * a.ld + b] = st.rd;
       a.info[3 * a.ld + b] = st.rho;
+#ifdef F16_EXP_STAMPW
+      a.info[1 * a.ld + b] = (double)wc0_;                 // diagnostic build: start / end of this solve on the 100 MHz clock
+      a.info[2 * a.ld + b] = (double)wall_clock64();
+#endif
     }
     if (a.status && infeasible) a.status[b] |= F16_ST_QP_INFEASIBLE;
     else if (a.status && (!converged || !ok)) a.status[b] |= F16_ST_QP_MAXITER;
@@ -1315,7 +1327,15 @@ int mpc_wave_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
   (void)ctx;
   if (a.N < 1 || a.N > WAVE_MAXN || !a.gramws) return set_error(F16_EINVAL, "wavefront MPC solver needs 1 <= N <= 30 and a workspace");
   if (a.B > 0x7fffffffL) return set_error(F16_EINVAL, "batch too large for one launch");
-  hipLaunchKernelGGL(wave::k_mpc_wave, dim3((unsigned)a.B), dim3(64), 0, (hipStream_t)stream, a);
+  MpcArgs w = a;
+  static const bool spread = [] { const char *e = getenv("F16_MPC_SPREAD"); return !(e && e[0] == '0'); }();
+  w.wave_stride = 0;
+  if (!a.order && spread && a.B > 16) {
+    static const unsigned primes[] = {2053, 2063, 2069, 2081, 2083, 2087, 2089, 2099};      // (B has at most a few of these factors)
+    for (unsigned p : primes)
+      if (a.B % p != 0) { w.wave_stride = p; break; }
+  }
+  hipLaunchKernelGGL(wave::k_mpc_wave, dim3((unsigned)a.B), dim3(64), 0, (hipStream_t)stream, w);
   return hip_check(hipGetLastError(), "f16_mpc_batch wavefront solve launch");
 }
 

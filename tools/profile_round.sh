@@ -29,6 +29,12 @@ rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CY
   -d $O/prof_dyn -o d -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mpc --no-config5 > /dev/null 2> $O/prof_dyn.err
 rocprofv3 --output-format csv --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_SALU \
   -d $O/prof_dyn2 -o d2 -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mpc --no-config5 > /dev/null 2> $O/prof_dyn2.err
+step "the horizon sweep (env.py:426-436, B = 64, N = 1..150): kernel trace, then HBM-side traffic and issue counters of its solve launch"
+rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_stats_sweep -o sw -- python3 tools/gpu_sweep_only.py 64 150 > $O/prof_stats_sweep.log 2> $O/prof_stats_sweep.err
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/prof_sweep_fetch -o f -- python3 tools/gpu_sweep_only.py 64 150 > /dev/null 2> $O/prof_sweep_fetch.err
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/prof_sweep_write -o w -- python3 tools/gpu_sweep_only.py 64 150 > /dev/null 2> $O/prof_sweep_write.err
+rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE \
+  -d $O/prof_sweep_sq -o s -- python3 tools/gpu_sweep_only.py 64 150 > /dev/null 2> $O/prof_sweep_sq.err
 step "plain bench (the record the profile is compared with)"
 python3 bench.py > $O/bench.json 2> $O/bench.err
 step "done"
