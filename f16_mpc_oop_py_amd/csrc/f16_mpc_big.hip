@@ -82,6 +82,9 @@ __device__ __forceinline__ Lds carve(double *p, int N) {
 // partial sums go to LDS and are added in slot order by whoever consumes them.  (The first version read both operands of every
 // product from LDS: 18 N^2 eight-byte reads per stage, 3.2 MB at N = 150 -- 27 k + 49 k cycles of a 185 k-cycle iteration.)
 typedef const double __attribute__((address_space(4))) *cgptr_t;
+#ifndef F16_TP_UNROLL
+#define F16_TP_UNROLL 1
+#endif
 struct TpPlan { int lo[3], hi[3]; };                     // slots holding the partial sums of step block sb: lo[sb] .. hi[sb]
 template <bool ADJ>
 __device__ __forceinline__ int tp_count(int sb, int N) { return ADJ ? N - 64 * sb : (N < 64 * sb + 64 ? N : 64 * sb + 64); }
@@ -126,6 +129,7 @@ __device__ __forceinline__ void tp_partials(double *part, cgptr_t Gc, const doub
     double acc[ADJ ? 3 : 6];
 #pragma unroll
     for (int k = 0; k < (ADJ ? 3 : 6); ++k) acc[k] = 0.0;
+#pragma unroll F16_TP_UNROLL
     for (int d = d0; d < d1; ++d) {
       cgptr_t g = Gc + 27 * d;
       if (ADJ) {
