@@ -34,3 +34,35 @@ def hip():
     """The product library; GPU tests fail loudly (no fallback) when it is missing."""
     from f16_mpc_oop_py_amd import lib
     return lib.load()
+
+
+# ---- G10: the time histories the reference holds as data files (tools/make_golden.py: g10_time_histories)
+G10_TOL = np.array([0.03, 0.03, 0.03, 3e-3, 2e-3, 2e-3, 5e-3, 1e-3, 5e-4, 3e-3, 1e-3, 1e-3])      # npos epos alt [ft] | phi theta psi [deg] |
+#                                                         vel [ft/s] | alpha beta [deg] | p q r [deg/s]: 5 x the largest
+#                                                         difference seen over 10 s (Simulink's integrator vs explicit Euler at 1 ms)
+G10_OUT_TOL = np.array([2e-5, 2e-5, 3e-5, 1e-5, 2e-3, 2e-3])                                      # nx ny nz mach qbar ps
+
+
+def g10_case(k):
+    """(rows [101,23], xcg, x0 [18], trim command [4], doublet): the initial state is the file's first row, the leading-edge flap
+    at its steady state (utils.py:332-350: lf1 = -alpha, lf2 = 1.38 alpha - 9.05 qbar / ps + 1.45, degrees)."""
+    g = golden("g10_time_histories.npz")
+    a = g[f"rows_{k}"]
+    d2r = np.pi / 180
+    t, npos, epos, alt, phi, th, psi, vel, al, be, p, q, r, nx, ny, nz, mach, qbar, ps, T, el, ail, rud = a[0]
+    lf2 = min(max(1.38 * al - 9.05 * qbar / ps + 1.45, 0.0), 25.0)
+    x0 = np.array([npos, epos, alt, phi * d2r, th * d2r, psi * d2r, vel, al * d2r, be * d2r, p * d2r, q * d2r, r * d2r, T, el, ail, rud,
+                   lf2, -al])
+    return a, float(g[f"xcg_{k}"]), x0, np.array([T, el, ail, rud]), float(g[f"doublet_{k}"])
+
+
+def g10_command(trim_u, doublet, k):
+    """command during sample interval k (0.1 s each): runF16Sim.m's doublet +d on [1, 3) s, -d on [3, 5) s, on all three surfaces"""
+    d = doublet if 10 <= k < 30 else (-doublet if 30 <= k < 50 else 0.0)
+    return trim_u + np.array([0.0, d, d, d])
+
+
+def g10_rows_of_states(s):
+    """[T,18] states -> the file's 12 state columns (angles and rates in degrees)"""
+    r2d = 180 / np.pi
+    return np.column_stack([s[:, 0:3], s[:, 3:6] * r2d, s[:, 6], s[:, 7:9] * r2d, s[:, 9:12] * r2d])

@@ -117,6 +117,44 @@ def test_g6_g7_linearise_c2d_lqr(oracle, xcg):
         np.testing.assert_allclose(u, g["lqr_action_u"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+def test_g10_restated_step_path_vs_the_time_histories_the_reference_holds(oracle, k):
+    """The reference keeps output of its Simulink driver as data files (C/ele_0.100...vel300.txt, Nguyen_m/ele_0.000...txt;
+    runF16Sim.m:100-150): 30 s of the trimmed hifi model at 1 ms, one of them with a 0.1 deg surface doublet.  The restated step
+    path (Nlplant + atmos + actuators + flap model + Euler, env.py:65-130) started from a file's first row reproduces its first
+    10 s -- 12 states and the six plant outputs nx ny nz mach qbar ps at every 0.1 s -- once the roll-damping-by-yaw-rate table is
+    really loaded (the Python reference's C never loads CLr, hifi_F16_AeroData.c:964-972: flag FIX_CLR): an independent pin of
+    rows a1-a11 that owes nothing to the Python reference's own binaries.  Without the flag the lateral states are 30 x further
+    off (asserted: this is what the defect does)."""
+    from conftest import G10_OUT_TOL, G10_TOL, g10_case, g10_command, g10_rows_of_states
+    a, xcg, x0, trim_u, dis = g10_case(k)
+
+    def run(fix):
+        oracle.lib.f16o_set_fix_clr(fix)
+        try:
+            x = x0[None].copy()
+            hist, outs = [x[0].copy()], [oracle.nlplant(x[0], 1, xcg)[12:18]]
+            for j in range(100):
+                x, _, st = oracle.rollout(x, g10_command(trim_u, dis, j)[None], 100, dt=0.001, fi_flag=1, xcg=xcg, store=False)
+                assert int(st[0]) == 0
+                hist.append(x[0].copy())
+                outs.append(oracle.nlplant(x[0], 1, xcg)[12:18])
+        finally:
+            oracle.lib.f16o_set_fix_clr(0)
+        return np.array(hist), np.array(outs)
+
+    s, outs = run(1)
+    err = np.abs(g10_rows_of_states(s) - a[:, 1:13])
+    assert np.all(err.max(0) < G10_TOL), err.max(0)
+    assert np.all(np.abs(outs[0] - a[0, 13:19]) < 6e-6)                  # the first row: the printed precision
+    assert np.all(np.abs(outs - a[:, 13:19]).max(0) < G10_OUT_TOL), np.abs(outs - a[:, 13:19]).max(0)
+    assert np.abs(s[:, 13:16] - a[:, 20:23]).max() < 2e-3               # surface positions (actuator model, utils.py:314-330)
+    if k == 0:
+        s0, _ = run(0)
+        e0 = np.abs(g10_rows_of_states(s0) - a[:, 1:13]).max(0)
+        assert e0[3] > 30 * err[:, 3].max() and e0[9] > 30 * err[:, 9].max()      # phi, p without the real CLr table
+
+
 def test_g5_trim_known_answers():
     g = golden("g567_trim_lin_lqr.npz")
     x = g["trim_x_xcg25"]

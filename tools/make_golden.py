@@ -261,5 +261,42 @@ def main():
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 
 
+G10_FILES = [  # (file under the reference root, cg location it was produced with, surface doublet in degrees)
+    ("C/ele_0.100ail_0.100rud_0.100_hifimodel_alt10000_vel300.txt", 0.30, 0.1),
+    ("Nguyen_m/ele_0.000ail_0.000rud_0.000_hifimodel_alt10000_vel500.txt", 0.30, 0.0),
+    ("Nguyen_m/ele_0.000ail_0.000rud_0.000_hifimodel_alt10000_vel600.txt", 0.30, 0.0),
+    ("Nguyen_m/ele_0.000ail_0.000rud_0.000_hifimodel_alt10000_vel700.txt", 0.25, 0.0)]
+
+
+def g10_time_histories(seconds=10.0):
+    """G10: the time histories the reference HOLDS as data files -- output of its Simulink driver (Nguyen_m/runF16Sim.m:100-150:
+    trim, then 30 s of the nonlinear hifi model at 1 ms, a -1 / +2 / -1 surface doublet between 1, 3 and 5 s, one line per 0.1 s:
+    time, 12 states, nx ny nz mach qbar ps, thrust and the three surface positions, every value '%8.5f,').  No reference code
+    runs here: the first `seconds` of each file are stored as numbers, with the text of the header and of the first row for the
+    writer's format test.  The cg location of each run is not recorded in the file; it is the one at which the file's first row
+    is an equilibrium of the plant (0.30 for three of them, 0.25 for the 700 ft/s run).  The C/...alt5000_vel1000 file is left
+    out: 1000 ft/s is outside the envelope of env.py:117-124."""
+    out = {}
+    for k, (rel, xcg, dis) in enumerate(G10_FILES):
+        lines = open(os.path.join(REF, rel)).read().split("\n")
+        rows = [l for l in lines if l.strip() and l.strip()[0].isdigit()]
+        a = np.array([[float(v) for v in l.strip().strip(",").split(",")] for l in rows])
+        n = int(round(seconds / 0.1)) + 1
+        out[f"rows_{k}"] = a[:n]
+        out[f"xcg_{k}"] = xcg
+        out[f"doublet_{k}"] = dis
+        out[f"name_{k}"] = os.path.basename(rel)
+        if k == 0:
+            out["header_line"] = [l for l in lines if l.startswith("time,")][0]
+            out["first_row_text"] = rows[0]
+            out["second_row_text"] = rows[1]
+    np.savez_compressed(os.path.join(OUT, "g10_time_histories.npz"), **out)
+    print("g10_time_histories.npz", os.path.getsize(os.path.join(OUT, "g10_time_histories.npz")))
+
+
 if __name__ == "__main__":
-    main()
+    if "--g10" in sys.argv:
+        g10_time_histories()
+    else:
+        main()
+        g10_time_histories()
