@@ -66,3 +66,39 @@ def g10_rows_of_states(s):
     """[T,18] states -> the file's 12 state columns (angles and rates in degrees)"""
     r2d = 180 / np.pi
     return np.column_stack([s[:, 0:3], s[:, 3:6] * r2d, s[:, 6], s[:, 7:9] * r2d, s[:, 9:12] * r2d])
+
+
+def g11_case(tag):
+    """(A [18,18], B [18,4], x [18], u [4], fi_flag) of fixture G11 (tools/make_golden.py: g11_state_space); tag "hi" or "lo"."""
+    g = golden("g11_state_space.npz")
+    r = g["trim_row_" + tag]
+    d2r = np.pi / 180
+    al, qbar, ps = r[8], r[17], r[18]
+    if tag == "hi":
+        T, el, ail, rud = r[19:23]
+        lf2 = min(max(1.38 * al - 9.05 * qbar / ps + 1.45, 0.0), 25.0)
+    else:                                       # (the lofi file repeats thrust and elevator in its output columns; no flap)
+        T, el, ail, rud = r[13], r[14], 0.0, 0.0
+        lf2 = 0.0
+    x = np.array([r[1], r[2], r[3], r[4] * d2r, r[5] * d2r, r[6] * d2r, r[7], al * d2r, r[9] * d2r, r[10] * d2r, r[11] * d2r, r[12] * d2r,
+                  T, el, ail, rud, lf2, -al])
+    return g["A_" + tag], g["B_" + tag], x, np.array([T, el, ail, rud]), 1 if tag == "hi" else 0
+
+
+def g11_perturbations(x, u, h=1e-5):
+    """the 44 points of a central-difference Jacobian: (X [44,18], U [44,4]); rows 2j, 2j+1 = +h, -h on state j, then the inputs"""
+    X, U = np.tile(x, (44, 1)), np.tile(u, (44, 1))
+    for j in range(18):
+        X[2 * j, j] += h
+        X[2 * j + 1, j] -= h
+    for j in range(4):
+        U[36 + 2 * j, j] += h
+        U[36 + 2 * j + 1, j] -= h
+    return X, U
+
+
+def g11_jacobians(xdot, h=1e-5):
+    """xdot [44,18] at those points -> (A [18,18], B [18,4])"""
+    A = np.array([(xdot[2 * j] - xdot[2 * j + 1]) / (2 * h) for j in range(18)]).T
+    B = np.array([(xdot[36 + 2 * j] - xdot[36 + 2 * j + 1]) / (2 * h) for j in range(4)]).T
+    return A, B

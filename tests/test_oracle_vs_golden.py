@@ -155,6 +155,32 @@ def test_g10_restated_step_path_vs_the_time_histories_the_reference_holds(oracle
         assert e0[3] > 30 * err[:, 3].max() and e0[9] > 30 * err[:, 9].max()      # phi, p without the real CLr table
 
 
+def test_g11_derivatives_of_the_restated_model_vs_the_state_space_file_the_reference_holds(oracle):
+    """Nguyen_m/StateSpace_alt10000_vel700.txt: A, B of the 18-state hifi and lofi models as the reference's Simulink tooling
+    linearised them (five decimals).  Central differences of the restated `_calc_xdot` (env.py:65-103: plant, actuators, flap
+    model) at the same trim points give the same matrices -- hifi: all 18 x 18 + 18 x 4 entries with the real CLr table (without
+    it d pdot / d r is 0.455 instead of the file's 0.621: asserted); lofi: the 12 rigid-body rows."""
+    from conftest import g11_case, g11_jacobians, g11_perturbations
+
+    def jac(tag, fix):
+        A, B, x, u, fi = g11_case(tag)
+        X, U = g11_perturbations(x, u)
+        oracle.lib.f16o_set_fix_clr(fix)
+        try:
+            xd = np.array([oracle.calc_xdot(X[i], U[i], fi, 0.25) for i in range(44)])
+        finally:
+            oracle.lib.f16o_set_fix_clr(0)
+        return A, B, *g11_jacobians(xd)
+
+    A, B, Ao, Bo = jac("hi", 1)
+    assert np.all(np.abs(Ao - A) < 1.5e-4 * np.maximum(1, np.abs(A))) and np.all(np.abs(Bo - B) < 1e-5)
+    A, B, Ao, Bo = jac("hi", 0)
+    assert abs(A[9, 11] - 0.62087) < 1e-9 and abs(Ao[9, 11] - 0.45504) < 1e-4
+    A, B, Ao, Bo = jac("lo", 0)
+    assert np.all(np.abs(Ao[:12, :16] - A[:12, :16]) < 1.5e-4 * np.maximum(1, np.abs(A[:12, :16])))
+    assert np.all(np.abs(Bo[:16] - B[:16]) < 1e-5)
+
+
 def test_g5_trim_known_answers():
     g = golden("g567_trim_lin_lqr.npz")
     x = g["trim_x_xcg25"]

@@ -294,9 +294,29 @@ def g10_time_histories(seconds=10.0):
     print("g10_time_histories.npz", os.path.getsize(os.path.join(OUT, "g10_time_histories.npz")))
 
 
+def g11_state_space():
+    """G11: the linearised 18-state models the reference HOLDS as a data file (Nguyen_m/StateSpace_alt10000_vel700.txt: A, B of the
+    hifi and of the lofi model at 10,000 ft / 700 ft/s, printed '%8.5f,'; states in the order of parameters.py:116-119 incl. the
+    actuator and flap states) and the trim points they were taken at (first rows of the 700 ft/s time-history files of the same
+    directory).  Numbers only; no reference code runs."""
+    import re
+    txt = open(os.path.join(REF, "Nguyen_m", "StateSpace_alt10000_vel700.txt")).read()
+    out = {}
+    for m in re.finditer(r"(\w+) = \n((?:[ \-\d\.,e]+\n)+)", txt):
+        out[m.group(1)] = np.array([[float(v) for v in l.strip().strip(",").split(",")] for l in m.group(2).strip().split("\n")])
+    for tag, rel in (("hi", "ele_0.000ail_0.000rud_0.000_hifimodel_alt10000_vel700.txt"),
+                     ("lo", "ele_0.000ail_0.000rud_0.000_lofimodel_alt10000_vel700_LTI.txt")):
+        rows = [l for l in open(os.path.join(REF, "Nguyen_m", rel)).read().split("\n") if l.strip() and l.strip()[0].isdigit()]
+        out["trim_row_" + tag] = np.array([float(v) for v in rows[0].strip().strip(",").split(",")])
+    np.savez_compressed(os.path.join(OUT, "g11_state_space.npz"), **out)
+    print("g11_state_space.npz", os.path.getsize(os.path.join(OUT, "g11_state_space.npz")), sorted(out))
+
+
 if __name__ == "__main__":
     if "--g10" in sys.argv:
         g10_time_histories()
+        g11_state_space()
     else:
         main()
         g10_time_histories()
+        g11_state_space()
