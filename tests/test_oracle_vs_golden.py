@@ -179,6 +179,14 @@ def test_g11_derivatives_of_the_restated_model_vs_the_state_space_file_the_refer
     A, B, Ao, Bo = jac("lo", 0)
     assert np.all(np.abs(Ao[:12, :16] - A[:12, :16]) < 1.5e-4 * np.maximum(1, np.abs(A[:12, :16])))
     assert np.all(np.abs(Bo[:16] - B[:16]) < 1e-5)
+    # MATLAB_SS.mat, the file the reference's own test_linearisation loads (test_env.py:186): the same lofi model in full
+    # precision (the trim point is still known to five decimals only); and its eigenvalues as quoted there (:159-176)
+    g = golden("g11_state_space.npz")
+    assert np.abs(g["A_mat"] - A).max() < 6e-6 and np.abs(g["B_mat"] - B).max() < 6e-6
+    assert np.all(np.abs(Ao[:12, :16] - g["A_mat"][:12, :16]) < 5e-5 * np.maximum(1, np.abs(g["A_mat"][:12, :16])))
+    ev = np.linalg.eigvals(np.block([[Ao[:12, :16]], [g["A_mat"][12:16, :16]]]))
+    for known in (-1.3929 + 2.7668j, -0.4478 + 3.9347j, -0.0067 + 0.0670j, -3.7888, -0.0089):
+        assert np.abs(ev - known).min() < 2e-4, known
 
 
 def test_g5_trim_known_answers():

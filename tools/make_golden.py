@@ -308,6 +308,9 @@ def g11_state_space():
                      ("lo", "ele_0.000ail_0.000rud_0.000_lofimodel_alt10000_vel700_LTI.txt")):
         rows = [l for l in open(os.path.join(REF, "Nguyen_m", rel)).read().split("\n") if l.strip() and l.strip()[0].isdigit()]
         out["trim_row_" + tag] = np.array([float(v) for v in rows[0].strip().strip(",").split(",")])
+    import scipy.io                      # MATLAB_SS.mat: what the reference's own test loads (test_env.py:186) -- the LOFI model of the
+    mat = scipy.io.loadmat(os.path.join(REF, "MATLAB_SS.mat"))      # same flight condition in full precision (= A_lo, B_lo to 5e-6)
+    out["A_mat"], out["B_mat"] = mat["A"], mat["B"]
     np.savez_compressed(os.path.join(OUT, "g11_state_space.npz"), **out)
     print("g11_state_space.npz", os.path.getsize(os.path.join(OUT, "g11_state_space.npz")), sorted(out))
 
