@@ -727,6 +727,13 @@ env.build_ssr()
 sw, inf = env._calc_constr_checking_hzn(max_hzn=58, return_info=True)
 np.savez(sys.argv[1], u=sw.cpu().numpy(), iters=inf["iters"].cpu().numpy(), status=inf["status"].cpu().numpy())
 ''' % REPO
+    # other settings go through the same call: the opt-in rule (no equilibration, automatic rho) and the generic one-wave kernels
+    for st in (dict(scaling=0, rho=0.0), dict(max_iter=-40000)):
+        sw2, inf2 = env._calc_constr_checking_hzn(max_hzn=36, settings=st, return_info=True)
+        for N in (1, 30, 33, 36):
+            u, i1 = env._calc_MPC_action(0, 0, 0, N, settings=st, return_info=True)
+            assert torch.equal(torch.nan_to_num(sw2[:, :, N - 1], nan=1e300), torch.nan_to_num(u, nan=1e300)), (st, N)
+            assert torch.equal(inf2["iters"][N - 1], i1["iters"]) and torch.equal(inf2["status"][N - 1], i1["status"]), (st, N)
     f = str(tmp_path / "groups.npz")
     r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, F16_SWEEP_WS_GB="0.002"), capture_output=True, text=True,
                        timeout=600)          # 2 MB: a group per horizon or two (N = 58: 0.46 MB per aircraft)
