@@ -1053,18 +1053,18 @@ static int mpc_work_free(void *block, void *stream) {
 }
 
 // Dispatch-order history of one-shot calls, per (stream, batch size); nullptr = none available (run in caller's order).
-static f16_ctx::sched_entry *mpc_sched_entry(f16_ctx *ctx, void *stream, long B) {
+static f16_ctx::sched_entry *mpc_sched_entry(f16_ctx *ctx, void *stream, long B, int tag = 0) {
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
   for (int i = 0; i < ctx->n_sched; ++i)
-    if (ctx->sched[i].stream == stream && ctx->sched[i].B == B) return &ctx->sched[i];
+    if (ctx->sched[i].stream == stream && ctx->sched[i].B == B && ctx->sched[i].tag == tag) return &ctx->sched[i];
   if (ctx->n_sched >= F16_MAX_SCHED) return nullptr;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
   int32_t *buf = nullptr;
   if (hipMalloc(&buf, 2 * (size_t)B * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   f16_ctx::sched_entry &e = ctx->sched[ctx->n_sched++];
-  e.stream = stream; e.B = B; e.buf = buf; e.valid = 0;
+  e.stream = stream; e.B = B; e.buf = buf; e.valid = 0; e.tag = tag;
   return &e;
 }
 
@@ -1219,9 +1219,20 @@ extern "C" int f16_mpc_hzn_sweep(f16_ctx *ctx, const double *Ad, const double *B
       rc = hip_check(hipGetLastError(), "f16_mpc_hzn_sweep build launch");
       off += mpc_big_sweep_job_doubles(Nn);
     }
+    // Queue order: the pairs of a previous sweep of the same horizons on this stream, costliest first (iterations x N^2) -- a
+    // sweep on states that moved little then ends with its packed phase instead of waiting for a straggler taken late (the
+    // first call: longest horizons first, 3.2 s at B = 64; with the history: see bench.py hzn_sweep).  Scheduling only.
+    const long npairs = (long)(hi - lo + 1) * B;
+    const char *ev = getenv("F16_MPC_DISPATCH_ORDER");
+    f16_ctx::sched_entry *se = (ev && ev[0] == '0') || npairs > 0x3fffffffL ? nullptr : mpc_sched_entry(ctx, stream, npairs, (lo << 16) | hi);
     if (!rc) rc = mpc_big_sweep_launch(ctx, a, lo, hi, (double *)block, u_cmd + (size_t)(lo - hzn_lo) * 3 * ld,
                                        info ? info + (size_t)(lo - hzn_lo) * 4 * ld : nullptr,
-                                       status ? status + (size_t)(lo - hzn_lo) * ld : nullptr, next, stream);
+                                       status ? status + (size_t)(lo - hzn_lo) * ld : nullptr, next, se ? se->buf : nullptr,
+                                       se && se->valid ? se->buf + npairs : nullptr, stream);
+    if (!rc && se) {
+      rc = mpc_big_sweep_order_launch(se->buf, se->buf + npairs, npairs, B, hi, stream);
+      if (!rc) se->valid = 1;
+    }
     const int rf = mpc_work_free(block, stream);
     if (rc || rf) return rc ? rc : rf;
     hi = lo - 1;

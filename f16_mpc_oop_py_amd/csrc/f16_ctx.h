@@ -19,7 +19,8 @@ struct f16_ctx {
   //    kept per (stream, batch size): calls on one stream are ordered, calls on different streams never touch the same
   //    buffer.  Beyond F16_MAX_SCHED entries a call simply runs in the caller's order.
   hipMemPool_t pool;
-  struct sched_entry { void *stream; long B; int32_t *buf; int valid; } sched[16];
+  struct sched_entry { void *stream; long B; int32_t *buf; int valid; int tag; } sched[16];   // tag 0: a batch of B aircraft;
+                                                        // (lo << 16) | hi: the pairs of a horizon sweep (B = their number)
   int n_sched;
 };
 #define F16_MAX_SCHED 16

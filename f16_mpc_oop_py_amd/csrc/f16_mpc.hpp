@@ -85,7 +85,10 @@ int mpc_big_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream);
 // the same states at every horizon lo..hi in one launch (longest first); per horizon [B][mpc_big_sweep_job_doubles(N)] behind base
 size_t mpc_big_sweep_job_doubles(int N);
 int mpc_big_sweep_launch(f16_ctx *ctx, const MpcArgs &a, int lo, int hi, double *base, double *ucmd, double *info, int32_t *status,
-                         unsigned int *next, void *stream);      // next: the work-queue counter, zero at the launch
+                         unsigned int *next, int32_t *iters, const int32_t *order, void *stream);
+// next: the work-queue counter, zero at the launch; iters (may be null): [pairs] iteration count of pair (hi - N) * B + aircraft;
+// order (may be null): the pairs in the order the queue hands them out (mpc_big_sweep_order_launch: costliest first)
+int mpc_big_sweep_order_launch(const int32_t *iters, int32_t *order, long pairs, long B, int hi, void *stream);
 
 // f16_mpc_solve.hip
 constexpr int FAST_MAXN = 32;

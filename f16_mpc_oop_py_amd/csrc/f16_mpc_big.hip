@@ -413,6 +413,8 @@ struct SweepArgs {
   double *ucmd, *info;
   int32_t *status;
   unsigned int *next;         // work queue: the next (horizon, aircraft) pair not yet taken (zeroed before the launch)
+  int32_t *iters;             // [pairs] iteration counts out (pair = (hi - N) * B + aircraft), or null
+  const int32_t *order;       // [pairs] the pairs in queue order (a previous sweep's, costliest first), or null
 };
 __host__ __device__ inline size_t sweep_job_doubles(int N) {      // per aircraft
   const size_t n = 3 * (size_t)N;
@@ -437,10 +439,12 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
     if (w >= total) break;
     long b = w;
     if (sw.hi) {
-      const int j = (int)(w / a.B);
-      b = (w - (long)j * a.B + j) % a.B;                   // rotated per horizon: workgroup ids map to XCDs round-robin, and
-                                                           // how hard an aircraft is repeats from horizon to horizon -- without
-                                                           // the rotation the XCD of the hard ones worked 3 x longer than the rest
+      const long pr = sw.order ? (long)__builtin_amdgcn_readfirstlane(sw.order[w]) : w;
+      const int j = (int)(pr / a.B);
+      b = sw.order ? pr - (long)j * a.B
+                   : (pr - (long)j * a.B + j) % a.B;       // rotated per horizon (first version: workgroup ids dealt out by the
+                                                           // launch went to the XCDs round-robin, and how hard an aircraft is
+                                                           // repeats from horizon to horizon: three XCDs worked 3 x longer)
       a.N = sw.hi - j;
       size_t off = 0;
       for (int Nn = sw.hi; Nn > a.N; --Nn) off += sweep_job_doubles(Nn);
@@ -452,7 +456,8 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
       a.ucmd = sw.ucmd + k * 3 * (size_t)a.ld;
       a.info = sw.info ? sw.info + k * 4 * (size_t)a.ld : nullptr;
       a.status = sw.status ? sw.status + k * (size_t)a.ld : nullptr;
-      a.useq = nullptr; a.iters_out = nullptr;
+      a.useq = nullptr;
+      a.iters_out = sw.iters ? sw.iters + (size_t)j * a.B : nullptr;
     }
 #ifdef F16_EXP_STAMPG
     const unsigned long long wc0 = wall_clock64(), tjob0 = __builtin_amdgcn_s_memtime();
@@ -783,7 +788,8 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
 size_t mpc_big_ws_doubles(int N) { return big::ws_doubles(N); }
 
 static int big_launch(f16_ctx *ctx, const MpcArgs &a, void *stream, int sw_lo, int sw_hi, double *sw_base, double *sw_ucmd,
-                      double *sw_info, int32_t *sw_status, unsigned int *sw_next) {
+                      double *sw_info, int32_t *sw_status, unsigned int *sw_next, int32_t *sw_iters = nullptr,
+                      const int32_t *sw_order = nullptr) {
   (void)ctx;
   static std::mutex mu;
   static bool ready[64] = {};
@@ -801,7 +807,7 @@ static int big_launch(f16_ctx *ctx, const MpcArgs &a, void *stream, int sw_lo, i
   if (sweep && (sw_lo < 1 || sw_hi < sw_lo || sw_hi > BIG_MAXN || !sw_base || !sw_ucmd || !sw_next)) return set_error(F16_EINVAL, "horizon sweep: bad arguments");
   big::SweepArgs sw{};
   sw.lo = sw_lo; sw.hi = sweep ? sw_hi : 0; sw.base = sw_base; sw.ucmd = sw_ucmd; sw.info = sw_info; sw.status = sw_status;
-  sw.next = sw_next;
+  sw.next = sw_next; sw.iters = sw_iters; sw.order = sw_order;
   const size_t lds = big::lds_doubles(sweep ? sw_hi : a.N) * sizeof(double);
   const long total = sweep ? (long)(sw_hi - sw_lo + 1) * a.B : a.B;
   long grid = total < 65536 ? total : 65536;
@@ -820,8 +826,35 @@ int mpc_big_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
 }
 size_t mpc_big_sweep_job_doubles(int N) { return big::sweep_job_doubles(N); }
 int mpc_big_sweep_launch(f16_ctx *ctx, const MpcArgs &a, int lo, int hi, double *base, double *ucmd, double *info, int32_t *status,
-                         unsigned int *next, void *stream) {
-  return big_launch(ctx, a, stream, lo, hi, base, ucmd, info, status, next);
+                         unsigned int *next, int32_t *iters, const int32_t *order, void *stream) {
+  return big_launch(ctx, a, stream, lo, hi, base, ucmd, info, status, next, iters, order);
+}
+
+// order <- the pairs of a sweep by decreasing cost estimate iterations x N^2 (256 buckets of the largest; one workgroup)
+__global__ __launch_bounds__(1024) void k_sweep_order(const int32_t *iters, int32_t *order, long pairs, long B, int hi) {
+  constexpr int NBK = 256;
+  __shared__ int cnt[NBK], base[NBK];
+  __shared__ float red[16];
+  const int t = threadIdx.x;
+  auto cost = [&](long p) { const float N = (float)(hi - (int)(p / B)); return (float)iters[p] * N * N; };
+  float mx = 0.f;
+  for (long p = t; p < pairs; p += 1024) mx = fmaxf(mx, cost(p));
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((t & 63) == 0) red[t >> 6] = mx;
+  for (int i = t; i < NBK; i += 1024) cnt[i] = 0;
+  __syncthreads();
+  for (int i = 0; i < 16; ++i) mx = fmaxf(mx, red[i]);
+  const float sc = mx > 0.f ? (NBK - 1) / mx : 0.f;
+  auto bucket = [&](long p) { const int k = (int)(cost(p) * sc); return NBK - 1 - (k < 0 ? 0 : (k > NBK - 1 ? NBK - 1 : k)); };
+  for (long p = t; p < pairs; p += 1024) atomicAdd(&cnt[bucket(p)], 1);
+  __syncthreads();
+  if (t == 0) { int s = 0; for (int k = 0; k < NBK; ++k) { base[k] = s; s += cnt[k]; } }     // bucket 0 = costliest
+  __syncthreads();
+  for (long p = t; p < pairs; p += 1024) order[atomicAdd(&base[bucket(p)], 1)] = (int32_t)p;
+}
+int mpc_big_sweep_order_launch(const int32_t *iters, int32_t *order, long pairs, long B, int hi, void *stream) {
+  hipLaunchKernelGGL(k_sweep_order, dim3(1), dim3(1024), 0, (hipStream_t)stream, iters, order, pairs, B, hi);
+  return hip_check(hipGetLastError(), "horizon sweep order launch");
 }
 
 }  // namespace f16

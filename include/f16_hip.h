@@ -171,7 +171,9 @@ int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double
  * for that horizon (bit-identical: same kernels).  Horizons <= 32 run one after the other; the longer ones are built per
  * horizon and solved by ONE launch over every (horizon, aircraft) pair, longest horizon first, so that the few solves that
  * need tens of thousands of iterations do not hold a launch of their own.  Workspace: stream-ordered, in groups of horizons
- * of at most F16_SWEEP_WS_GB (default 32) GB (3.3 MB per aircraft at N = 150).  Not capturable. */
+ * of at most F16_SWEEP_WS_GB (default 32) GB (3.5 MB per aircraft at N = 150).  Not capturable.
+ * Scheduling only: a repeated sweep of the same horizons on the same stream takes its pairs costliest-first by the iteration
+ * counts of the previous one (results do not depend on it; F16_MPC_DISPATCH_ORDER=0 switches it off). */
 int f16_mpc_hzn_sweep(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
                       const double *dem, double *u_cmd, double *info, int32_t *status, long B, long ld, int hzn_lo,
                       int hzn_hi, double dt, const f16_qp_settings *s, void *stream);

@@ -727,6 +727,10 @@ env.build_ssr()
 sw, inf = env._calc_constr_checking_hzn(max_hzn=58, return_info=True)
 np.savez(sys.argv[1], u=sw.cpu().numpy(), iters=inf["iters"].cpu().numpy(), status=inf["status"].cpu().numpy())
 ''' % REPO
+    # a repeated sweep takes its pairs in another order (costliest first by the first one's iteration counts): same results
+    sw_b, inf_b = env._calc_constr_checking_hzn(max_hzn=58, return_info=True)
+    assert torch.equal(torch.nan_to_num(sw, nan=1e300), torch.nan_to_num(sw_b, nan=1e300))
+    assert torch.equal(inf["iters"], inf_b["iters"]) and torch.equal(inf["status"], inf_b["status"])
     # other settings go through the same call: the opt-in rule (no equilibration, automatic rho) and the generic one-wave kernels
     for st in (dict(scaling=0, rho=0.0), dict(max_iter=-40000)):
         sw2, inf2 = env._calc_constr_checking_hzn(max_hzn=36, settings=st, return_info=True)

@@ -14,6 +14,10 @@ t0 = time.perf_counter()
 sw, inf = env._calc_constr_checking_hzn(max_hzn=H, return_info=True)
 torch.cuda.synchronize()
 print(f"_calc_constr_checking_hzn({H}) for B = {B}: {time.perf_counter() - t0:.2f} s", flush=True)
+t0 = time.perf_counter()
+sw2 = env._calc_constr_checking_hzn(max_hzn=H)
+torch.cuda.synchronize()
+print(f"again (queue ordered by the first sweep's iteration counts): {time.perf_counter() - t0:.2f} s; identical {bool(torch.equal(torch.nan_to_num(sw, nan=1e300), torch.nan_to_num(sw2, nan=1e300)))}", flush=True)
 it = inf["iters"].cpu().numpy()
 for N in range(1, H + 1):
     print(N, int(it[N - 1].max()), float(it[N - 1].mean()))
