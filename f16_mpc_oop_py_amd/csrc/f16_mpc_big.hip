@@ -56,19 +56,23 @@ __host__ __device__ inline size_t part_doubles(int N) {
   const size_t a = (size_t)(NW > 2 * SWB ? NW : 2 * SWB) * 3 * N, b = (size_t)TP_SLOTS * TP_FWD;
   return a > b ? a : b;
 }
+// The prediction blocks G_d (9 state rows x 3 inputs) in LDS: GS doubles per lag, the six rows that carry bounds (SROW) first and
+// in SROW's order -- 18 doubles, 16-byte aligned: what the Toeplitz stages read -- then rows 0, 1, 7 (equilibration only), one pad.
+constexpr int GS = 28;
+__host__ __device__ constexpr int gslot(int r) { return r == 0 ? 6 : (r == 1 ? 7 : (r == 7 ? 8 : (r == 8 ? 5 : r - 2))); }
 struct Lds {
   double *G, *qv, *pred, *wbuf, *xs, *xt, *rhs, *tv, *Dg, *E9, *Ec, *Er, *cvec, *red, *part, *zpad;
 };
 __host__ __device__ inline size_t lds_doubles(int N) {
   const size_t n = 3 * (size_t)N, m = 12 * (size_t)N;
   auto ev = [](size_t v) { return (v + 1) & ~(size_t)1; };
-  return ev(27 * N) + ev(n) + ev(9 * N) + ev(m) + 5 * ev(n) + ev(9 * N) + ev(n) + ev(n + 3) + ev(n) + ev(NW) + ev(part_doubles(N)) + 8;
+  return ev(GS * N) + ev(n) + ev(9 * N) + ev(m) + 5 * ev(n) + ev(9 * N) + ev(n) + ev(n + 3) + ev(n) + ev(NW) + ev(part_doubles(N)) + 8;
 }
 __device__ __forceinline__ Lds carve(double *p, int N) {
   const int n = 3 * N, m = 12 * N;
   auto take = [&](int k) { double *r = p; p += (k + 1) & ~1; return r; };
   Lds L;
-  L.G = take(27 * N); L.qv = take(n); L.pred = take(9 * N); L.wbuf = take(m);
+  L.G = take(GS * N); L.qv = take(n); L.pred = take(9 * N); L.wbuf = take(m);
   L.xs = take(n); L.xt = take(n); L.rhs = take(n); L.tv = take(n); L.Dg = take(n);
   L.E9 = take(9 * N); L.Ec = take(n); L.Er = take(n + 3); L.cvec = take(n); L.red = take(NW); L.part = take((int)part_doubles(N)); L.zpad = take(8);
   return L;
@@ -111,9 +115,17 @@ __device__ __forceinline__ TpPlan tp_plan(int N) {
   }
   return P;
 }
+#ifdef F16_TP_SMEM
+#define F16_TP_G(d) cgptr_t g = Gc + 27 * (d); constexpr int GR[6] = {6, 9, 12, 15, 18, 24};      /* rows SROW of the workspace copy */
+#else
+// G_d from the LDS copy instead (18 doubles, nine 16-byte reads of one address): with every CU streaming its KKT inverse the
+// scalar loads miss all the way to memory -- stages 24 k + 34 k cycles alone at N = 150, 50 k + 71 k with all 256 CUs busy
+#define F16_TP_G(d) double g[18]; { const double2 *g2_ = reinterpret_cast<const double2 *>(Gl + GS * (d)); \
+    _Pragma("unroll") for (int q_ = 0; q_ < 9; ++q_) { const double2 t_ = g2_[q_]; g[2 * q_] = t_.x; g[2 * q_ + 1] = t_.y; } } \
+    constexpr int GR[6] = {0, 3, 6, 9, 12, 15};
+#endif
 template <bool ADJ>
-__device__ __forceinline__ void tp_partials(double *part, cgptr_t Gc, const double *vec, const double *zpad, int N) {
-  constexpr int SR[6] = {2, 3, 4, 5, 6, 8};               // SROW
+__device__ __forceinline__ void tp_partials(double *part, cgptr_t Gc, const double *Gl, const double *vec, const double *zpad, int N) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
   const int nb = (N + 63) >> 6;
   int U = 0;
@@ -131,7 +143,7 @@ __device__ __forceinline__ void tp_partials(double *part, cgptr_t Gc, const doub
     for (int k = 0; k < (ADJ ? 3 : 6); ++k) acc[k] = 0.0;
 #pragma unroll F16_TP_UNROLL
     for (int d = d0; d < d1; ++d) {
-      cgptr_t g = Gc + 27 * d;
+      F16_TP_G(d)
       if (ADJ) {
         const int ii = i + d;
         const double2 *vp = reinterpret_cast<const double2 *>(ii < N ? vec + 6 * ii : zpad);
@@ -140,13 +152,13 @@ __device__ __forceinline__ void tp_partials(double *part, cgptr_t Gc, const doub
 #pragma unroll
         for (int rr = 0; rr < 6; ++rr)
 #pragma unroll
-          for (int k = 0; k < 3; ++k) acc[k] = fma(g[SR[rr] * 3 + k], v[rr], acc[k]);
+          for (int k = 0; k < 3; ++k) acc[k] = fma(g[GR[rr] + k], v[rr], acc[k]);
       } else {
         const int idx = i - d;
         const double *up = (idx >= 0 && i < N) ? vec + 3 * idx : zpad;
         const double x0 = up[0], x1 = up[1], x2 = up[2];
 #pragma unroll
-        for (int rr = 0; rr < 6; ++rr) acc[rr] = fma(g[SR[rr] * 3 + 2], x2, fma(g[SR[rr] * 3 + 1], x1, fma(g[SR[rr] * 3], x0, acc[rr])));
+        for (int rr = 0; rr < 6; ++rr) acc[rr] = fma(g[GR[rr] + 2], x2, fma(g[GR[rr] + 1], x1, fma(g[GR[rr]], x0, acc[rr])));
       }
     }
     double *out = part + (w + sb) * (ADJ ? TP_ADJ : TP_FWD) + l;
@@ -476,7 +488,8 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
     const TpPlan planF = tp_plan<false>(N), planA = tp_plan<true>(N);
     double *const part = L.part;
     for (int e = l; e < n; e += BLK) qv[e] = exw[e];
-    for (int e = l; e < 27 * N; e += BLK) G[e] = exw[n + e];
+    for (int e = l; e < 27 * N; e += BLK) { const int d = e / 27, rc = e - 27 * d; G[d * GS + gslot(rc / 3) * 3 + rc % 3] = exw[n + e]; }
+    for (int d = l; d < N; d += BLK) G[d * GS + 27] = 0.0;
     for (int e = l; e < 9 * N; e += BLK) pred[e] = exw[n + 27 * N + e];
     __syncthreads();
     // ---------------- bounds of the kept rows (utils.py:129-152): [6N state | 3N command | 3N rate]
@@ -513,7 +526,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
         double mp = 0.0, ma = 0.0;
         for (int i = 0; i < n; ++i) mp = fmax(mp, fabs(Pg[i >= e ? tri(i, e) : tri(e, i)]) * Dg[i]);
         for (int i = jb; i < N; ++i)
-          for (int r = 0; r < 9; ++r) ma = fmax(ma, fabs(G[(i - jb) * 27 + r * 3 + c]) * E9[9 * i + r]);
+          for (int r = 0; r < 9; ++r) ma = fmax(ma, fabs(G[(i - jb) * GS + gslot(r) * 3 + c]) * E9[9 * i + r]);
         ma = fmax(fmax(ma, Ec[e]), fmax(Er[e], Er[e + 3]));
         tv[e] = 1.0 / sqrt(osqp_limit_scaling(Dg[e] * fmax(cs * mp, ma)));
       }
@@ -521,7 +534,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
         const int i = e / 9, r = e - 9 * i;
         double m_ = 0.0;
         for (int jb = 0; jb <= i; ++jb)
-          for (int c = 0; c < 3; ++c) m_ = fmax(m_, fabs(G[(i - jb) * 27 + r * 3 + c]) * Dg[3 * jb + c]);
+          for (int c = 0; c < 3; ++c) m_ = fmax(m_, fabs(G[(i - jb) * GS + gslot(r) * 3 + c]) * Dg[3 * jb + c]);
         wbuf[e] = 1.0 / sqrt(osqp_limit_scaling(E9[e] * m_));          // (m = 12N >= 9N)
       }
       for (int e = l; e < n; e += BLK) {
@@ -573,9 +586,9 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
           const int jb = ib / 3, cb = ib - 3 * jb;
           double s = 0.0;
           for (int i = ja; i < N; ++i) {
-            const double *ga = G + (i - ja) * 27 + ca, *gb = G + (i - jb) * 27 + cb, *wv = E9 + 9 * i;
+            const double *ga = G + (i - ja) * GS + ca, *gb = G + (i - jb) * GS + cb, *wv = E9 + 9 * i;
 #pragma unroll
-            for (int rr = 0; rr < 6; ++rr) s += wv[SROW[rr]] * ga[SROW[rr] * 3] * gb[SROW[rr] * 3];
+            for (int rr = 0; rr < 6; ++rr) s += wv[SROW[rr]] * ga[rr * 3] * gb[rr * 3];        // (kept rows: slots 0..5)
           }
           if (ia == ib) s += Ec[ia] + Er[ia] + Er[ia + 3];
           else if (ia == ib + 3) s -= Er[ia];
@@ -651,7 +664,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
       }
       __syncthreads();
       GSTAMP(0)
-      tp_partials<true>(part, Gc, wbuf, L.zpad, N);
+      tp_partials<true>(part, Gc, G, wbuf, L.zpad, N);
       __syncthreads();
       GSTAMP(1)
       for (int e = l; e < n; e += BLK) rhs[e] = Dg[e] * xs[e] - cs * qv[e] + adjoint(wbuf, e);
@@ -659,7 +672,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
       GSTAMP(2)
       half_symv(xt, Hinv, rhs, n, L.part);                 // x~ (ends with a barrier)
       GSTAMP(3)
-      tp_partials<false>(part, Gc, xt, L.zpad, N);
+      tp_partials<false>(part, Gc, G, xt, L.zpad, N);
       __syncthreads();
       GSTAMP(5)
       // zb~ = E A x~ ; relaxation, projection, dual update
@@ -686,7 +699,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
       if (it % a.s.check_every == 0 || it >= a.s.max_iter) {
         // residuals of the UNSCALED problem (OSQP termination test) + the scaled ones for the rho estimate
         double r1 = 0.0, nAx = 0.0, nz = 0.0, r1s = 0.0, nAxs = 0.0, nzs = 0.0;
-        tp_partials<false>(part, Gc, xs, L.zpad, N);
+        tp_partials<false>(part, Gc, G, xs, L.zpad, N);
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
@@ -704,7 +717,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
         }
         __syncthreads();
         half_symv(xt, HP, xs, n, L.part);                  // P x
-        tp_partials<true>(part, Gc, wbuf, L.zpad, N);
+        tp_partials<true>(part, Gc, G, wbuf, L.zpad, N);
         __syncthreads();
         double r2 = 0.0, nPx = 0.0, nAty = 0.0, nq = 0.0, r2s = 0.0, nPxs = 0.0, nAtys = 0.0, nqs = 0.0;
         for (int e = l; e < n; e += BLK) {
@@ -734,7 +747,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
           supp = block_reduce<true>(supp, L.red);
           __syncthreads();
           if (ndy > a.s.eps_prim_inf && supp < -a.s.eps_prim_inf * ndy) {
-            tp_partials<true>(part, Gc, wbuf, L.zpad, N);
+            tp_partials<true>(part, Gc, G, wbuf, L.zpad, N);
             __syncthreads();
             double nat = 0.0;
             for (int e = l; e < n; e += BLK) nat = fmax(nat, fabs(adjoint(wbuf, e)));

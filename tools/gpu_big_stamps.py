@@ -22,4 +22,7 @@ for N in Ns:
     for k, nm in enumerate(names):
         if nm != "-":
             print(f"   {nm:30s} {s[b, k] / it[b]:9.1f}  ({100 * s[b, k] / s[b].sum():.0f} %)")
+    if B > 256:                                  # all CUs busy: the phases of an aircraft of median length (it never runs alone)
+        bm = int(np.argsort(it)[len(it) // 2])
+        print(f"   aircraft {bm} ({it[bm]:.0f} iterations, all CUs busy): " + " | ".join(f"{nm} {s[bm, k] / it[bm]:.0f}" for k, nm in enumerate(names) if nm != "-"))
     print(f"   set-up (equilibration, Gram product): {sa[b, 10]:.3e} ticks; KKT factorisations: {sa[b, 9]:.0f} x {sa[b, 8] / max(sa[b, 9], 1):.3e} ticks;  batch medians: set-up {np.median(sa[:, 10]):.3e}, factorisations {np.median(sa[:, 9]):.0f} x {np.median(sa[:, 8] / np.maximum(sa[:, 9], 1)):.3e}, iterations {np.median(it):.0f} x {np.median(s[:, :7].sum(1) / it):.0f}")
