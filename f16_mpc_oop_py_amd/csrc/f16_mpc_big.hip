@@ -10,8 +10,8 @@
 //     diagonal halved) that serves x~ = K^-1 rhs with every entry read once: 0.93 MB per product at N = 150 -- a CU takes in
 //     ~33 GB/s from the Infinity Cache (MI355X_MICROARCH.md, gather table), and that stream is the floor of an iteration;
 //   * the inverse is the symmetric sweep, eight pivots per pass over the matrix (sweep_inverse_blocked), in its own function;
-//   * the two block-Toeplitz products of an iteration run with lanes across the horizon steps and the blocks G_d through the
-//     scalar cache (tp_partials);
+//   * the two block-Toeplitz products of an iteration run with lanes across the horizon steps and the blocks G_d as uniform
+//     16-byte reads of an LDS copy (tp_partials);
 //   * vectors (q, pred, x, rhs, E, D, the row vector w) live in LDS, the per-row values of a lane's (up to four) constraint
 //     rows in registers.
 // A sweep over horizons is ONE launch: resident workgroups take (horizon, aircraft) pairs from a work queue, longest horizons
@@ -79,8 +79,9 @@ __device__ __forceinline__ Lds carve(double *p, int N) {
 }
 
 // ---- The two block-Toeplitz products of an iteration, z_i = sum_{j<=i} G_{i-j} u_j (rows SROW) and its adjoint, with LANES
-// ACROSS THE STEPS: at lag d every lane of a wavefront needs the same block G_d -- it comes through the SCALAR cache from the
-// QP workspace (constant address space, uniform address: s_load into SGPRs, which v_fma_f64 reads directly) -- and its own
+// ACROSS THE STEPS: at lag d every lane of a wavefront needs the same block G_d -- nine 16-byte LDS reads of one address (the
+// kept rows of the LDS copy; -DF16_TP_SMEM takes it through the scalar cache from the QP workspace instead: s_load into SGPRs,
+// which v_fma_f64 reads directly -- as fast with 64 aircraft, four times slower with every CU streaming) -- and its own
 // operand step, one LDS read of 3 (forward) or 6 (adjoint) doubles.  The (step block of 64, lag) pairs of the triangle are dealt
 // to the NW wavefronts in equal contiguous shares (a share spans at most two step blocks: TP_SLOTS partial-sum slots); the
 // partial sums go to LDS and are added in slot order by whoever consumes them.  (The first version read both operands of every
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
                  *const HP = Hinv + half_doubles(n);
     __syncthreads();
     if (l < 8) L.zpad[l] = 0.0;
-    const cgptr_t Gc = (cgptr_t)(exw + n);                  // G_k of the workspace through the scalar cache
+    const cgptr_t Gc = (cgptr_t)(exw + n);                  // G_k of the workspace (scalar-cache variant of the stages only)
     const TpPlan planF = tp_plan<false>(N), planA = tp_plan<true>(N);
     double *const part = L.part;
     for (int e = l; e < n; e += BLK) qv[e] = exw[e];
