@@ -578,22 +578,39 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
     for (int e = l; e < n; e += BLK) Dg[e] = sigma / (Dg[e] * Dg[e]);
     __syncthreads();
     const double cinv = 1.0 / cs;
-    // ---------------- A'WA, packed, once (it does not depend on rho): one wavefront per row of the lower triangle
+    // ---------------- A'WA, packed, once (it does not depend on rho): one wavefront per BLOCK row (the three inputs of a step),
+    // a lane per block column: nine entries share the operands of a step -- 42 LDS reads per step for 54 products, where an
+    // entry of its own re-read 18 for 6 (the product was LDS-bound: 11 M of the 19 M set-up cycles at N = 150)
     {
       const int w = __builtin_amdgcn_readfirstlane(l >> 6), ll = l & 63;
-      for (int ia = w; ia < n; ia += NW) {
-        const int ja = ia / 3, ca = ia - 3 * ja;
-        for (int ib = ll; ib <= ia; ib += 64) {
-          const int jb = ib / 3, cb = ib - 3 * jb;
-          double s = 0.0;
+      for (int ja = w; ja < N; ja += NW) {
+        for (int jb = ll; jb <= ja; jb += 64) {
+          double s[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
           for (int i = ja; i < N; ++i) {
-            const double *ga = G + (i - ja) * GS + ca, *gb = G + (i - jb) * GS + cb, *wv = E9 + 9 * i;
+            const double *ga = G + (i - ja) * GS, *gb = G + (i - jb) * GS, *wv = E9 + 9 * i;
 #pragma unroll
-            for (int rr = 0; rr < 6; ++rr) s += wv[SROW[rr]] * ga[rr * 3] * gb[rr * 3];        // (kept rows: slots 0..5)
+            for (int rr = 0; rr < 6; ++rr) {                // (kept rows: slots 0..5; per entry the same order of sums as before)
+              const double wr = wv[SROW[rr]];
+#pragma unroll
+              for (int ca = 0; ca < 3; ++ca) {
+                const double wa = wr * ga[rr * 3 + ca];
+#pragma unroll
+                for (int cb = 0; cb < 3; ++cb) s[ca][cb] += wa * gb[rr * 3 + cb];
+              }
+            }
           }
-          if (ia == ib) s += Ec[ia] + Er[ia] + Er[ia + 3];
-          else if (ia == ib + 3) s -= Er[ia];
-          gram[tri(ia, ib)] = s;
+#pragma unroll
+          for (int ca = 0; ca < 3; ++ca)
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+              const int ia = 3 * ja + ca, ib = 3 * jb + cb;
+              if (ib <= ia) {
+                double v = s[ca][cb];
+                if (ia == ib) v += Ec[ia] + Er[ia] + Er[ia + 3];
+                else if (ia == ib + 3) v -= Er[ia];
+                gram[tri(ia, ib)] = v;
+              }
+            }
         }
       }
     }
