@@ -202,7 +202,9 @@ __device__ __forceinline__ void half_from_packed(double *H, const double *S, int
 // every load of the R rows issued before the first product (R x KT independent 512-byte loads per wavefront in flight: the
 // stream comes from the Infinity Cache or HBM at 1-3 us of latency); the column part accumulates in registers (lane l: columns
 // l + 64 k) and is summed over the wavefronts in a fixed order at the end.  Ends with y complete and a barrier behind it.
-template <int KT, int R>
+// MAXABS: the same pass with (max, |a| x) in place of (+, x): y_j = max_i |S_ij| v_i, the diagonal at half weight (the column
+// norms of the equilibration; the caller adds |S_jj| v_j).
+template <int KT, int R, bool MAXABS>
 __device__ __forceinline__ void half_symv_t(double *y, const double *H, const double *v, int n, double *part) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
   const double *zeros = H + hoff(n) + l;
@@ -227,8 +229,11 @@ __device__ __forceinline__ void half_symv_t(double *y, const double *H, const do
       const double vi = ir < n ? v[ir] : 0.0;
       double dot = 0.0;
 #pragma unroll
-      for (int k = 0; k < KT; ++k) { dot = fma(a[r][k], vj[k], dot); acc[k] = fma(a[r][k], vi, acc[k]); }
-      dot = wave_reduce_dpp<true>(dot);
+      for (int k = 0; k < KT; ++k) {
+        if (MAXABS) { const double aa = fabs(a[r][k]); dot = fmax(dot, aa * vj[k]); acc[k] = fmax(acc[k], aa * vi); }
+        else { dot = fma(a[r][k], vj[k], dot); acc[k] = fma(a[r][k], vi, acc[k]); }
+      }
+      dot = wave_reduce_dpp<!MAXABS>(dot);
       if (l == 0 && ir < n) y[ir] = dot;
     }
   };
@@ -250,21 +255,22 @@ __device__ __forceinline__ void half_symv_t(double *y, const double *H, const do
   for (int j = threadIdx.x; j < n; j += BLK) {
     double s = y[j];
 #pragma unroll
-    for (int ww = 0; ww < NW; ++ww) s += part[ww * n + j];
+    for (int ww = 0; ww < NW; ++ww) s = MAXABS ? fmax(s, part[ww * n + j]) : s + part[ww * n + j];
     y[j] = s;
   }
   __syncthreads();
 }
+template <bool MAXABS = false>
 __device__ __forceinline__ void half_symv(double *y, const double *H, const double *v, int n, double *part) {
   switch ((n + 63) >> 6) {
-    case 1: half_symv_t<1, 2>(y, H, v, n, part); break;
-    case 2: half_symv_t<2, 2>(y, H, v, n, part); break;
-    case 3: half_symv_t<3, 2>(y, H, v, n, part); break;
-    case 4: half_symv_t<4, 2>(y, H, v, n, part); break;
-    case 5: half_symv_t<5, 2>(y, H, v, n, part); break;
-    case 6: half_symv_t<6, 2>(y, H, v, n, part); break;
-    case 7: half_symv_t<7, 2>(y, H, v, n, part); break;
-    default: half_symv_t<8, 2>(y, H, v, n, part); break;
+    case 1: half_symv_t<1, 2, MAXABS>(y, H, v, n, part); break;
+    case 2: half_symv_t<2, 2, MAXABS>(y, H, v, n, part); break;
+    case 3: half_symv_t<3, 2, MAXABS>(y, H, v, n, part); break;
+    case 4: half_symv_t<4, 2, MAXABS>(y, H, v, n, part); break;
+    case 5: half_symv_t<5, 2, MAXABS>(y, H, v, n, part); break;
+    case 6: half_symv_t<6, 2, MAXABS>(y, H, v, n, part); break;
+    case 7: half_symv_t<7, 2, MAXABS>(y, H, v, n, part); break;
+    default: half_symv_t<8, 2, MAXABS>(y, H, v, n, part); break;
   }
 }
 // In-place inverse of the packed SPD matrix S (HBM) by the symmetric sweep; c: LDS scratch [n].  Afterwards S = S^-1.
@@ -521,11 +527,16 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
     for (int e = l; e < 3; e += BLK) Er[n + e] = 0.0;
     for (int e = l; e < 9 * N; e += BLK) E9[e] = 1.0;
     __syncthreads();
+    // (the column norms of P D through the padded half of P: one coalesced pass per norm -- walking the packed triangle by
+    // columns was 20 strided sweeps of 0.8 MB per solve, ~10 M cycles at N = 150; same maxima, bit for bit)
+    half_from_packed(HP, Pg, n);
+    __threadfence_block();
+    __syncthreads();
     for (int pass = 0; pass < a.s.scaling; ++pass) {
+      half_symv<true>(xs, HP, Dg, n, part);                // xs_e = max_i |P_ie| D_i (ends with a barrier)
       for (int e = l; e < n; e += BLK) {                   // column norms of [Pb; Ab]
         const int jb = e / 3, c = e - 3 * jb;
-        double mp = 0.0, ma = 0.0;
-        for (int i = 0; i < n; ++i) mp = fmax(mp, fabs(Pg[i >= e ? tri(i, e) : tri(e, i)]) * Dg[i]);
+        double mp = fmax(xs[e], fabs(Pg[tri(e, e)]) * Dg[e]), ma = 0.0;
         for (int i = jb; i < N; ++i)
           for (int r = 0; r < 9; ++r) ma = fmax(ma, fabs(G[(i - jb) * GS + gslot(r) * 3 + c]) * E9[9 * i + r]);
         ma = fmax(fmax(ma, Ec[e]), fmax(Er[e], Er[e + 3]));
@@ -547,9 +558,9 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
       for (int e = l; e < 9 * N; e += BLK) E9[e] *= wbuf[e];
       __syncthreads();
       double sm = 0.0, qn = 0.0;                          // cost scaling: mean column norm of Pb, ||qb||
+      half_symv<true>(xs, HP, Dg, n, part);
       for (int e = l; e < n; e += BLK) {
-        double mp = 0.0;
-        for (int i = 0; i < n; ++i) mp = fmax(mp, fabs(Pg[i >= e ? tri(i, e) : tri(e, i)]) * Dg[i]);
+        const double mp = fmax(xs[e], fabs(Pg[tri(e, e)]) * Dg[e]);
         sm += cs * Dg[e] * mp;
         qn = fmax(qn, cs * Dg[e] * fabs(qv[e]));
       }
@@ -654,7 +665,6 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
 #endif
       return __syncthreads_and(good) != 0;
     };
-    half_from_packed(HP, Pg, n);
     bool ok = build_minv(rho);
     for (int e = l; e < n; e += BLK) xs[e] = 0.0;
     __syncthreads();

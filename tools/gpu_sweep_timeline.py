@@ -15,6 +15,11 @@ t0 = time.perf_counter()
 sw, inf = env._calc_constr_checking_hzn(max_hzn=H, return_info=True)
 torch.cuda.synchronize()
 print(f"sweep {time.perf_counter() - t0:.2f} s")
+if len(sys.argv) > 3 and sys.argv[3] == "repeat":          # analyse a repeated sweep (queue ordered by the first one's iteration counts)
+    t0 = time.perf_counter()
+    sw, inf = env._calc_constr_checking_hzn(max_hzn=H, return_info=True)
+    torch.cuda.synchronize()
+    print(f"repeated sweep {time.perf_counter() - t0:.2f} s")
 it = inf["iters"].cpu().numpy()[32:]; st = inf["r_prim"].cpu().numpy()[32:] / 1e8; en = inf["r_dual"].cpu().numpy()[32:] / 1e8
 t00 = st.min(); st -= t00; en -= t00
 print(f"launch span {en.max():.2f} s; busy CU-seconds {float((en - st).sum()):.0f} = {float((en - st).sum()) / en.max():.0f} CUs on average")
