@@ -638,7 +638,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
     unsigned long long tS[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     tS[10] = __builtin_amdgcn_s_memtime() - tjob0;        // set-up: equilibration, Gram product
 #endif
-    auto build_minv = [&](double r) {                     // Full <- (c P + sigma D^-2 + r A'WA)^-1
+    auto build_minv = [&](double r) {                     // Hinv <- padded half of (c P + sigma D^-2 + r A'WA)^-1
 #ifdef F16_EXP_STAMPG
       const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
 #endif
