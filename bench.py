@@ -511,8 +511,20 @@ def bench_hzn_sweep(dev, B=64, max_hzn=150):
     torch.cuda.synchronize()
     dt2 = time.perf_counter() - t0
     assert torch.equal(torch.nan_to_num(sw, nan=1e300), torch.nan_to_num(sw2, nan=1e300))
+    # algorithmic bytes of the long horizons' solve launch: every iteration streams the padded half of the KKT inverse once
+    # ((n^2 / 2 + ~32 n) doubles, n = 3 N: csrc/f16_mpc_big.hip hoff); factorisations, set-up and the vectors are not counted
+    def half_bytes(N):
+        n, q = 3 * N, (3 * N) >> 6
+        return 8.0 * (2048 * q * (q + 1) + (n - 64 * q) * (q + 1) * 64 + 64)
+    itn = it.sum(dim=1).cpu().numpy()                      # iterations per horizon, all aircraft
+    stream = float(sum(itn[N - 1] * half_bytes(N) for N in range(33, max_hzn + 1)))
+    roof = {"bound": "hbm", "kernel": "k_mpc_big (one launch over the pairs N = 33..%d)" % max_hzn, "achieved": stream / dt2 / 1e9,
+            "peak": 8000.0, "unit": "GB/s", "frac": stream / dt2 / 8e12, "bytes_per_launch": stream,
+            "traffic": None, "note": "achieved = iterations x padded-half bytes of the KKT inverse over the whole REPEATED call (upper bound "
+            "on the launch time; N <= 32 included in the time, not in the bytes); counters: profiles/r03_sweep.json (FETCH_SIZE 2.8-5.5 TB "
+            "+ WRITE_SIZE 0.5 TB per launch: factorisations and set-up included)"}
     return {"aircraft": B, "max_hzn": max_hzn, "seconds": dt, "seconds_repeated_call": dt2, "solves": int(it.numel()),
-            "solves_per_s": it.numel() / dt,
+            "solves_per_s": it.numel() / dt, "roofline": roof,
             "aircraft_iterations": float(it.sum()), "iterations_max": int(it.max()),
             "certified_infeasible": int((inf["status"] & 128).ne(0).sum()), "settings": "osqp_defaults",
             "note": "horizons <= 32 one call after the other; 33..150: one build launch per horizon, then ONE launch of the "
