@@ -1221,7 +1221,7 @@ extern "C" int f16_mpc_hzn_sweep(f16_ctx *ctx, const double *Ad, const double *B
     }
     // Queue order: the pairs of a previous sweep of the same horizons on this stream, costliest first (iterations x N^2) -- a
     // sweep on states that moved little then ends with its packed phase instead of waiting for a straggler taken late (the
-    // first call: longest horizons first, 2.4 s at B = 64; repeated: 1.65 s; bench.py hzn_sweep).  Scheduling only.
+    // first call: longest horizons first, 2.25 s at B = 64; repeated: 1.6 s; bench.py hzn_sweep).  Scheduling only.
     const long npairs = (long)(hi - lo + 1) * B;
     const char *ev = getenv("F16_MPC_DISPATCH_ORDER");
     f16_ctx::sched_entry *se = (ev && ev[0] == '0') || npairs > 0x3fffffffL ? nullptr : mpc_sched_entry(ctx, stream, npairs, (lo << 16) | hi);

@@ -204,41 +204,49 @@ __device__ __forceinline__ void half_from_packed(double *H, const double *S, int
 // l + 64 k) and is summed over the wavefronts in a fixed order at the end.  Ends with y complete and a barrier behind it.
 // MAXABS: the same pass with (max, |a| x) in place of (+, x): y_j = max_i |S_ij| v_i, the diagonal at half weight (the column
 // norms of the equilibration; the caller adds |S_jj| v_j).
-template <int KT, int R, bool MAXABS>
+// Loads are 16 bytes per lane: lanes 0..31 take one 64-column trip of a row (two columns each), lanes 32..63 the next one.  One CU
+// streams 8-byte-per-lane loads at 25 / 50 / 76 GB/s (0.92 MB from the Infinity Cache / 0.43 MB and 0.92 MB from L2) and
+// 16-byte ones at 45 / 127 / 150 GB/s (tools/micro/cu_stream.hip): the rate follows the load instructions, not the bytes in flight.
+template <int KD, int R, bool MAXABS>                     // KD: pairs of trips covering n columns
 __device__ __forceinline__ void half_symv_t(double *y, const double *H, const double *v, int n, double *part) {
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
-  const double *zeros = H + hoff(n) + l;
-  double vj[KT], acc[KT];
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, hh = l >> 5, m2 = 2 * (l & 31);
+  const int zeros = (int)hoff(n) + m2;                    // (32-bit element offsets: one select per load, scalar base address)
+  double vj[KD][2], acc[KD][2];
 #pragma unroll
-  for (int k = 0; k < KT; ++k) { const int j = l + 64 * k; vj[k] = j < n ? v[j] : 0.0; acc[k] = 0.0; }
-  // two row groups in flight: the loads of the next group are issued before the products of this one (a group per memory
-  // round trip otherwise: 2-3 k cycles each from the Infinity Cache, ten of them per wavefront at N = 100)
-  auto load = [&](double (&a)[R][KT], int i0) {
+  for (int k = 0; k < KD; ++k)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { const int j = 128 * k + 64 * hh + m2 + c; vj[k][c] = j < n ? v[j] : 0.0; acc[k][c] = 0.0; }
+  // two row groups in flight: the loads of the next group are issued before the products of this one
+  auto load = [&](double2 (&a)[R][KD], int i0) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int ir = i0 + NW * r, irc = ir < n ? ir : i0, kr = irc >> 6;
-      const double *row = H + hoff(irc) + l;
+      const int row = (int)hoff(irc) + 64 * hh + m2;
 #pragma unroll
-      for (int k = 0; k < KT; ++k) { const double *p = k <= kr ? row + 64 * k : zeros; a[r][k] = *p; }
+      for (int k = 0; k < KD; ++k) a[r][k] = *reinterpret_cast<const double2 *>(H + (2 * k + hh <= kr ? row + 128 * k : zeros));
     }
   };
-  auto products = [&](const double (&a)[R][KT], int i0) {
+  auto products = [&](const double2 (&a)[R][KD], int i0) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int ir = i0 + NW * r;
       const double vi = ir < n ? v[ir] : 0.0;
       double dot = 0.0;
 #pragma unroll
-      for (int k = 0; k < KT; ++k) {
-        if (MAXABS) { const double aa = fabs(a[r][k]); dot = fmax(dot, aa * vj[k]); acc[k] = fmax(acc[k], aa * vi); }
-        else { dot = fma(a[r][k], vj[k], dot); acc[k] = fma(a[r][k], vi, acc[k]); }
+      for (int k = 0; k < KD; ++k) {
+        const double e[2] = {a[r][k].x, a[r][k].y};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          if (MAXABS) { const double aa = fabs(e[c]); dot = fmax(dot, aa * vj[k][c]); acc[k][c] = fmax(acc[k][c], aa * vi); }
+          else { dot = fma(e[c], vj[k][c], dot); acc[k][c] = fma(e[c], vi, acc[k][c]); }
+        }
       }
       dot = wave_reduce_dpp<!MAXABS>(dot);
       if (l == 0 && ir < n) y[ir] = dot;
     }
   };
   constexpr int STEP = NW * R;
-  double bufA[R][KT], bufB[R][KT];
+  double2 bufA[R][KD], bufB[R][KD];
   if (w < n) load(bufA, w);
   for (int i0 = w; i0 < n; i0 += 2 * STEP) {
     const bool second = i0 + STEP < n;
@@ -250,7 +258,9 @@ __device__ __forceinline__ void half_symv_t(double *y, const double *H, const do
     }
   }
 #pragma unroll
-  for (int k = 0; k < KT; ++k) { const int j = l + 64 * k; if (j < n) part[w * n + j] = acc[k]; }
+  for (int k = 0; k < KD; ++k)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { const int j = 128 * k + 64 * hh + m2 + c; if (j < n) part[w * n + j] = acc[k][c]; }
   __syncthreads();
   for (int j = threadIdx.x; j < n; j += BLK) {
     double s = y[j];
@@ -262,15 +272,11 @@ __device__ __forceinline__ void half_symv_t(double *y, const double *H, const do
 }
 template <bool MAXABS = false>
 __device__ __forceinline__ void half_symv(double *y, const double *H, const double *v, int n, double *part) {
-  switch ((n + 63) >> 6) {
+  switch ((n + 127) >> 7) {
     case 1: half_symv_t<1, 2, MAXABS>(y, H, v, n, part); break;
     case 2: half_symv_t<2, 2, MAXABS>(y, H, v, n, part); break;
     case 3: half_symv_t<3, 2, MAXABS>(y, H, v, n, part); break;
-    case 4: half_symv_t<4, 2, MAXABS>(y, H, v, n, part); break;
-    case 5: half_symv_t<5, 2, MAXABS>(y, H, v, n, part); break;
-    case 6: half_symv_t<6, 2, MAXABS>(y, H, v, n, part); break;
-    case 7: half_symv_t<7, 2, MAXABS>(y, H, v, n, part); break;
-    default: half_symv_t<8, 2, MAXABS>(y, H, v, n, part); break;
+    default: half_symv_t<4, 2, MAXABS>(y, H, v, n, part); break;
   }
 }
 // In-place inverse of the packed SPD matrix S (HBM) by the symmetric sweep; c: LDS scratch [n].  Afterwards S = S^-1.
