@@ -421,11 +421,146 @@ __device__ F16_SWEEP_INLINE bool sweep_inverse_blocked(double *S_, int n, double
   return __syncthreads_and(ok) != 0;
 }
 
-// per-aircraft HBM workspace of this solver (MpcArgs.bigws): Gram packed | K / inverse packed | padded half of the inverse |
-// padded half of P
+// The same blocked sweep on the PADDED layout (row i at hoff(i): 512-byte aligned, so the pass over the matrix moves 16 bytes
+// per lane -- a CU streams those ~1.8 x faster than the 8-byte accesses the packed triangle forces, tools/micro/cu_stream.hip).
+// Lanes 0..31 take one 64-column trip of a row (two columns each), lanes 32..63 the next; entries right of the diagonal inside a
+// row's last trip are padding: computed along, never read as data.  S is left as MINUS the inverse (the copy into the streamed
+// half negates: one pass over the matrix less).
+__device__ __forceinline__ bool sweep_inverse_padded(double *S_, int n, double *cp_, double *tp_) {
+  typedef double __attribute__((address_space(3))) *lds_ptr_t;
+  typedef double __attribute__((address_space(1))) *glb_ptr_t;
+  typedef double dbl2_t __attribute__((ext_vector_type(2)));
+  typedef dbl2_t __attribute__((address_space(1))) *glb2_ptr_t;
+  const lds_ptr_t cp = (lds_ptr_t)cp_, tp = (lds_ptr_t)tp_;
+  const glb_ptr_t S = (glb_ptr_t)S_;
+  constexpr int RU = 8;                                   // rows of a wavefront in flight per column trip
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, hh = l >> 5, m2 = 2 * (l & 31);
+  bool ok = true;
+  for (int k0 = 0; k0 < n; k0 += SWB) {
+    const int nb = n - k0 < SWB ? n - k0 : SWB;
+    __syncthreads();                                      // the previous step's stores are done (block scope: also visible)
+    // 1. the panel
+    for (int e = threadIdx.x; e < nb * k0; e += BLK) {
+      const int p = e / k0, i = e - p * k0;
+      cp[p * n + i] = S[hoff(k0 + p) + i];
+    }
+    for (int e = threadIdx.x; e < (n - k0) * nb; e += BLK) {
+      const int i = k0 + e / nb, p = e - (i - k0) * nb, k = k0 + p;
+      cp[p * n + i] = i >= k ? S[hoff(i) + k] : S[hoff(k) + i];
+    }
+    __syncthreads();
+    // 2. A^-1 (every wavefront the same arithmetic): lane (r, c) of the 8 x 8 block, identity outside nb
+    const int r = l >> 3, c = l & 7;
+    double v = (r < nb && c < nb) ? cp[c * n + k0 + r] : (r == c ? 1.0 : 0.0);
+    for (int p = 0; p < nb; ++p) {
+      const double app = __shfl(v, 9 * p), arp = __shfl(v, 8 * r + p), apc = __shfl(v, 8 * p + c);
+      if (!(app > 0.0)) ok = false;
+      const double d = 1.0 / app;
+      v = r == p ? (c == p ? -d : apc * d) : (c == p ? arp * d : v - arp * d * apc);
+    }
+    v = -v;
+    // 3. T = c A^-1
+    for (int ib = 0; ib < n; ib += BLK) {                 // (whole wavefronts: the shuffles read lanes 0..63)
+      const int ii = ib + threadIdx.x, i = ii < n ? ii : n - 1;
+      double ci[SWB], ti[SWB];
+#pragma unroll
+      for (int p = 0; p < SWB; ++p) { ci[p] = p < nb ? cp[p * n + i] : 0.0; ti[p] = 0.0; }
+#pragma unroll
+      for (int p = 0; p < SWB; ++p)
+#pragma unroll
+        for (int q = 0; q < SWB; ++q) ti[q] = fma(ci[p], __shfl(v, 8 * p + q), ti[q]);
+      if (ii < n) {
+#pragma unroll
+        for (int q = 0; q < SWB; ++q) tp[q * n + i] = ti[q];
+      }
+    }
+    __syncthreads();
+    // 4. the rows outside K (their entries in the block's columns are overwritten in 5)
+    for (int kd = 0; 128 * kd < n; ++kd) {
+      const int j = 128 * kd + 64 * hh + m2, trip = 2 * kd + hh;
+      double cj[SWB][2];
+#pragma unroll
+      for (int p = 0; p < SWB; ++p) { cj[p][0] = j < n ? cp[p * n + j] : 0.0; cj[p][1] = j + 1 < n ? cp[p * n + j + 1] : 0.0; }
+      for (int i0 = 128 * kd + w; i0 < n; i0 += RU * NW) {
+        dbl2_t val[RU];
+        bool on[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          const int i = i0 + u * NW;
+          on[u] = i < n && !(i >= k0 && i < k0 + nb) && trip <= (i >> 6);
+          val[u] = *(glb2_ptr_t)(S + (on[u] ? (int)hoff(i) + j : 0));          // (unconditional: no branch per load)
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          const int i = i0 + u * NW < n ? i0 + u * NW : i0;
+#pragma unroll
+          for (int q = 0; q < SWB; ++q) { const double t = -tp[q * n + i]; val[u].x = fma(t, cj[q][0], val[u].x); val[u].y = fma(t, cj[q][1], val[u].y); }
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+          if (on[u]) *(glb2_ptr_t)(S + (int)hoff(i0 + u * NW) + j) = val[u];
+      }
+    }
+    __syncthreads();                                      // (5 overwrites entries 4 has just updated: other wavefronts' rows)
+    // 5. the block's rows and columns
+    for (int e = threadIdx.x; e < nb * k0; e += BLK) {
+      const int p = e / k0, i = e - p * k0;
+      S[hoff(k0 + p) + i] = tp[p * n + i];
+    }
+    for (int e = threadIdx.x; e < (n - k0 - nb) * nb; e += BLK) {
+      const int i = k0 + nb + e / nb, q = e - (i - k0 - nb) * nb;
+      S[hoff(i) + k0 + q] = tp[q * n + i];
+    }
+    if (w == 0 && r < nb && c <= r) S[hoff(k0 + r) + k0 + c] = -v;
+    __threadfence_block();
+  }
+  __syncthreads();
+  return __syncthreads_and(ok) != 0;
+}
+// H <- the streamed half of MINUS the padded matrix S (what sweep_inverse_padded leaves): diagonal halved, padding zero
+__device__ __forceinline__ void half_from_padded_neg(double *H, const double *S, int n) {
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
+  for (int i = w; i < n; i += NW) {
+    const double *row = S + hoff(i);
+    double *out = H + hoff(i);
+    for (int j = l; j < 64 * ((i >> 6) + 1); j += 64) out[j] = j < i ? -row[j] : (j == i ? -0.5 * row[j] : 0.0);
+  }
+  if (threadIdx.x < 64) H[hoff(n) + threadIdx.x] = 0.0;
+}
+
+// (c P + sigma D^-2 + r A'WA) -> its inverse as the streamed half Hinv; Minv: scratch for the padded matrix.  -DF16_BIG_PADDED_SWEEP
+// only: measured, the factorisation itself is 28 % faster this way (6.9 M against 9.6 M cycles at N = 150), but with this code in
+// the kernel the compiler keeps the per-row state of the lanes in scratch inside the iteration (w + projection 8 k -> 27 k cycles per
+// iteration; the kernel spills ~300 scalar registers either way and small changes tip the vector allocation), a net loss:
+// iteration 41 -> 54 us at N = 150.  The default stays the sweep on the packed triangle.
+__device__ __noinline__ bool kkt_inverse(double *Minv, double *Hinv, const double *Pg_, const double *gram_, const double *Dg_, double cs,
+                                         double r, int n, double *part) {
+  typedef const double __attribute__((address_space(3))) *lds_cptr_t;
+  typedef const double __attribute__((address_space(1))) *glb_cptr_t;
+  typedef double __attribute__((address_space(1))) *glb_ptr_t;
+  const lds_cptr_t Dg = (lds_cptr_t)Dg_;
+  const glb_cptr_t Pg = (glb_cptr_t)Pg_, gram = (glb_cptr_t)gram_;
+  const glb_ptr_t M = (glb_ptr_t)Minv;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), ll = threadIdx.x & 63;
+  __syncthreads();
+  for (int ia = w; ia < n; ia += NW)
+    for (int ib = ll; ib <= ia; ib += 64) {
+      const int e = tri(ia, ib);
+      M[hoff(ia) + ib] = cs * Pg[e] + r * gram[e] + (ia == ib ? Dg[ia] : 0.0);
+    }
+  __threadfence_block();
+  const bool good = sweep_inverse_padded(Minv, n, part, part + SWB * n);
+  half_from_padded_neg(Hinv, Minv, n);
+  __threadfence_block();
+  __syncthreads();
+  return good;
+}
+
+// per-aircraft HBM workspace of this solver (MpcArgs.bigws): Gram packed | K / minus its inverse, padded | padded half of the
+// inverse | padded half of P
 __host__ __device__ inline size_t ws_doubles(int N) {
   const size_t n = 3 * (size_t)N;
-  return n * (n + 1) + 2 * half_doubles((int)n);
+  return n * (n + 1) / 2 + 3 * half_doubles((int)n);
 }
 
 // A sweep over horizons lo..hi in ONE launch (env.py:426-436 solves the same states for every N): workgroup w solves aircraft
@@ -493,7 +628,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
            *E9 = L.E9, *Ec = L.Ec, *Er = L.Er;
     const double *exw = a.ext + (size_t)b * mpc_ext_doubles(N);
     const double *Pg = a.Ppk + (size_t)b * np;
-    double *const gram = a.bigws + (size_t)b * ws_doubles(N), *const Minv = gram + np, *const Hinv = Minv + np,
+    double *const gram = a.bigws + (size_t)b * ws_doubles(N), *const Minv = gram + np, *const Hinv = Minv + half_doubles(n),
                  *const HP = Hinv + half_doubles(n);
     __syncthreads();
     if (l < 8) L.zpad[l] = 0.0;
@@ -648,6 +783,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
 #ifdef F16_EXP_STAMPG
       const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
 #endif
+#ifndef F16_BIG_PADDED_SWEEP      // (default: the sweep on the packed triangle; see kkt_inverse)
       __syncthreads();
       {
         const int w = __builtin_amdgcn_readfirstlane(l >> 6), ll = l & 63;
@@ -658,14 +794,13 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
           }
       }
       __threadfence_block();
-#ifdef F16_BIG_SCALAR_SWEEP
-      const bool good = sweep_inverse_packed(Minv, n, L.cvec);
-#else
       const bool good = sweep_inverse_blocked(Minv, n, L.part, L.part + SWB * n);
-#endif
       half_from_packed(Hinv, Minv, n);
       __threadfence_block();
       __syncthreads();
+#else
+      const bool good = kkt_inverse(Minv, Hinv, Pg, gram, Dg, cs, r, n, L.part);
+#endif
 #ifdef F16_EXP_STAMPG
       tS[8] += __builtin_amdgcn_s_memtime() - tb0; tS[9] += 1;
 #endif
