@@ -1224,7 +1224,9 @@ extern "C" int f16_mpc_hzn_sweep(f16_ctx *ctx, const double *Ad, const double *B
     // first call: longest horizons first, 2.25 s at B = 64; repeated: 1.6 s; bench.py hzn_sweep).  Scheduling only.
     const long npairs = (long)(hi - lo + 1) * B;
     const char *ev = getenv("F16_MPC_DISPATCH_ORDER");
-    f16_ctx::sched_entry *se = (ev && ev[0] == '0') || npairs > 0x3fffffffL ? nullptr : mpc_sched_entry(ctx, stream, npairs, (lo << 16) | hi);
+    const bool one_group = lo == N && hi == hzn_hi;        // (a sweep cut into many groups must not use up the context's few history slots)
+    f16_ctx::sched_entry *se = (ev && ev[0] == '0') || npairs > 0x3fffffffL || !one_group ? nullptr
+                                                                                          : mpc_sched_entry(ctx, stream, npairs, (lo << 16) | hi);
     if (!rc) rc = mpc_big_sweep_launch(ctx, a, lo, hi, (double *)block, u_cmd + (size_t)(lo - hzn_lo) * 3 * ld,
                                        info ? info + (size_t)(lo - hzn_lo) * 4 * ld : nullptr,
                                        status ? status + (size_t)(lo - hzn_lo) * ld : nullptr, next, se ? se->buf : nullptr,
