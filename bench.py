@@ -55,6 +55,9 @@ def parse_args(argv=None):
                          "the ranks it started and exits non-zero with their stderr tails")
     ap.add_argument("--dry-run-stall-rank", type=int, default=-1,
                     help="(test) --dry-run: this rank sleeps instead of entering the first collective")
+    ap.add_argument("--force-group", action="store_true",
+                    help="form a process group even with one rank (F16_DIST_FORCE_GROUP=1): the all-gather and the scalar "
+                         "reductions then execute through RCCL on a one-GPU box, and the `allgather` block is printed")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch path only: rendezvous, shard bookkeeping and the collectives on CPU tensors (no GPU needed)")
     return ap.parse_args(argv)
@@ -132,6 +135,8 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.rank_timeout))
+    if args.force_group:
+        os.environ["F16_DIST_FORCE_GROUP"] = "1"
     if args.dry_run:
         return dry_run(args)
     run(args)
@@ -157,8 +162,8 @@ def dry_run(args):
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": fdist.world_size(), "requested_gpus": args.gpus,
                           "allgather_ok": ok, "max_over_ranks": t,
-                          "backend": dist.get_backend() if world > 1 else None, "versions": versions()}))
-    if world > 1:
+                          "backend": dist.get_backend() if fdist.group_active() else None, "versions": versions()}))
+    if fdist.group_active():
         dist.barrier()
         dist.destroy_process_group()
     if not ok:
@@ -191,8 +196,10 @@ def run(args):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    grouped = fdist.group_active()              # (world > 1, or one rank with --force-group)
+
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -244,14 +251,14 @@ def run(args):
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel_ms": kern_ms, "bytes_per_launch": B * T * BYTES_PER_STORED_STEP,
                      "note": "B=4096: 256 workgroups of 16 aircraft (four lanes per aircraft, four role wavefronts), one per CU; bound by the per-step dependency chain (lookup round trips + fp64 issue), not HBM (DESIGN.md 4)"},
-        "versions": versions(),
+        "versions": versions(), "backend": dist.get_backend() if grouped else None,
         "scaling_note": "1/2/4/8-GPU values exist only where the driver ran this command on an 8-GPU node; the builder's "
                         "box has one GPU (multi-rank paths rehearsed there with F16_DIST_BACKEND=gloo)",
     }
     tr, src = recorded_traffic(B, T)
     out["roofline"]["traffic"] = tr
     out["roofline"]["traffic_source"] = src
-    if world > 1:
+    if grouped:
         # the one data-path collective -- all-gather of the trajectory shards -- timed on its own
         barrier()
         t0 = time.perf_counter()
@@ -292,7 +299,7 @@ def run(args):
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if grouped:
         barrier()
         dist.destroy_process_group()
 
@@ -573,7 +580,7 @@ def bench_closed_loop(args, dev, rank, world, fdist, barrier):
             full = fdist.all_gather_trajectories(traj, layout="ranks")
             barrier()
             tg = fdist.max_over_ranks(time.perf_counter() - t0, dev)
-            res["allgather"] = {"ms": tg * 1e3, "bytes_received_per_gpu": int(full.numel() * 8) if world > 1 else 0,
+            res["allgather"] = {"ms": tg * 1e3, "bytes_received_per_gpu": int(full.numel() * 8) if fdist.group_active() else 0,
                                 "shape": list(full.shape), "world": fdist.world_size()}
             res["aircraft_steps_per_s"] = world * B * steps / dt
             res["aircraft_steps_per_s_including_collation"] = world * B * steps / (dt + tg)

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -65,10 +66,13 @@ extern "C" int f16_create(f16_ctx **out, int device) {
     props.location.type = hipMemLocationTypeDevice;
     props.location.id = device;
     if ((rc = hip_check(hipMemPoolCreate(&c->pool, &props), "hipMemPoolCreate"))) { c->pool = nullptr; f16_destroy(c); return rc; }
-    // Finite release threshold: the fast-path workspace of the documented batch sizes (0.9 GB at B = 8192, N = 30) stays
-    // cached between calls; what a long-horizon sweep leaves behind (1.7 MB per aircraft at N = 150: 7 GB at B = 4096) goes
-    // back to the driver at the next synchronisation instead of staying invisible to torch's allocator until f16_destroy.
+    // Finite release threshold: the fast-path workspace of the documented batch sizes (1.9 GB at B = 8192, N = 30, wavefront
+    // solver) stays cached between calls; what a long-horizon sweep leaves behind (mpc_big_sweep_job_doubles(150) = 4.45 MB per
+    // aircraft at N = 150 -- 3.59 MB of it the solver's own operands, mpc_big_ws_doubles(150) --, 10.4 GB for N = 33..150 at B = 64) goes back to the driver at the next synchronisation instead of
+    // staying invisible to torch's allocator until f16_destroy.  F16_POOL_KEEP_GB overrides the 4 GiB (e.g. 16 for repeated
+    // horizon sweeps or one-shot calls above ~17,000 aircraft at N = 30, whose workspace would otherwise be re-mapped per call).
     uint64_t keep = 4ull << 30;
+    if (const char *e = getenv("F16_POOL_KEEP_GB")) { const double g = atof(e); if (g > 0) keep = (uint64_t)(g * 1073741824.0); }
     (void)hipMemPoolSetAttribute(c->pool, hipMemPoolAttrReleaseThreshold, &keep);
   }
   *out = c;

@@ -1028,10 +1028,10 @@ static int mpc_work_alloc(f16_ctx *ctx, MpcArgs &a, bool with_ext, void *stream,
   const size_t need = (np + (with_ext ? mpc_ext_doubles(a.N) : 0) + (with_gram ? MPC_TILE_DOUBLES : 0) + bigd +
                        (with_pblk ? WAVE_PBLK_DOUBLES : 0)) * (size_t)a.B * sizeof(double);
   *block = nullptr;
-  // Not under stream capture.  Root cause established in round 3 (profiles/r03_capture_pool.log, r03_capture_probe.log): on
-  // ROCm 7.2 a graph that holds a stream-ordered allocation (mem-alloc node ... mem-free node) is not safe beside EAGER
-  // allocations from the same pool -- tools/micro/capture_pool.hip, plain HIP with none of this library's kernels, sees its
-  // graph-owned block overwritten by an eager block of another stream; tools/gpu_capture_probe.py replays the one-shot call
+  // Not under stream capture.  What round 3 established (profiles/r03_capture_pool.log, r03_capture_probe.log): on ROCm 7.2 a
+  // plain-HIP graph with mem-alloc / mem-free nodes (tools/micro/capture_pool.hip, none of this library's kernels) replays
+  // WRONGLY beside eager allocations from the same pool (302,520 wrong elements at replay 11 of 12); the mechanism is not
+  // established -- the logged eager blocks never overlap the graph's block.  tools/gpu_capture_probe.py replays the one-shot call
   // with no host state in the capture (F16_MPC_DISPATCH_ORDER=0): every replay is bit-identical to the eager call EXCEPT the
   // ones with an eager call of the same context enqueued behind them (NaN in 20-200 of 256 aircraft), with either solver.
   // The fault is the runtime's, not in what the capture bakes in; the refusal stays.  A prepared plan owns its workspace for
@@ -1086,7 +1086,7 @@ static int mpc_solve_dispatch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
 }
 
 // mode 0: generic one-wave kernel (build + ADMM); 1: build only (workspace P, A'A, q|G|pred; *keep receives the block,
-// the caller frees it); 2: build, then the register-resident 512-thread solver (N <= 32); 3: build, then the 1024-lane workgroup
+// the caller frees it); 2: build, then the register-resident 512-thread solver (N <= 32); 3: build, then the 512-lane workgroup
 // solver for long horizons (N > 32, f16_mpc_big.hip).
 static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream, int mode, void **keep = nullptr) {
   const int N = a.N;
@@ -1189,7 +1189,7 @@ extern "C" int f16_mpc_hzn_sweep(f16_ctx *ctx, const double *Ad, const double *B
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
     return set_error(F16_EINVAL, "f16_mpc_hzn_sweep cannot be captured into a HIP graph (per-call workspace)");
-  // groups of horizons, longest first, each within the workspace budget (N = 150: 3.3 MB per aircraft)
+  // groups of horizons, longest first, each within the workspace budget (N = 150: 4.45 MB per aircraft = mpc_big_sweep_job_doubles(150) x 8)
   static const size_t budget = [] { const char *e = getenv("F16_SWEEP_WS_GB"); const double g = e ? atof(e) : 0; return (size_t)((g > 0 ? g : 32.0) * (1ull << 30)); }();
   int hi = hzn_hi;
   while (hi >= N) {
@@ -1283,6 +1283,9 @@ extern "C" int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const doub
   }
   const size_t np = (size_t)(3 * hzn) * (3 * hzn + 1) / 2;
   const bool wide = hzn > FAST_MAXN;                   // horizons 33..40: the model part is kept, every solve runs the workgroup solver
+  if (wide) {                                          // its LDS opt-in now: the first solve of the plan may already be under capture
+    if (int rc = mpc_big_opt_in()) { delete p; return rc; }
+  }
   const size_t per = np + mpc_ext_doubles(hzn) + 2 * MPC_TILE_DOUBLES + (wide ? mpc_big_ws_doubles(hzn) : 0);      // P | extras | inverse (scaling = 0) | A'WA | long-horizon operands
   if (int rc = hip_check(hipMalloc(&p->buf, per * (size_t)B * sizeof(double)), "hipMalloc MPC plan")) { delete p; return rc; }
   if (int rc = hip_check(hipMalloc(&p->sched, 2 * (size_t)B * sizeof(int32_t)), "hipMalloc MPC plan")) { (void)hipFree(p->buf); delete p; return rc; }

@@ -36,7 +36,18 @@ struct DynArgs {
   double dt, xcg;
   int fi;
   unsigned flags;
+  // closed loop under the LQR law (f16_rollout_lqr; env.py:360-371 inside the loop of test_env_mk2.py:70-85)
+  const double *K;      // [27][ld] the reference's K = -dlqr (3 x 9 row-major), or null
+  const double *dem;    // [3][ld] p, q, r demands
+  double *u_out;        // [4][ld] the action of the last step (self.u.values after the loop), may be null
 };
+
+// env.py:360-371 `_calc_LQR_action`: u = -K (x_ref - x) + u0 with x_ref = x except x_ref[4:7] = (p, q, r)_dem -- x_ref - x is
+// exactly zero outside the three rate entries, so row i of the product is K[i][4..6] . (dem - (p, q, r)); the thrust command is
+// not an LQR output (test_env_mk2.py:76-79 overwrites u.values[1:] only).  kr = K[i][4..6] of the lane's row.
+F16_DEV double lqr_action(double kr0, double kr1, double kr2, double e0, double e1, double e2, double u0) {
+  return -(kr0 * e0 + kr1 * e1 + kr2 * e2) + u0;
+}
 
 // Cooperative copy of the table image into LDS (16 B per lane per load).
 __device__ __forceinline__ void stage_tables(double *lds, const double *__restrict__ g) {
@@ -85,14 +96,23 @@ __global__ __launch_bounds__(BLOCK) void k_nlplant(DynArgs a) {
 
 // One lane = one aircraft, the whole rollout in registers.  TP = the table image the lookups read (plant header: fp64
 // values or scaled integers).
-template <int BLOCK, int FI, typename TP>
-__device__ __forceinline__ void rollout_lanes(const DynArgs &a, TP T, double (*us)[BLOCK]) {
+template <int BLOCK, int FI, typename TP, bool LQR = false>
+__device__ __forceinline__ void rollout_lanes(const DynArgs &a, TP T, double (*us)[BLOCK], double (*kq)[BLOCK] = nullptr) {
   for (long b = (long)blockIdx.x * BLOCK + threadIdx.x; b < a.B; b += (long)gridDim.x * BLOCK) {
     double x[18];
 #pragma unroll
     for (int k = 0; k < 18; ++k) x[k] = a.out[k * a.ld + b];
 #pragma unroll
     for (int k = 0; k < 4; ++k) us[k][threadIdx.x] = a.u[k * a.ld + b];
+    double ul[3] = {0.0, 0.0, 0.0};
+    if (LQR) {   // K[i][4..6] and the demands: lane-indexed LDS slots like the inputs (constant over the rollout, used once per step)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) kq[3 * i + j][threadIdx.x] = a.K[(9 * i + 4 + j) * a.ld + b];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) kq[9 + j][threadIdx.x] = a.dem[j * a.ld + b];
+    }
     int st = a.status ? a.status[b] : 0;
     double *tr = a.traj ? a.traj + b : nullptr;
     int until_store = a.traj_every;
@@ -103,6 +123,12 @@ __device__ __forceinline__ void rollout_lanes(const DynArgs &a, TP T, double (*u
         double xd[18], u[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) u[k] = us[k][threadIdx.x];
+        if (LQR) {
+          const double e0 = kq[9][threadIdx.x] - x[9], e1 = kq[10][threadIdx.x] - x[10], e2 = kq[11][threadIdx.x] - x[11];
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            ul[i] = u[1 + i] = lqr_action(kq[3 * i][threadIdx.x], kq[3 * i + 1][threadIdx.x], kq[3 * i + 2][threadIdx.x], e0, e1, e2, u[1 + i]);
+        }
         calc_xdot<FI>(T, a.lofi, x, u, xd, a.xcg, a.fi, a.flags, st);
 #pragma unroll
         for (int k = 0; k < 18; ++k) x[k] += xd[k] * a.dt;   // env.py:126
@@ -121,33 +147,40 @@ __device__ __forceinline__ void rollout_lanes(const DynArgs &a, TP T, double (*u
 #pragma unroll
     for (int k = 0; k < 18; ++k) a.out[k * a.ld + b] = x[k];
     if (a.status) a.status[b] = st;
+    if (LQR && a.u_out) {
+      a.u_out[b] = us[0][threadIdx.x];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) a.u_out[(1 + i) * a.ld + b] = ul[i];
+    }
   }
 }
 
-template <int BLOCK, int FI>
+template <int BLOCK, int FI, bool LQR = false>
 __global__ __launch_bounds__(BLOCK) void k_rollout(DynArgs a) {
   __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
   // the four inputs of a lane are constant over the rollout and used once per step: kept in lane-indexed (conflict-free) LDS
   // slots rather than in eight registers that the 512-lane instantiation (256 registers per lane) spilled and reloaded per step
   __shared__ double us[4][BLOCK];
+  __shared__ double kq[LQR ? 12 : 1][LQR ? BLOCK : 1];
   if (a.fi == 1) stage_tables(tab, a.tab);
-  rollout_lanes<BLOCK, FI>(a, (const double *)tab, us);
+  rollout_lanes<BLOCK, FI, const double *, LQR>(a, (const double *)tab, us, reinterpret_cast<double (*)[BLOCK]>(kq));
 }
 
 // The same rollout on the scaled-integer table image (hifi, default numerics; large batches: the LDS pipe -- 1.5 KB of
 // table vertices per aircraft-step as doubles, more than half of its cycles bank-conflict replays of the per-lane gathers --
 // is one of the two ceilings of k_rollout there).
-template <int BLOCK>
+template <int BLOCK, bool LQR = false>
 __global__ __launch_bounds__(BLOCK) void k_rollout_i(DynArgs a) {
   __shared__ __attribute__((aligned(16))) int tab[i32::IMAGE_INTS];
   __shared__ double us[4][BLOCK];
+  __shared__ double kq[LQR ? 12 : 1][LQR ? BLOCK : 1];
   {
     const int4 *src = reinterpret_cast<const int4 *>(a.tab32);
     int4 *dst = reinterpret_cast<int4 *>(tab);
     for (int i = threadIdx.x; i < i32::IMAGE_INTS / 4; i += BLOCK) dst[i] = src[i];
     __syncthreads();
   }
-  rollout_lanes<BLOCK, 1>(a, TabI32{tab}, us);
+  rollout_lanes<BLOCK, 1, TabI32, LQR>(a, TabI32{tab}, us, reinterpret_cast<double (*)[BLOCK]>(kq));
 }
 
 // Four-wavefront rollout (latency regime, hifi): one workgroup = 64 aircraft on the four SIMDs of a CU; the state is
@@ -165,6 +198,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_i(DynArgs a) {
 #else
 #define STAMP(acc)
 #endif
+template <bool LQR>
 __global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
   __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
   __shared__ double xs[17][64], xt[14][64];  // xs: x[0..16] published at step start ; xt: 4 x 3 partial totals, qbar, ps
@@ -185,6 +219,15 @@ __global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
     for (int k = 0; k < 18; ++k) x[k] = a.out[k * a.ld + b];
 #pragma unroll
     for (int k = 0; k < 4; ++k) u[k] = a.u[k * a.ld + b];
+    double kq[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ul[3] = {0.0, 0.0, 0.0};   // LQR (wave 3): K[i][4..6], demands; last action
+    if (LQR && wave == 3) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) kq[3 * i + j] = a.K[(9 * i + 4 + j) * a.ld + b];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) kq[9 + j] = a.dem[j * a.ld + b];
+    }
     int st = a.status ? a.status[b] : 0;
     double *tr = a.traj ? a.traj + b : nullptr;           // next sample to be written by THIS wave
     int until_store = a.traj_every;
@@ -249,6 +292,13 @@ __global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
 #pragma unroll
           for (int k = 0; k < 17; ++k) xq[k] = xa[k];
           xq[17] = x[17];
+          if (LQR) {
+            const double e0 = kq[9] - xa[9], e1 = kq[10] - xa[10], e2 = kq[11] - xa[11];
+            double uc[4] = {u[0], 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) ul[i] = uc[1 + i] = lqr_action(kq[3 * i], kq[3 * i + 1], kq[3 * i + 2], e0, e1, e2, u[1 + i]);
+            actuators_dev(xq, uc, qbar, ps, xd);
+          } else
           actuators_dev(xq, u, qbar, ps, xd);
 #pragma unroll
           for (int k = 12; k < 18; ++k) x[k] += xd[k] * a.dt;   // env.py:126 on the actuator / flap states
@@ -314,6 +364,11 @@ __global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
       for (int k = 0; k < 18; ++k)
         if (k >= k0 && k < k1) { finite = finite && isfinite(x[k]); a.out[k * a.ld + b] = x[k]; }
       if (a.status) atomicOr(&a.status[b], st | (finite ? 0 : ST_NONFINITE));
+      if (LQR && wave == 3 && a.u_out) {
+        a.u_out[b] = u[0];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) a.u_out[(1 + i) * a.ld + b] = ul[i];
+      }
     }
     __syncthreads();
   }
@@ -330,7 +385,7 @@ __global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
 // Owned states are replicated over the sub-lanes of their wave; two barriers per step as in k_rollout_4w.
 // GROUPS = 2 (4096 < B <= 8192): two independent 16-aircraft groups per workgroup share the LDS table image, one role
 // wave of each on every SIMD -- the two dependency chains interleave.
-template <int GROUPS>
+template <int GROUPS, bool LQR = false>
 __global__ __launch_bounds__(256 * GROUPS) void k_rollout_q(DynArgs a) {
   constexpr int NA = 16 * GROUPS;
   __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
@@ -351,6 +406,13 @@ __global__ __launch_bounds__(256 * GROUPS) void k_rollout_q(DynArgs a) {
 #pragma unroll
     for (int k = 0; k < 18; ++k) x[k] = a.out[k * a.ld + b];
     const double ucmd = a.u[s * a.ld + b];                 // wave 3: sub-lane s drives actuator s
+    // LQR (wave 3, sub-lanes 1..3): row s - 1 of K, columns 4..6, and the demands; the action of the last step
+    double kr0 = 0, kr1 = 0, kr2 = 0, dm0 = 0, dm1 = 0, dm2 = 0, ulast = ucmd;
+    if (LQR && wave == 3) {
+      const long row = 9 * (s > 0 ? s - 1 : 0) + 4;
+      kr0 = a.K[row * a.ld + b]; kr1 = a.K[(row + 1) * a.ld + b]; kr2 = a.K[(row + 2) * a.ld + b];
+      dm0 = a.dem[b]; dm1 = a.dem[a.ld + b]; dm2 = a.dem[2 * a.ld + b];
+    }
     double xact = s == 0 ? x[12] : (s == 1 ? x[13] : (s == 2 ? x[14] : x[15]));   // wave 3: its actuator state
     int st = a.status ? a.status[b] : 0;
     double *tr = a.traj ? a.traj + b : nullptr;            // next sample (written by wave 2 from the published state)
@@ -485,8 +547,14 @@ __global__ __launch_bounds__(256 * GROUPS) void k_rollout_q(DynArgs a) {
         if (live) {
           // utils.py:308-330: thrust on sub-lane 0, elevator / aileron / rudder on 1..3 (same form, own limits)
           const double lim = s == 1 ? 25.0 : (s == 2 ? 21.5 : 30.0), rate = s == 1 ? 60.0 : (s == 2 ? 80.0 : 120.0);
+          double uc = ucmd;
+          if (LQR) {
+            const double ua = lqr_action(kr0, kr1, kr2, dm0 - xa[9], dm1 - xa[10], dm2 - xa[11], ucmd);
+            uc = s > 0 ? ua : ucmd;
+            ulast = uc;
+          }
           const double dth = clipd(clipd(ucmd, 1000, 19000) - xact, -10000, 10000);
-          const double dsf = clipd(20.2 * (clipd(ucmd, -lim, lim) - xact), -rate, rate);
+          const double dsf = clipd(20.2 * (clipd(uc, -lim, lim) - xact), -rate, rate);
           double lf1_dot, lf2_dot;
           upd_lef_dev(xa[2], xa[6], xa[7], x[17], x[16], qbar, ps, lf1_dot, lf2_dot);
           xact += (s == 0 ? dth : dsf) * a.dt;             // env.py:126 on the actuator / flap states
@@ -557,6 +625,7 @@ __global__ __launch_bounds__(256 * GROUPS) void k_rollout_q(DynArgs a) {
         bool finite = isfinite(xact);
         if (s < 2) { const double v = s == 0 ? x[16] : x[17]; finite = finite && isfinite(v); a.out[(16 + s) * a.ld + b] = v; }
         if (a.status) atomicOr(&a.status[b], st | (finite ? 0 : ST_NONFINITE));
+        if (LQR && a.u_out) a.u_out[s * a.ld + b] = ulast;
       }
     }
     __syncthreads();
@@ -673,6 +742,59 @@ extern "C" int f16_nlplant_batch(f16_ctx *ctx, const double *xu, double *xdot, i
   return hip_check(hipGetLastError(), "f16_nlplant_batch launch");
 }
 
+// LQR = true: the closed loop of f16_rollout_lqr (same launch rules; the one-lane kernels keep K[i][4..6] and the demands in
+// lane-indexed LDS slots, which a 512-lane workgroup has room for only beside the integer table image)
+template <bool LQR>
+static int rollout_dispatch(f16_ctx *ctx, DynArgs &a, void *stream) {
+  const long B = a.B;
+  const int fi_flag = a.fi;
+  static const long max4w = [] { const char *e = getenv("F16_ROLLOUT_4W_MAXB"); return e ? atol(e) : 64L * 256; }();
+  static const long maxq = [] { const char *e = getenv("F16_ROLLOUT_QUAD_MAXB"); return e ? atol(e) : 16L * 256; }();
+  if (fi_flag == 1 && B <= maxq) {
+    // at most 16 aircraft per CU: four lanes per aircraft, one 16-aircraft workgroup per CU
+    hipLaunchKernelGGL((k_rollout_q<1, LQR>), dim3((unsigned)((B + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a);
+    return hip_check(hipGetLastError(), "f16_rollout launch");
+  }
+  if (fi_flag == 1 && B <= 2 * maxq) {
+    // at most 32 per CU: two 16-aircraft groups per workgroup
+    hipLaunchKernelGGL((k_rollout_q<2, LQR>), dim3((unsigned)((B + 31) / 32)), dim3(512), 0, (hipStream_t)stream, a);
+    return hip_check(hipGetLastError(), "f16_rollout launch");
+  }
+  // (three groups per workgroup leave 168 registers per lane: the roles spill, 3.96 ms against the 4-wave kernel's 2.13)
+  if (fi_flag == 1 && B <= max4w) {
+    // latency regime: four wavefronts per 64 aircraft, one workgroup per CU
+    hipLaunchKernelGGL(k_rollout_4w<LQR>, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a);
+    return hip_check(hipGetLastError(), "f16_rollout launch");
+  }
+  Geometry g = geometry(B, fi_flag);
+#ifdef F16_FAST_DIV
+  // throughput regime, default numerics: lookups on the scaled-integer image
+  static const int use_i32 = [] { const char *e = getenv("F16_ROLLOUT_I32"); return e ? atoi(e) : 1; }();
+  if (fi_flag == 1 && use_i32 && g.block == 512) {
+    a.tab32 = ctx->d_tab32;
+    hipLaunchKernelGGL((k_rollout_i<512, LQR>), dim3(g.grid), dim3(512), 0, (hipStream_t)stream, a);
+    return hip_check(hipGetLastError(), "f16_rollout launch");
+  }
+#endif
+  if (LQR) {
+    if (g.block == 512) g.block = 256;       // (fp64 image + 16 slots of 512 lanes would not fit the 160 KB of a CU)
+    const hipStream_t st = (hipStream_t)stream;
+    if (g.block == 64) {
+      if (fi_flag == 0) hipLaunchKernelGGL((k_rollout<64, 0, LQR>), dim3(g.grid), dim3(64), 0, st, a);
+      else hipLaunchKernelGGL((k_rollout<64, -1, LQR>), dim3(g.grid), dim3(64), 0, st, a);
+    } else if (g.block == 128) {
+      if (fi_flag == 0) hipLaunchKernelGGL((k_rollout<128, 0, LQR>), dim3(g.grid), dim3(128), 0, st, a);
+      else hipLaunchKernelGGL((k_rollout<128, -1, LQR>), dim3(g.grid), dim3(128), 0, st, a);
+    } else {
+      if (fi_flag == 0) hipLaunchKernelGGL((k_rollout<256, 0, LQR>), dim3(g.grid), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((k_rollout<256, -1, LQR>), dim3(g.grid), dim3(256), 0, st, a);
+    }
+    return hip_check(hipGetLastError(), "f16_rollout launch");
+  }
+  LAUNCH_BY_BLOCK_FI(k_rollout, g, (hipStream_t)stream, a);
+  return hip_check(hipGetLastError(), "f16_rollout launch");
+}
+
 extern "C" int f16_rollout(f16_ctx *ctx, double *x, const double *u, double *traj, int32_t *status, long B, long ld,
                            int nsteps, int traj_every, double dt, double xcg, int fi_flag, unsigned flags,
                            void *stream) {
@@ -684,36 +806,23 @@ extern "C" int f16_rollout(f16_ctx *ctx, double *x, const double *u, double *tra
   a.tab = ctx->d_tab; a.lofi = ctx->d_lofi; a.u = u; a.out = x; a.traj = traj; a.status = status;
   a.B = B; a.ld = ld; a.nsteps = nsteps; a.traj_every = traj ? traj_every : nsteps + 1;
   a.dt = dt; a.xcg = xcg; a.fi = fi_flag; a.flags = flags;
-  static const long max4w = [] { const char *e = getenv("F16_ROLLOUT_4W_MAXB"); return e ? atol(e) : 64L * 256; }();
-  static const long maxq = [] { const char *e = getenv("F16_ROLLOUT_QUAD_MAXB"); return e ? atol(e) : 16L * 256; }();
-  if (fi_flag == 1 && B <= maxq) {
-    // at most 16 aircraft per CU: four lanes per aircraft, one 16-aircraft workgroup per CU
-    hipLaunchKernelGGL(k_rollout_q<1>, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a);
-    return hip_check(hipGetLastError(), "f16_rollout launch");
-  }
-  if (fi_flag == 1 && B <= 2 * maxq) {
-    // at most 32 per CU: two 16-aircraft groups per workgroup
-    hipLaunchKernelGGL(k_rollout_q<2>, dim3((unsigned)((B + 31) / 32)), dim3(512), 0, (hipStream_t)stream, a);
-    return hip_check(hipGetLastError(), "f16_rollout launch");
-  }
-  // (three groups per workgroup leave 168 registers per lane: the roles spill, 3.96 ms against the 4-wave kernel's 2.13)
-  if (fi_flag == 1 && B <= max4w) {
-    // latency regime: four wavefronts per 64 aircraft, one workgroup per CU
-    hipLaunchKernelGGL(k_rollout_4w, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a);
-    return hip_check(hipGetLastError(), "f16_rollout launch");
-  }
-  Geometry g = geometry(B, fi_flag);
-#ifdef F16_FAST_DIV
-  // throughput regime, default numerics: lookups on the scaled-integer image
-  static const int use_i32 = [] { const char *e = getenv("F16_ROLLOUT_I32"); return e ? atoi(e) : 1; }();
-  if (fi_flag == 1 && use_i32 && g.block == 512) {
-    a.tab32 = ctx->d_tab32;
-    hipLaunchKernelGGL(k_rollout_i<512>, dim3(g.grid), dim3(512), 0, (hipStream_t)stream, a);
-    return hip_check(hipGetLastError(), "f16_rollout launch");
-  }
-#endif
-  LAUNCH_BY_BLOCK_FI(k_rollout, g, (hipStream_t)stream, a);
-  return hip_check(hipGetLastError(), "f16_rollout launch");
+  return rollout_dispatch<false>(ctx, a, stream);
+}
+
+extern "C" int f16_rollout_lqr(f16_ctx *ctx, double *x, const double *u0, const double *K, const double *dem, double *traj,
+                               double *u_out, int32_t *status, long B, long ld, int nsteps, int traj_every, double dt,
+                               double xcg, int fi_flag, unsigned flags, void *stream) {
+  if (int rc = check_common(ctx, x, u0, B, ld)) return rc;
+  if (!K || !dem) return set_error(F16_EINVAL, "K / dem is NULL");
+  if (nsteps < 0 || (traj && (traj_every < 1 || nsteps % traj_every != 0)))
+    return set_error(F16_EINVAL, "nsteps must be >= 0 and a multiple of traj_every >= 1 when traj is given");
+  if (B == 0 || nsteps == 0) return F16_OK;
+  DynArgs a{};
+  a.tab = ctx->d_tab; a.lofi = ctx->d_lofi; a.u = u0; a.out = x; a.traj = traj; a.status = status;
+  a.B = B; a.ld = ld; a.nsteps = nsteps; a.traj_every = traj ? traj_every : nsteps + 1;
+  a.dt = dt; a.xcg = xcg; a.fi = fi_flag; a.flags = flags;
+  a.K = K; a.dem = dem; a.u_out = u_out;
+  return rollout_dispatch<true>(ctx, a, stream);
 }
 
 extern "C" int f16_xdot_na_batch(f16_ctx *ctx, const double *x_full, const double *x9, const double *u3, double *xdot9,

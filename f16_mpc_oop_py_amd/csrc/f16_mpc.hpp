@@ -79,8 +79,9 @@ constexpr int WAVE_PBLK_DOUBLES = 2 * 36 * 64 * 2;      // P block image | per-l
 bool mpc_wave_enabled(const MpcArgs &a);
 int mpc_wave_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream);
 
-// f16_mpc_big.hip: one 1024-lane workgroup per aircraft, 33 <= N <= 150 (operands in the HBM workspace `bigws`)
+// f16_mpc_big.hip: one 512-lane workgroup per aircraft, 33 <= N <= 150 (operands in the HBM workspace `bigws`)
 size_t mpc_big_ws_doubles(int N);
+int mpc_big_opt_in();      // once per device: the kernel's dynamic-LDS limit (not legal under stream capture)
 int mpc_big_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream);
 // the same states at every horizon lo..hi in one launch (longest first); per horizon [B][mpc_big_sweep_job_doubles(N)] behind base
 size_t mpc_big_sweep_job_doubles(int N);

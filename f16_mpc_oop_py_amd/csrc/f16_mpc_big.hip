@@ -33,7 +33,7 @@ namespace big {
 #define F16_BIG_BLK 512
 #endif
 constexpr int BLK = F16_BIG_BLK, NW = BLK / 64;
-constexpr int TM = (12 * BIG_MAXN + BLK - 1) / BLK;          // constraint rows per lane (2)
+constexpr int TM = (12 * BIG_MAXN + BLK - 1) / BLK;          // constraint rows per lane (4 at 512 lanes)
 
 // block-wide reduction of one value (sum, or max of non-negative values); every lane receives the result
 template <bool SUM>
@@ -969,21 +969,29 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
 
 size_t mpc_big_ws_doubles(int N) { return big::ws_doubles(N); }
 
-static int big_launch(f16_ctx *ctx, const MpcArgs &a, void *stream, int sw_lo, int sw_hi, double *sw_base, double *sw_ucmd,
-                      double *sw_info, int32_t *sw_status, unsigned int *sw_next, int32_t *sw_iters = nullptr,
-                      const int32_t *sw_order = nullptr) {
-  (void)ctx;
+// k_mpc_big's dynamic LDS exceeds the default limit: opt in ONCE per device, to the BIG_MAXN size (never per launch; attribute
+// calls are not legal under stream capture, so f16_mpc_plan_create calls this for wide plans before any solve can be captured).
+int mpc_big_opt_in() {
   static std::mutex mu;
   static bool ready[64] = {};
   int dev = 0;
   if (int rc = hip_check(hipGetDevice(&dev), "hipGetDevice")) return rc;
+  std::lock_guard<std::mutex> lk(mu);
+  if (dev < 0 || dev >= 64 || ready[dev]) return F16_OK;
+  if (int rc = hip_check(hipFuncSetAttribute((const void *)big::k_mpc_big, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)(big::lds_doubles(BIG_MAXN) * sizeof(double))), "hipFuncSetAttribute(k_mpc_big)")) return rc;
+  ready[dev] = true;
+  return F16_OK;
+}
+
+static int big_launch(f16_ctx *ctx, const MpcArgs &a, void *stream, int sw_lo, int sw_hi, double *sw_base, double *sw_ucmd,
+                      double *sw_info, int32_t *sw_status, unsigned int *sw_next, int32_t *sw_iters = nullptr,
+                      const int32_t *sw_order = nullptr) {
+  (void)ctx;
   {
-    std::lock_guard<std::mutex> lk(mu);
-    if (dev >= 0 && dev < 64 && !ready[dev]) {           // once per device, to the BIG_MAXN size (never per launch; not legal under capture)
-      if (int rc = hip_check(hipFuncSetAttribute((const void *)big::k_mpc_big, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)(big::lds_doubles(BIG_MAXN) * sizeof(double))), "hipFuncSetAttribute(k_mpc_big)")) return rc;
-      ready[dev] = true;
-    }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    if (!capturing) { if (int rc = mpc_big_opt_in()) return rc; }      // (a captured plan solve: done by f16_mpc_plan_create)
   }
   const bool sweep = sw_hi > 0;
   if (sweep && (sw_lo < 1 || sw_hi < sw_lo || sw_hi > BIG_MAXN || !sw_base || !sw_ucmd || !sw_next)) return set_error(F16_EINVAL, "horizon sweep: bad arguments");
@@ -994,7 +1002,8 @@ static int big_launch(f16_ctx *ctx, const MpcArgs &a, void *stream, int sw_lo, i
   const long total = sweep ? (long)(sw_hi - sw_lo + 1) * a.B : a.B;
   long grid = total < 65536 ? total : 65536;
   if (sweep) {                                            // resident workgroups only (two per CU at most: LDS)
-    int cus = 256;
+    int cus = 256, dev = 0;
+    (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (grid > 2L * cus) grid = 2L * cus;
   }

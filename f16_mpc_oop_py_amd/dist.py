@@ -21,11 +21,25 @@ def shard_bounds(total, world, rank):
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/LOCAL_RANK/MASTER_* (torchrun contract).
-    Returns (rank, world, local_rank).  World size 1 needs no process group."""
+    Returns (rank, world, local_rank).  World size 1 needs no process group; F16_DIST_FORCE_GROUP=1 forms one anyway
+    (MASTER_ADDR / MASTER_PORT default to 127.0.0.1 / a free port): every collective of this module then really runs
+    through the backend -- the way to execute the RCCL path on a one-GPU box (tests/test_gpu_dist_rccl.py,
+    `bench.py --force-group`)."""
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("F16_DIST_FORCE_GROUP") == "1"
+    if world == 1 and force and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            s.close()
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool
         # F16_DIST_BACKEND=gloo: rehearsal of the multi-rank paths on a box with fewer GPUs than ranks
         backend = backend or os.environ.get("F16_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -44,6 +58,11 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def group_active():
+    """A process group exists (world size 1 included, F16_DIST_FORCE_GROUP): the collectives go through the backend."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def all_gather_trajectories(traj_local, total=None, layout="flat", chunk_bytes=1 << 28, algo="collective"):
     """Collate the per-rank trajectory shards traj_local [T,18,Bl] (equal Bl on every rank; global aircraft
     g = rank*Bl + b) on every rank.
@@ -60,7 +79,7 @@ def all_gather_trajectories(traj_local, total=None, layout="flat", chunk_bytes=1
         SURVEY.md 8(e) describes for the xGMI mesh (7 links per GPU), beside the library's all-gather ("collective").  Same
         result; `bench.py` times both on a multi-GPU run."""
     W = world_size()
-    if W == 1:
+    if not group_active():
         return traj_local if layout == "flat" else traj_local.unsqueeze(2)
     T, K, Bl = traj_local.shape
     src = traj_local.contiguous()
@@ -76,7 +95,7 @@ def all_gather_trajectories(traj_local, total=None, layout="flat", chunk_bytes=1
                 to, frm = (me + d) % W, (me - d) % W
                 ops.append(dist.P2POp(dist.isend, src, to))
                 ops.append(dist.P2POp(dist.irecv, recv[frm], frm))
-            for r in dist.batch_isend_irecv(ops):
+            for r in (dist.batch_isend_irecv(ops) if ops else []):
                 r.wait()
             return recv.permute(1, 2, 0, 3)
         dist.all_gather_into_tensor(recv.view(-1), src.view(-1))          # flat: valid for RCCL and gloo
@@ -97,7 +116,7 @@ def all_gather_trajectories(traj_local, total=None, layout="flat", chunk_bytes=1
 
 def max_over_ranks(value, device=None):
     """max of a Python float over all ranks (the bench's timing rule)."""
-    if world_size() == 1:
+    if not group_active():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -105,7 +124,7 @@ def max_over_ranks(value, device=None):
 
 
 def sum_over_ranks(value, device=None):
-    if world_size() == 1:
+    if not group_active():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -119,7 +138,7 @@ def or_status(status):
     for bit in (1, 2, 4, 8, 16, 32, 64, 128):
         if (s & bit).any():
             v |= bit
-    if world_size() == 1:
+    if not group_active():
         return v
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([(v >> k) & 1 for k in range(8)], dtype=torch.int32, device=dev)
@@ -131,7 +150,9 @@ def closed_loop_mpc_rollout(env, steps, hzn, p_dem=0.0, q_dem=0.0, r_dem=0.0, tr
     """BASELINE config 5 / test_env.py:480-495 pattern on this rank's shard, then one all-gather:
     per step  cmd = calc_MPC_action(p,q,r,hzn); u.values[1:] = cmd; step(u.values).
     use_plan: the model is frozen (env.py:49-60), so the model-only part of the QP is prepared once
-    (F16Batch.prepare_MPC) -- same commands bit for bit, about two thirds of the time per step.
+    (F16Batch.prepare_MPC) -- same commands bit for bit.  With the reference's solver settings (OSQP defaults) a plan saves
+    the QP build only: the equilibration looks at q, i.e. at the state of the call, so it and the factorisation are redone
+    per solve (bench.py reports both legs at equal length); with the opt-in rule the factorisation is cached as well.
     (A HIP-graph replay of the step was measured and is SLOWER than the six eager launches on ROCm 7.2: 0.50 vs
     0.19 ms per step at B = 256, 3.36 vs 3.15 ms at B = 8192 -- the step is kept capture-safe but launched eagerly.)
     Returns the collated trajectory [steps//traj_every, 18, B_total] (or the local shard if gather=False)."""

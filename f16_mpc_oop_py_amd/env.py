@@ -95,7 +95,9 @@ class F16Batch:
             t = t.unsqueeze(0).expand(self.B, -1)
         if rows is not None:
             assert t.shape[1] == rows, (tuple(t.shape), rows)
-        return t.t().contiguous()
+        out = t.t().contiguous()
+        # (a [k,B] device tensor viewed as [B,k] comes back as the SAME storage: the resident copies must not alias their source)
+        return out.clone() if isinstance(a, torch.Tensor) and out.data_ptr() == a.data_ptr() else out
 
     @property
     def _stream(self):
@@ -322,6 +324,31 @@ class F16Batch:
         x_ref[:, 4], x_ref[:, 5], x_ref[:, 6] = p_dem, q_dem, r_dem
         return -(K @ (x_ref - x).unsqueeze(-1)).squeeze(-1) + u0
 
+    def rollout_LQR(self, nsteps, p_dem, q_dem, r_dem, K=None, u0=None, traj_every=None):
+        """The reference's nonlinear LQR loop (test_env_mk2.py:70-85; flight_sim.py:139,181) as ONE launch: per step
+        `u = _calc_LQR_action(p_dem, q_dem, r_dem, K, x._get_mpc_x(), u.initial_condition[1:])`, `u.values[1:] = u`,
+        `step(u.values)`, the state in registers for all nsteps.  K [B,3,9] defaults to `_calc_LQR_gain()` at the current
+        point, u0 [B,4] to u.initial_condition; demands scalars or [B].  u.values ends up holding the last action, as in
+        the reference.  traj_every=k returns the states after every k-th step, [nsteps//k, 18, B]."""
+        if K is None:
+            K = self._calc_LQR_gain()
+        Ks = torch.as_tensor(K, device=self.device, dtype=torch.float64).reshape(self.B, 27).t().contiguous()
+        u0s = self._u_init if u0 is None else self._soa(u0, 4)
+        dem = torch.empty((3, self.B), dtype=torch.float64, device=self.device)
+        for k, v in enumerate((p_dem, q_dem, r_dem)):
+            if isinstance(v, (int, float)):
+                dem[k].fill_(float(v))
+            else:
+                dem[k] = torch.as_tensor(v, dtype=torch.float64, device=self.device)
+        traj = None
+        if traj_every:
+            assert nsteps % traj_every == 0
+            traj = torch.empty((nsteps // traj_every, 18, self.B), dtype=torch.float64, device=self.device)
+        self._check(self.lib.f16_rollout_lqr(self.ctx.handle, _vp(self._x), _vp(u0s), _vp(Ks), _vp(dem), _vp(traj), _vp(self._u),
+                                             _vp(self.status), self.B, self.B, int(nsteps), int(traj_every or 1), self.dt,
+                                             self.xcg, self.fi_flag, self.flags, self._stream))
+        return traj
+
     # ------------------------------------------------------------------ env.py:373-424
     def prepare_MPC(self, hzn, settings=None, warm_start=False):
         """Prepare the model-only part of calc_MPC_action for horizon hzn from the frozen reduced model self.ssr
@@ -448,6 +475,7 @@ class F16Batch:
         self._check(self.lib.f16_mpc_hzn_sweep(self.ctx.handle, _vp(Ad), _vp(Bd), _vp(Cd), _vp(self._x), _vp(dem), _vp(ucmd),
                                                _vp(info), _vp(st), self.B, self.B, 1, int(max_hzn), self.dt, ctypes.byref(s),
                                                self._stream))
+        self.last_status = st
         out = ucmd.permute(2, 1, 0)
         if return_info:
             return out, dict(iters=info[:, 0], r_prim=info[:, 1], r_dual=info[:, 2], rho=info[:, 3], status=st)

@@ -56,7 +56,7 @@ def _fingerprint():
     return h.hexdigest()
 
 
-def _compile_and_link(srcs, flags, out, verbose=False, stamp=None, fp=None):
+def _compile_and_link(srcs, flags, out, verbose=False, stamp=None, fp=None, force=False):
     """One object per source, compiled in parallel and cached under build/obj/ by a hash of (source, every header, flags);
     then one link.  A change to one kernel file recompiles that file only.  One builder at a time per tree (file lock);
     the stamp is re-checked after the lock is taken and written inside it, so that the ranks of a multi-GPU run that all
@@ -68,8 +68,8 @@ def _compile_and_link(srcs, flags, out, verbose=False, stamp=None, fp=None):
     lock = open(os.path.join(objdir, ".lock"), "w")
     fcntl.flock(lock, fcntl.LOCK_EX)
     try:
-        if stamp and fp and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == fp:
-            return                      # another process built it while this one waited for the lock
+        if not force and stamp and fp and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == fp:
+            return                      # another process built it while this one waited for the lock (force: relink regardless)
         _compile_and_link_locked(srcs, flags, out, verbose, hipcc, objdir)
         if stamp and fp:
             with open(stamp + ".tmp", "w") as f:
@@ -119,7 +119,7 @@ def build(force=False, verbose=False):
     stamp = SO_PATH + ".stamp"
     if not force and os.path.exists(SO_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == fp:
         return SO_PATH
-    _compile_and_link(srcs, HIPCC_FLAGS + os.environ.get("F16_HIPCC_EXTRA", "").split(), SO_PATH, verbose, stamp, fp)
+    _compile_and_link(srcs, HIPCC_FLAGS + os.environ.get("F16_HIPCC_EXTRA", "").split(), SO_PATH, verbose, stamp, fp, force)
     return SO_PATH
 
 
@@ -133,7 +133,7 @@ def build_strict(force=False):
     if not force and os.path.exists(STRICT_SO_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == h:
         return STRICT_SO_PATH
     flags = [f for f in HIPCC_FLAGS if f not in _NUMERICS] + ["-ffp-contract=off"]
-    _compile_and_link(srcs, flags, STRICT_SO_PATH, False, stamp, h)
+    _compile_and_link(srcs, flags, STRICT_SO_PATH, False, stamp, h, force)
     return STRICT_SO_PATH
 
 
@@ -192,6 +192,7 @@ def load():
     L.f16_xdot_batch.argtypes = [vp, vp, vp, vp, vp, l, l, d, i, u, vp]
     L.f16_nlplant_batch.argtypes = [vp, vp, vp, vp, l, l, d, i, u, vp]
     L.f16_rollout.argtypes = [vp, vp, vp, vp, vp, l, l, i, i, d, d, i, u, vp]
+    L.f16_rollout_lqr.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, l, l, i, i, d, d, i, u, vp]
     L.f16_xdot_na_batch.argtypes = [vp, vp, vp, vp, vp, vp, l, l, d, i, u, vp]
     L.f16_debug_table_lookup.argtypes = [vp, i, vp, vp, vp, i, vp, vp]
     if hasattr(L, "f16_trim_batch"):

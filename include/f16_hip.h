@@ -98,6 +98,18 @@ int f16_nlplant_batch(f16_ctx *ctx, const double *xu, double *xdot, int32_t *sta
 int f16_rollout(f16_ctx *ctx, double *x, const double *u, double *traj, int32_t *status,
                 long B, long ld, int nsteps, int traj_every, double dt, double xcg, int fi_flag,
                 unsigned flags, void *stream);
+/* The reference's closed loop under its LQR controller (the only controller its drivers actually run: flight_sim.py:139,181;
+ * nonlinear loop test_env_mk2.py:70-85) as ONE launch: per step the action of env.py:360-371
+ *     u[1:4] = -K (x_ref - x9) + u0[1:4],   x9 = x[mpc idx] (parameters.py:135), x_ref = x9 with x_ref[4:7] = (p, q, r)_dem
+ * from the state at the start of the step, the thrust command u0[0] held (test_env_mk2.py:79 overwrites u.values[1:] only),
+ * then env.py:105-130 step -- inside the same kernels f16_rollout launches, the state in registers for all nsteps.
+ * K[27][ld]: the gain as the reference holds it (`_calc_LQR_gain` returns K = -dlqr; 3 x 9 row-major: f16_lqr_batch's output);
+ * dem[3][ld]; u0[4][ld] = u.initial_condition.  x in place; traj as in f16_rollout; u_out (may be NULL) [4][ld] receives the
+ * action of the last step (what self.u.values holds after the loop).  (x_ref - x9 is exactly zero outside the three rate
+ * entries, so only K[:, 4:7] enters the product.) */
+int f16_rollout_lqr(f16_ctx *ctx, double *x, const double *u0, const double *K, const double *dem, double *traj,
+                    double *u_out, int32_t *status, long B, long ld, int nsteps, int traj_every, double dt, double xcg,
+                    int fi_flag, unsigned flags, void *stream);
 /* env.py:152-193 _calc_xdot_na: x9[9][ld], u3[3][ld] scattered over x_full[18][ld] -> xdot9[9][ld] */
 int f16_xdot_na_batch(f16_ctx *ctx, const double *x_full, const double *x9, const double *u3, double *xdot9,
                       int32_t *status, long B, long ld, double xcg, int fi_flag, unsigned flags, void *stream);
@@ -171,7 +183,7 @@ int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double
  * for that horizon (bit-identical: same kernels).  Horizons <= 32 run one after the other; the longer ones are built per
  * horizon and solved by ONE launch over every (horizon, aircraft) pair, longest horizon first, so that the few solves that
  * need tens of thousands of iterations do not hold a launch of their own.  Workspace: stream-ordered, in groups of horizons
- * of at most F16_SWEEP_WS_GB (default 32) GB (3.5 MB per aircraft at N = 150).  Not capturable.
+ * of at most F16_SWEEP_WS_GB (default 32) GB (4.45 MB per aircraft at N = 150: P, the QP extras and the solver's 3.59 MB of operands).  Not capturable.
  * Scheduling only: a repeated sweep of the same horizons on the same stream takes its pairs costliest-first by the iteration
  * counts of the previous one (results do not depend on it; F16_MPC_DISPATCH_ORDER=0 switches it off). */
 int f16_mpc_hzn_sweep(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,

@@ -551,3 +551,37 @@ void f16o_rollout(double *x, const double *u, long B, int T, double dt, int fi_f
     if (status) status[b] = st;
   }
 }
+
+/* The reference's nonlinear LQR loop (test_env_mk2.py:70-85): per step u = _calc_LQR_action(p, q, r, K, x._get_mpc_x(),
+ * u.initial_condition[1:]) (env.py:360-371: x_ref = copy of x9 with [4:7] = demands; u = -K (x_ref - x9) + u0), u.values[1:] = u,
+ * step(u.values) (env.py:105-130).  x [B][18] in place, u0 [B][4], K [B][27] (3 x 9 row-major, the reference's K = -dlqr),
+ * dem [B][3]; traj (may be NULL) [T][B][18]; u_out (may be NULL) [B][4] = u.values after the loop. */
+void f16o_rollout_lqr(double *x, const double *u0, const double *K, const double *dem, long B, int T, double dt, int fi_flag,
+                      double xcg, double *traj, double *u_out, int *status, int nthreads) {
+  f16o_init();
+  (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 1 ? nthreads : 1)
+#endif
+  for (long b = 0; b < B; ++b) {
+    int st = status ? status[b] : 0;
+    double u[4];
+    memcpy(u, u0 + 4 * b, sizeof u);
+    for (int t = 0; t < T; ++t) {
+      if (!(st & F16O_ST_ENVELOPE)) {
+        double x9[9], xr[9];
+        for (int i = 0; i < 9; ++i) x9[i] = xr[i] = x[18 * b + MPC_X_IDX[i]];
+        xr[4] = dem[3 * b]; xr[5] = dem[3 * b + 1]; xr[6] = dem[3 * b + 2];
+        for (int i = 0; i < 3; ++i) {
+          double s = 0.0;
+          for (int j = 0; j < 9; ++j) s += -K[27 * b + 9 * i + j] * (xr[j] - x9[j]);
+          u[1 + i] = s + u0[4 * b + 1 + i];
+        }
+        st |= f16o_step(x + 18 * b, u, dt, fi_flag, xcg);
+      }
+      if (traj) memcpy(traj + ((long)t * B + b) * 18, x + 18 * b, 18 * sizeof(double));
+    }
+    if (u_out) memcpy(u_out + 4 * b, u, sizeof u);
+    if (status) status[b] = st;
+  }
+}

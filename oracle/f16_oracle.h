@@ -60,6 +60,10 @@ void f16o_xdot_batch(const double *x, const double *u, double *xdot, long B, int
 void f16o_rollout(double *x, const double *u, long B, int T, double dt, int fi_flag, double xcg,
                   double *traj, int *status, int nthreads);
 
+/* test_env_mk2.py:70-85 (nonlinear LQR loop) for B aircraft: env.py:360-371 action + env.py:105-130 step, T times */
+void f16o_rollout_lqr(double *x, const double *u0, const double *K, const double *dem, long B, int T, double dt, int fi_flag,
+                      double xcg, double *traj, double *u_out, int *status, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

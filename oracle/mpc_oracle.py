@@ -73,6 +73,7 @@ class COracle:
         L.f16o_linearise_full.argtypes = [dp, dp, d, dp, dp, dp, dp, i, d]
         L.f16o_xdot_batch.argtypes = [dp, dp, dp, l, i, d, i]
         L.f16o_rollout.argtypes = [dp, dp, l, i, d, i, d, dp, ip, i]
+        L.f16o_rollout_lqr.argtypes = [dp, dp, dp, dp, l, i, d, i, d, dp, dp, ip, i]
         L.f16o_set_xcg.argtypes = [d]
         L.f16o_last_status.restype = i
         L.atmos.argtypes = [d, d, dp]
@@ -143,6 +144,22 @@ class COracle:
                               self._p(traj) if store else None,
                               status.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), nthreads)
         return x, traj, status
+
+    def rollout_lqr(self, x0, u0, K, dem, T, dt=0.001, fi_flag=1, xcg=0.25, store=True, nthreads=1):
+        """test_env_mk2.py:70-85 for B aircraft: x0 [B,18], u0 [B,4], K [B,3,9] (= -dlqr), dem [B,3]
+        -> (x_final, traj [T,B,18] or None, u_last [B,4], status)."""
+        x = np.array(x0, dtype=np.float64, order="C")
+        B = x.shape[0]
+        u0 = np.ascontiguousarray(np.broadcast_to(u0, (B, 4)), dtype=np.float64)
+        K = np.ascontiguousarray(np.broadcast_to(K, (B, 3, 9)), dtype=np.float64)
+        dem = np.ascontiguousarray(np.broadcast_to(dem, (B, 3)), dtype=np.float64)
+        traj = np.zeros((T, B, 18)) if store else None
+        u_out = np.zeros((B, 4))
+        status = np.zeros(B, dtype=np.int32)
+        self.lib.f16o_rollout_lqr(self._p(x), self._p(u0), self._p(K), self._p(dem), B, T, dt, fi_flag, xcg,
+                                  self._p(traj) if store else None, self._p(u_out),
+                                  status.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), nthreads)
+        return x, traj, u_out, status
 
     def linearise_na(self, x_full, x9=None, u3=None, eps=1e-5, fi_flag=1, xcg=0.25):
         x_full = np.ascontiguousarray(x_full, dtype=np.float64)

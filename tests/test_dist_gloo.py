@@ -91,6 +91,22 @@ def test_bench_gpus_2_starts_two_ranks_by_itself():
     assert rec["max_over_ranks"] == 2.0
 
 
+def test_one_rank_with_a_forced_group_goes_through_the_backend():
+    """F16_DIST_FORCE_GROUP=1 (`bench.py --force-group`): one rank forms a real process group, so the all-gather and the
+    reductions execute through the backend instead of short-circuiting (gloo here; RCCL in tests/test_gpu_dist_rccl.py)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["F16_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--dry-run", "--force-group"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["n_gpus"] == 1 and rec["allgather_ok"] and rec["backend"] == "gloo" and rec["max_over_ranks"] == 1.0
+
+
 def test_bench_parent_propagates_a_rank_failure():
     import subprocess
     import sys

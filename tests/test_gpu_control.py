@@ -6,12 +6,13 @@ strictly convex QP (tests/golden/g8, computed by oracle.mpc_oracle.qp_exact) and
 Tolerances: A,B by differences <= 1e-6 abs; K,P,q <= 1e-6 relative; MPC first move within the
 OSQP default tolerance band of the exact minimiser."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import golden
+from conftest import REPO, golden
 from oracle import mpc_oracle as mo
 
 pytestmark = pytest.mark.gpu
@@ -661,6 +662,40 @@ def test_plan_solves_replay_from_a_hip_graph_and_one_shot_calls_refuse_capture()
             env._calc_MPC_action(0, 0, 0, 30)
     torch.cuda.synchronize()
     assert torch.equal(env._calc_MPC_action(0, 0, 0, 30), u_eager)       # the context is still usable afterwards
+
+
+def test_first_solve_of_a_wide_plan_inside_a_capture():
+    """Plans accept horizons 33..40 (every solve runs the long-horizon workgroup solver) and plan solves are capturable: the
+    kernel's dynamic-LDS opt-in (hipFuncSetAttribute, not legal under capture) must therefore have happened in
+    f16_mpc_plan_create.  Fresh process, so that no earlier call has set the attribute: the FIRST solve of an N = 36 plan is
+    captured, replayed, and compared with the eager solve."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import torch
+        from f16_mpc_oop_py_amd import F16Batch
+        from f16_mpc_oop_py_amd.workload import config4_states
+        x0, u0 = config4_states(48, seed=9)
+        env = F16Batch(x0, u0, xcg=0.35)
+        env.build_ssr()
+        env.prepare_MPC(36)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            u_cap = env._calc_MPC_action(0, 0, 0, 36, use_plan=True)
+        for _ in range(3):
+            u_cap.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            u1 = u_cap.clone()
+        u_eager = env._calc_MPC_action(0, 0, 0, 36, use_plan=True)
+        torch.cuda.synchronize()
+        assert torch.isfinite(u_eager).all() and torch.equal(u1, u_eager), (u1 - u_eager).abs().max()
+        print("captured-first-solve ok")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=REPO), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "captured-first-solve ok" in r.stdout, r.stderr[-3000:]
 
 
 @pytest.mark.parametrize("mode", ["osqp", "builder"])

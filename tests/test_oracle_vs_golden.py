@@ -94,6 +94,25 @@ def test_g4_rollouts(oracle, xcg):
 
 
 @pytest.mark.parametrize("xcg", [25, 35])
+def test_g12_nonlinear_lqr_loop(oracle, xcg):
+    """G12: the reference's closed loop under its LQR controller (test_env_mk2.py:70-85 run by tools/make_golden.py --g12):
+    six cases x 300 steps, every 25th state and the last action -- the restated loop (env.py:360-371 action + step)."""
+    g = golden("g12_lqr_loop.npz")
+    x0, dem = g[f"x0_xcg{xcg}"], g[f"dem_xcg{xcg}"]
+    xf, traj, u_last, st = oracle.rollout_lqr(x0, g[f"u0_xcg{xcg}"], g[f"K_xcg{xcg}"], dem, 300, 0.001, 1, xcg / 100)
+    assert not st.any()
+    assert rel(traj[24::25].transpose(1, 0, 2), g[f"traj_xcg{xcg}"]) < 1e-10
+    assert rel(u_last, g[f"u_last_xcg{xcg}"]) < 1e-10
+    # the action itself, as numpy computes it (oracle.mpc_oracle.lqr_action: env.py:360-371 literally)
+    x9 = x0[3][mo.MPC_X_IDX]
+    ua = mo.lqr_action(*dem[3], g[f"K_xcg{xcg}"], x9, g[f"u0_xcg{xcg}"][1:])
+    e = dem[3] - x0[3][9:12]
+    np.testing.assert_allclose(ua, -(g[f"K_xcg{xcg}"][:, 4:7] @ e) + g[f"u0_xcg{xcg}"][1:], rtol=1e-13)
+    # the controller does something: the rates move towards the demands of case 1
+    assert np.abs(g[f"traj_xcg{xcg}"][1, -1, 9:12] - dem[1]).max() < np.abs(x0[1][9:12] - dem[1]).max()
+
+
+@pytest.mark.parametrize("xcg", [25, 35])
 def test_g6_g7_linearise_c2d_lqr(oracle, xcg):
     g = golden("g567_trim_lin_lqr.npz")
     x = g[f"trim_x_xcg{xcg}"]

@@ -315,8 +315,130 @@ def g11_state_space():
     print("g11_state_space.npz", os.path.getsize(os.path.join(OUT, "g11_state_space.npz")), sorted(out))
 
 
+def make_f16_objects(parameters, env, libs):
+    def make_f16(stab):
+        P = parameters
+        sv = P.stateVector(P.states, np.copy(P.x0), P.x_units, P.x_ub, P.x_lb, np.copy(P.x0), P.observed_states,
+                           P.mpc_states, P.mpc_inputs, P.mpc_controlled_states)
+        iv = P.inputVector(P.inputs, np.copy(P.u0), P.u_units, P.u_ub, P.u_lb, P.udot_ub, P.udot_lb, np.copy(P.u0),
+                           P.mpc_inputs)
+        sp = P.simulationParameters(P.dt, P.time_start, P.time_end, stab, 1)
+        ss = P.stateSpace(*[np.zeros((1, 1))] * 8)
+        return env.F16(sv, iv, sp, ss, libs[35 if stab else 25])
+    return {25: make_f16(0), 35: make_f16(1)}
+
+
+def clr_reads_zero(lib):
+    """The reference's `_CLr` interpolates memory it never filled (hifi_F16_AeroData.c:964-972): every fixture of this
+    repository is taken in a process where that memory reads ~0 (G2 was) -- checked, not assumed."""
+    f = lib._CLr
+    f.restype = ctypes.c_double
+    f.argtypes = [ctypes.c_double]
+    return all(abs(f(a)) < 1e-290 for a in np.linspace(-20, 89, 45))
+
+
+def g12_lqr_loop_and_g8b_weights():
+    """G12: the reference's nonlinear closed loop under its LQR controller (test_env_mk2.py:70-85: K = _calc_LQR_gain() once,
+    then per step u = _calc_LQR_action(p, q, r, K, x._get_mpc_x(), u.initial_condition[1:]); u.values[1:] = u; step(u.values)),
+    300 steps, both xcg builds: from trim with rate demands, and from perturbed starts.  Every 25th state + the last action.
+    G8b: utils.setup_OSQP (utils.py:21-167) called with weights, reference and bounds OTHER than the ones env.py:373-424 hard-wires:
+    the weights the author left commented out at env.py:391-403 with R = 0.01 I, and a dense SPD Q / R with a free reference and
+    tightened / widened boxes."""
+    parameters, env, utils = import_reference()
+    libs = {25: ctypes.CDLL(os.path.join(REF, "C", "nlplant_xcg25.so")),
+            35: ctypes.CDLL(os.path.join(REF, "C", "nlplant_xcg35.so"))}
+    f16 = make_f16_objects(parameters, env, libs)
+    for k in libs:
+        if not clr_reads_zero(libs[k]):
+            raise SystemExit("this process's _CLr does not read ~0 (uninitialised heap): run the script again")
+    rng = np.random.default_rng(20261005)
+    g12 = {}
+    for k, f in f16.items():
+        f.reset()
+        K = f._calc_LQR_gain()
+        g12[f"K_xcg{k}"] = K
+        g12[f"u0_xcg{k}"] = np.copy(f.u.initial_condition)
+        cases_x0, cases_dem, cases_traj, cases_u = [], [], [], []
+        for j in range(6):
+            f.reset()
+            x0 = np.copy(f.x.values)
+            if j == 0:
+                dem = np.zeros(3)                                   # test_env_mk2.py:37-39 as written: hold the trim
+            elif j == 1:
+                dem = np.array([0.1, -0.05, 0.02])                  # the sample of fixture G7's action
+            else:
+                dem = rng.uniform(-0.15, 0.15, 3)
+                x0[3:6] += rng.uniform(-0.1, 0.1, 3)
+                x0[6] += rng.uniform(-60, 60)
+                x0[7] += rng.uniform(-0.02, 0.06)
+                x0[8] += rng.uniform(-0.03, 0.03)
+                x0[9:12] += rng.uniform(-0.15, 0.15, 3)
+            f.x.values = np.copy(x0)
+            f.u.values = np.copy(f.u.initial_condition)
+            tr = []
+            for t in range(300):
+                u = f._calc_LQR_action(dem[0], dem[1], dem[2], K, f.x._get_mpc_x(), f.u.initial_condition[1:])
+                f.u.values[1:] = u
+                f.step(f.u.values)
+                if (t + 1) % 25 == 0:
+                    tr.append(np.copy(f.x.values))
+            cases_x0.append(x0), cases_dem.append(dem), cases_traj.append(np.array(tr)), cases_u.append(np.copy(f.u.values))
+            f.u.values = np.copy(f.u.initial_condition)
+        g12[f"x0_xcg{k}"], g12[f"dem_xcg{k}"] = np.array(cases_x0), np.array(cases_dem)
+        g12[f"traj_xcg{k}"], g12[f"u_last_xcg{k}"] = np.array(cases_traj), np.array(cases_u)
+        f.reset()
+    for k in libs:
+        if not clr_reads_zero(libs[k]):
+            raise SystemExit("_CLr stopped reading ~0 during the run: run the script again")
+    np.savez_compressed(os.path.join(OUT, "g12_lqr_loop.npz"), **g12)
+    print("g12_lqr_loop.npz", os.path.getsize(os.path.join(OUT, "g12_lqr_loop.npz")))
+
+    g8b = {}
+    Qa = np.diag([0.01, 0.0, 0.01, 0.01, 0.0, 1.0, 1.0, 1.0, 0.0])      # env.py:391-401 (the tenth line indexes past a 9 x 9 Q)
+    Ra = np.eye(3) * 0.01                                               # env.py:403
+    M = rng.uniform(-1, 1, (9, 9))
+    Qb = M @ M.T / 9 + np.diag(rng.uniform(0.05, 1.0, 9))
+    M3 = rng.uniform(-1, 1, (3, 3))
+    Rb = M3 @ M3.T / 3 + np.diag(rng.uniform(0.1, 2.0, 3))
+    g8b["Qa"], g8b["Ra"], g8b["Qb"], g8b["Rb"] = Qa, Ra, Qb, Rb
+    for k, f in f16.items():
+        f.reset()
+        x = f.x._get_mpc_x()
+        act = f.x._get_mpc_act_states()
+        A, B = f.ssr.Ad, f.ssr.Bd
+        for tag, Q, R in (("a", Qa, Ra), ("b", Qb, Rb)):
+            if tag == "a":
+                x_ref = np.copy(x)
+                x_ref[5:8] = [0.05, -0.02, 0.01]
+                bnds = (f.x._vec_mpc_x_lb, f.x._vec_mpc_x_ub, f.u._vec_mpc_u_lb, f.u._vec_mpc_u_ub,
+                        f.u._vec_mpc_udot_lb, f.u._vec_mpc_udot_ub)
+            else:
+                x_ref = x + rng.uniform(-0.05, 0.05, 9)              # a free reference, not "x with three entries replaced"
+                xlb = np.array([-np.inf, -np.inf, -10., -15., -200., -60., -30., -np.inf, 0.])
+                xub = np.array([np.inf, np.inf, 40., 15., 200., 60., 30., np.inf, 20.])
+                bnds = tuple(np.asarray(v)[:, None] for v in (                # vertical vectors, as utils.py:57-68 wants them
+                    xlb, xub, np.array([-20., -15., -25.]), np.array([22., 18., 28.]),
+                    np.array([-50., -70., -100.]), np.array([55., 75., 110.])))
+            g8b[f"xref_{tag}_xcg{k}"] = x_ref
+            for nm, v in zip(("xlb", "xub", "ulb", "uub", "rlb", "rub"), bnds):
+                g8b[f"{nm}_{tag}"] = np.asarray(v, dtype=float).ravel()
+            for N in (4, 10, 30):
+                Pm, q, Ac, l, u = utils.setup_OSQP(x_ref, A, B, Q, R, N, f.paras.dt, x, act, *bnds)
+                t = f"{tag}_xcg{k}_N{N}"
+                g8b[f"P_{t}"], g8b[f"q_{t}"], g8b[f"l_{t}"], g8b[f"u_{t}"] = Pm, q.ravel(), l.ravel(), u.ravel()
+                if N < 30:
+                    g8b[f"A_{t}"] = Ac
+            g8b[f"K_{tag}_xcg{k}"] = utils.dlqr(A, B, Q, R)             # utils.py:219 with the same weights
+        g8b[f"x_full_xcg{k}"] = np.copy(f.x.values)
+        g8b[f"Ad_xcg{k}"], g8b[f"Bd_xcg{k}"], g8b[f"Cd_xcg{k}"] = f.ssr.Ad, f.ssr.Bd, f.ssr.Cd
+    np.savez_compressed(os.path.join(OUT, "g8b_mpc_qp_weights.npz"), **g8b)
+    print("g8b_mpc_qp_weights.npz", os.path.getsize(os.path.join(OUT, "g8b_mpc_qp_weights.npz")))
+
+
 if __name__ == "__main__":
-    if "--g10" in sys.argv:
+    if "--g12" in sys.argv:
+        g12_lqr_loop_and_g8b_weights()
+    elif "--g10" in sys.argv:
         g10_time_histories()
         g11_state_space()
     else:
