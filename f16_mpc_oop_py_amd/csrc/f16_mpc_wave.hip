@@ -41,13 +41,22 @@ constexpr int FN = 16 * NT;                // 96
 // ---- LDS map (doubles).  [0, KI_SIZE) is the block image of the KKT inverse during the iterations and scratch of the
 // factorisation before that; the vectors of the iteration sit behind it.
 constexpr int KI_SIZE = 36 * NL * 2;                  // 4320
-constexpr int WS_REC = 12;                             // state-row vectors: per step rows 0..5, then 3,4,5,0,1,2
-constexpr int WS_OFF = KI_SIZE, WS_SIZE = (WN + 7) * WS_REC;           // 444
+constexpr int WS_OFF = KI_SIZE, WS_SIZE = 444;         // state-row vector: six kept rows per step, steps 0..33 (equilibration: E of all nine rows)
 constexpr int WC_OFF = WS_OFF + WS_SIZE, WC_SIZE = 92;                 // command rows (also: rhs of the linear system)
 constexpr int WR_OFF = WC_OFF + WC_SIZE, WR_SIZE = 96;                 // rate rows (read up to k + 3)
-constexpr int XT_PAD = 21, XT_OFF = WR_OFF + WR_SIZE, XT_SIZE = XT_PAD + 3 * WN + 5;     // x~ / x behind 7 zero steps
 constexpr int LDS_DOUBLES = 5120;                      // 40,960 B: four wavefront-workgroups per CU
-static_assert(XT_OFF + XT_SIZE <= LDS_DOUBLES, "LDS map");
+constexpr int XT_PAD = 21, XT_OFF = WR_OFF + WR_SIZE, XT_SIZE = LDS_DOUBLES - XT_OFF;    // 168.  Equilibration / KKT diagonal: three
+                                                       // per step behind 7 zero steps (XT_PAD); iterations: FOUR per step behind XPADS zero steps
+constexpr int XPADS = 7;
+static_assert(6 * 34 <= WS_SIZE && 4 * (XPADS + WN + 5) <= XT_SIZE && XT_PAD + 3 * WN + 5 <= XT_SIZE, "LDS map");
+// During the iterations only the B blocks of the KKT inverse stay in LDS (chunks 18..35 of the block image, where the scatter of
+// the factorisation leaves them); the A blocks live in registers (reloaded from the workspace at every entry of the hot loop), and
+// their half of the image holds the partial sums of the two Toeplitz stages:
+constexpr int KB_OFF = 18 * NL * 2;                    // 2160
+constexpr int P3_OFF = 0, P3_REC = 30, P3_SIZE = 22 * P3_REC;             // stage 3: record (block) = [5 steps][6 kept rows]; record 21: the idle lane's
+constexpr int P1_OFF = P3_OFF + P3_SIZE, P1_REC = 20, P1_SIZE = 64 * P1_REC;   // stage 1: record (lane) = [5 steps][3 sums + 1 pad]
+constexpr int ZP_OFF = P1_OFF + P1_SIZE;               // eight zeros: what an absent partial sum reads
+static_assert(ZP_OFF + 8 <= KB_OFF && (P1_OFF & 1) == 0 && (ZP_OFF & 1) == 0, "partial-sum records");
 // scratch of the factorisation phases inside [0, KI_SIZE)
 constexpr int GL_OFF = 0, GL_SIZE = 27 * (WN + 1) + 1;                 // all nine rows of every G_k + a zero block
 constexpr int WG_OFF = GL_OFF + GL_SIZE, WG_SIZE = 6 * WN + 8;         // Gram weights of the kept state rows (zero padded)
@@ -127,188 +136,178 @@ struct SolveState {
 struct IterSettings { double alpha, eps_abs, eps_rel, eps_prim_inf; int max_iter, check_every, rho_every, adaptive_rho; };
 
 // ----------------------------------------------------------------------------------------------------------------
-// The two block-Toeplitz stages on the lane's 72 register-resident doubles Gd[u][rr'][c] = G_(4t+u)[kept row][c]; row slot
-// rr' < 3 is kept row 3h + rr', rr' >= 3 kept row 3(1-h) + rr' - 3 (h = par ^ b2), so that the first halving step of stage 3
-// is free of selects.  Zero for lags beyond the horizon.
-__device__ __forceinline__ void load_G(double (&Gd)[4][6][3], const double *Gg, const Role &R, int N) {
-  // (unconditional loads from clamped addresses, the masks applied afterwards: a load under a lane condition becomes a
-  //  branch around it, and 72 of those in a row wait out 72 memory latencies -- 43 k cycles per call when measured)
+// The two block-Toeplitz stages (utils.py:171-197: CC[i,j] = A^(i-j) B, never formed; stage 3 = CCs x~, stage 1 = CCs' w) with
+// the causal zeros folded away (round 4).  The N x N triangle of (step, lag) pairs is cut into 5 x 5 blocks: six step blocks I,
+// six lag blocks T, and only the 21 blocks with T <= I hold products that are not structurally zero.  Lane (s, I, T) -- 63 of
+// the 64 lanes, l = 21 s + I (I + 1) / 2 + T -- owns block (I, T) for the kept state rows 2s, 2s + 1: THIRTY register-resident
+// doubles Gd[u][r][c] = G_(5T+u)[kept row 2s + r][c] (round 3: 72 per lane, half of whose products multiplied zeros), used both
+// ways: stage 3 gives the lane's two rows of steps 5I..5I+4 from the variable steps 5(I-T)-4 .. 5(I-T)+4, stage 1 gives the
+// variables of steps 5(I-T)..5(I-T)+4 from its two rows of steps 5I..5I+8 -- 150 products each.  The partial sums of a block
+// row / block diagonal do not sit in a DPP-friendly lane pattern, so they meet in LDS: every lane stores its partial sums in a
+// record of its own, and the lane that owns a row (a variable) adds the records that hold a part of it, in a fixed order
+// (absent records read a block of zeros).
+constexpr int TB = 5;
+constexpr int GIMG_DOUBLES = 15 * 64 * 2;         // the lanes' Toeplitz operands in the workspace; the A blocks of the KKT inverse ([18][64] double2) follow
+static_assert(GIMG_DOUBLES + 18 * 64 * 2 <= WAVE_PBLK_DOUBLES / 2, "workspace map");
+struct TJob { int s, I, T, D, rec3; };
+__device__ __forceinline__ TJob tjob() {
+  const int l = threadIdx.x;
+  TJob J;
+  const bool live = l < 63;
+  const int ll = live ? l : 0;
+  J.s = ll / 21;
+  const int j = ll - 21 * J.s;
+  J.I = j >= 15 ? 5 : (j >= 10 ? 4 : (j >= 6 ? 3 : (j >= 3 ? 2 : (j >= 1 ? 1 : 0))));
+  J.T = j - J.I * (J.I + 1) / 2;
+  J.D = J.I - J.T;
+  J.rec3 = live ? j : 21;                                   // (lane 63: zero operands, a record nobody reads)
+  return J;
+}
+// from G_k in the workspace ([k][9 rows][3], build kernel); zero for lags beyond the horizon and on the idle lane
+__device__ __forceinline__ void load_G(double (&Gd)[TB][2][3], const double *Gg, const TJob &J, int N) {
+  // (unconditional loads from clamped addresses, the masks applied afterwards: a load under a lane condition becomes a branch)
+  const bool live = threadIdx.x < 63;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int d = 4 * R.t + u;
+  for (int u = 0; u < TB; ++u) {
+    const int d = TB * J.T + u;
     const gptr_t gp = as_global(Gg) + (d < N ? d : 0) * 27;
-    const double m = d < N ? 1.0 : 0.0;
+    const double m = (d < N && live) ? 1.0 : 0.0;
 #pragma unroll
-    for (int rr = 0; rr < 6; ++rr) {
-      const int kept = 3 * (R.h ^ (rr >= 3 ? 1 : 0)) + rr % 3;      // kept-row index of slot rr
+    for (int r = 0; r < 2; ++r) {
+      const int kept = 2 * J.s + r;
       const int row = kept < 5 ? kept + 2 : 8;                        // MPC state row (SROW)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) Gd[u][rr][c] = gp[row * 3 + c] * m;
+      for (int c = 0; c < 3; ++c) Gd[u][r][c] = gp[row * 3 + c] * m;
     }
   }
 }
-
-// The same 72 doubles from the per-lane image the prologue leaves in the workspace ([36][64] double2, lane-major: 36 fully
-// coalesced 16-byte loads instead of 24 strided ones per lane) -- the hot loop and the termination test reload them at every
-// call (~4 k cycles each from the strided layout).
-__device__ __forceinline__ void load_G_image(double (&Gd)[4][6][3], const double *gimg, int l) {
+// The same 30 doubles as a per-lane image in the workspace ([15][64] double2, lane-major: fully coalesced 16-byte loads) -- the hot
+// loop and the termination test reload them at every call.
+__device__ __forceinline__ void load_G_image(double (&Gd)[TB][2][3], const double *gimg, int l) {
   typedef double dbl2_t __attribute__((ext_vector_type(2)));
   typedef const dbl2_t __attribute__((address_space(1))) *g2ptr_t;
   const g2ptr_t gp = (g2ptr_t)gimg + l;
-  double f[72];
 #pragma unroll
-  for (int m = 0; m < 36; ++m) { const dbl2_t a = gp[m * 64]; f[2 * m] = a.x; f[2 * m + 1] = a.y; }
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int rr = 0; rr < 6; ++rr)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) Gd[u][rr][c] = f[(u * 6 + rr) * 3 + c];
+  for (int m = 0; m < 15; ++m) {
+    const dbl2_t a = gp[m * 64];
+    const int e0 = 2 * m, e1 = 2 * m + 1;
+    Gd[e0 / 6][(e0 % 6) / 3][e0 % 3] = a.x; Gd[e1 / 6][(e1 % 6) / 3][e1 % 3] = a.y;
+  }
 }
-__device__ __forceinline__ void store_G_image(const double (&Gd)[4][6][3], double *gimg, int l) {
+__device__ __forceinline__ void store_G_image(const double (&Gd)[TB][2][3], double *gimg, int l) {
   double2 *gp = reinterpret_cast<double2 *>(gimg) + l;
 #pragma unroll
-  for (int m = 0; m < 36; ++m) {
+  for (int m = 0; m < 15; ++m) {
     const int e0 = 2 * m, e1 = 2 * m + 1;
-    gp[m * 64] = make_double2(Gd[e0 / 18][(e0 % 18) / 3][e0 % 3], Gd[e1 / 18][(e1 % 18) / 3][e1 % 3]);
+    gp[m * 64] = make_double2(Gd[e0 / 6][(e0 % 6) / 3][e0 % 3], Gd[e1 / 6][(e1 % 6) / 3][e1 % 3]);
   }
 }
 
-// stage 1: (CCs' v)_j, j = 4o + e, from the state-row vector in LDS (record of 12 per step); returns the three totals of step
-// istep in BOTH lanes of the pair (t, t ^ 1).  The seven operand steps are a sliding window over the lag u: step m + 4 is
-// fetched under the products of lag m (memory operations keep their order, the arithmetic may float).
-__device__ __forceinline__ void stage1(const double (&Gd)[4][6][3], const double *vs, const Role &R, int N, double (&out)[3]) {
-  const int base = 4 * (R.o + R.t), wb = base < N ? base : N;
-  const double2 *wp = reinterpret_cast<const double2 *>(vs + WS_REC * wb + 6 * R.h);
-  double wv[7][6];
-  auto ld = [&](int m) {
-    const double2 a = wp[6 * m], b = wp[6 * m + 1], c = wp[6 * m + 2];
-    wv[m][0] = a.x; wv[m][1] = a.y; wv[m][2] = b.x; wv[m][3] = b.y; wv[m][4] = c.x; wv[m][5] = c.y;
-  };
-  double acc[4][3];
+// stage 3, block (I, T): partial sums of (CCs v)_i, i = 5I + e, rows 2s, 2s + 1, over the lags 5T..5T+4, from the variable vector
+// in LDS (four doubles per step behind XPADS zero steps) -> record rec3: [e][6 kept rows]
+__device__ __forceinline__ void stage3_partials(const double (&Gd)[TB][2][3], const TJob &J) {
+  const double *xp = s_w + XT_OFF + 4 * (TB * J.D - 4 + XPADS);
+  double f[9][3];
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
+  for (int m = 0; m < 9; ++m) {
+    const double2 a = *reinterpret_cast<const double2 *>(xp + 4 * m);
+    f[m][0] = a.x; f[m][1] = a.y; f[m][2] = xp[4 * m + 2];
+  }
+  WAVE_LDS_PHASE();
+  double acc[TB][2];
+#pragma unroll
+  for (int e = 0; e < TB; ++e) { acc[e][0] = 0.0; acc[e][1] = 0.0; }
+#pragma unroll
+  for (int u = 0; u < TB; ++u)
+#pragma unroll
+    for (int e = 0; e < TB; ++e)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[e][r] = fma(Gd[u][r][c], f[e - u + 4][c], acc[e][r]);
+  double2 *out = reinterpret_cast<double2 *>(s_w + P3_OFF + J.rec3 * P3_REC + 2 * J.s);
+#pragma unroll
+  for (int e = 0; e < TB; ++e) out[3 * e] = make_double2(acc[e][0], acc[e][1]);
+}
+// ... and the totals of the lane's three kept rows 3h..3h+2 of step istep: a3[T] = LDS index of those rows in the record of
+// block (I, T), or of the zero block
+__device__ __forceinline__ void stage3_totals(const int (&a3)[6], double (&out)[3]) {
+  double v[6][3];
+#pragma unroll
+  for (int T = 0; T < 6; ++T)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[T][c] = s_w[a3[T] + c];
+  WAVE_LDS_PHASE();
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[c] = ((v[0][c] + v[1][c]) + (v[2][c] + v[3][c])) + (v[4][c] + v[5][c]);
+}
+// stage 1, block (I, T): partial sums of (CCs' v)_j, j = 5(I - T) + e, all three variables, from rows 2s, 2s + 1 of the state-row
+// vector in LDS (six per step), steps 5I..5I+8 -> record of the lane: [e][3 + one pad]
+__device__ __forceinline__ void stage1_partials(const double (&Gd)[TB][2][3], const TJob &J) {
+  const double2 *wp = reinterpret_cast<const double2 *>(s_w + WS_OFF + 6 * TB * J.I + 2 * J.s);
+  double wv[9][2];
+#pragma unroll
+  for (int m = 0; m < 9; ++m) { const double2 a = wp[3 * m]; wv[m][0] = a.x; wv[m][1] = a.y; }
+  WAVE_LDS_PHASE();
+  double acc[TB][3];
+#pragma unroll
+  for (int e = 0; e < TB; ++e)
 #pragma unroll
     for (int c = 0; c < 3; ++c) acc[e][c] = 0.0;
-  ld(0); ld(1); ld(2); ld(3);
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    WAVE_LDS_PHASE();
-    if (u < 3) ld(4 + u);
+  for (int u = 0; u < TB; ++u)
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < TB; ++e)
 #pragma unroll
       for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int rr = 0; rr < 6; ++rr) acc[e][c] = fma(Gd[u][rr][c], wv[e + u][rr], acc[e][c]);
-  }
-  // halving: half-mirror partner keeps the other pair of steps, xor-2 partner the other step of the pair, xor-1 partner shares
-  double k[2][3];
+        for (int r = 0; r < 2; ++r) acc[e][c] = fma(Gd[u][r][c], wv[e + u][r], acc[e][c]);
+  double *out = s_w + P1_OFF + threadIdx.x * P1_REC;
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const double keep = R.b2 ? acc[2 + m][c] : acc[m][c], send = R.b2 ? acc[m][c] : acc[2 + m][c];
-      k[m][c] = keep + dpp<DPP_HMIRROR>(send);
-    }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const double keep = R.b1 ? k[1][c] : k[0][c], send = R.b1 ? k[0][c] : k[1][c];
-    const double v = keep + dpp<DPP_XOR2>(send);
-    out[c] = v + dpp<DPP_XOR1>(v);
+  for (int e = 0; e < TB; ++e) {
+    *reinterpret_cast<double2 *>(out + 4 * e) = make_double2(acc[e][0], acc[e][1]);
+    out[4 * e + 2] = acc[e][2];
   }
 }
-
-// stage 3: (CCs v)_i, i = 4o + e, from the zero-padded variable vector in LDS (step s at 3 (s + 7)); returns the lane's three
-// kept rows 3h..3h+2 of step istep.  Lag u needs the operand steps 3 - u .. 6 - u: from u = 3 down, one more pair per lag.
-__device__ __forceinline__ void stage3(const double (&Gd)[4][6][3], const double *vx, const Role &R, double (&out)[3]) {
-  const int s0 = 4 * (R.o - R.t) - 3, sb = s0 > -7 ? s0 : -7;
-  const double2 *xp = reinterpret_cast<const double2 *>(vx + 3 * (sb + 7));
-  double f[22];                                            // f[3 m + c] = operand step m, component c
-  auto ld = [&](int p) { const double2 a = xp[p]; f[2 * p] = a.x; f[2 * p + 1] = a.y; };
-  double acc[4][6];
+// ... and the totals of step istep in BOTH lanes of its pair: a block diagonal has up to 18 records (six lag blocks x three row
+// pairs); the even lane adds nine of them, the odd lane the other nine (a1[k]: LDS index of the step's three sums in record k of
+// this lane's half, or of the zero block), then the two halves meet over DPP
+__device__ __forceinline__ void stage1_totals(const int (&a1)[9], double (&out)[3]) {
+  double v[9][3];
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
-#pragma unroll
-    for (int rr = 0; rr < 6; ++rr) acc[e][rr] = 0.0;
-  ld(0); ld(1); ld(2); ld(3); ld(4); ld(5);               // steps 0..3
-#pragma unroll
-  for (int uu = 0; uu < 4; ++uu) {
-    const int u = 3 - uu;
-    WAVE_LDS_PHASE();
-    if (uu == 0) { ld(6); ld(7); }                          // step 4 (needs f up to 14)
-    if (uu == 1) { ld(8); }                                 // step 5 (up to 17)
-    if (uu == 2) { ld(9); ld(10); }                         // step 6 (up to 20)
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int rr = 0; rr < 6; ++rr)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc[e][rr] = fma(Gd[u][rr][c], f[3 * (e - u + 3) + c], acc[e][rr]);
-  }
-  double v1[4][3];
-#pragma unroll
-  for (int e = 0; e < 4; ++e)
-#pragma unroll
-    for (int r3 = 0; r3 < 3; ++r3) v1[e][r3] = acc[e][r3] + dpp<DPP_XOR1>(acc[e][3 + r3]);      // partner's slots 3..5 are this lane's rows
-  double k[2][3];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int r3 = 0; r3 < 3; ++r3) {
-      const double keep = R.b2 ? v1[2 + m][r3] : v1[m][r3], send = R.b2 ? v1[m][r3] : v1[2 + m][r3];
-      k[m][r3] = keep + dpp<DPP_HMIRROR>(send);
-    }
-#pragma unroll
-  for (int r3 = 0; r3 < 3; ++r3) {
-    const double keep = R.b1 ? k[1][r3] : k[0][r3], send = R.b1 ? k[0][r3] : k[1][r3];
-    out[r3] = keep + dpp<DPP_XOR2>(send);
-  }
-}
-
-// ---- y = M v for the symmetric block image: M from LDS (KI) or gathered from the packed P in HBM (termination test).
-// v: natural order, 6 r at v[6 r]; all four lanes of quad r receive y[6r..6r+5].
-template <bool FROM_P>
-__device__ __forceinline__ void sym_matvec(const double *Pg, int n, const double *v, const Role &R, double (&y)[6]) {
-  // (FROM_P: Pg = the block image of P in HBM; the operand sits at an odd double index -- 8-byte loads)
-  (void)n;
-  double A[6][6], Bk[6][6];
-  const int lb = R.l < NL ? R.l : NL - 1;
-  if (FROM_P) {
-    // the block image of P in the workspace (built once per solve by the prologue): 36 coalesced 16-byte loads
-    typedef double dbl2_t __attribute__((ext_vector_type(2)));
-    typedef const dbl2_t __attribute__((address_space(1))) *g2ptr_t;
-    const g2ptr_t pb = (g2ptr_t)Pg + R.l;
-#pragma unroll
-    for (int m = 0; m < 18; ++m) {
-      const dbl2_t a = pb[m * 64], b = pb[(18 + m) * 64];
-      A[(2 * m) / 6][(2 * m) % 6] = a.x; A[(2 * m + 1) / 6][(2 * m + 1) % 6] = a.y;
-      Bk[(2 * m) / 6][(2 * m) % 6] = b.x; Bk[(2 * m + 1) / 6][(2 * m + 1) % 6] = b.y;
-    }
-  } else {
-    const double2 *ki = reinterpret_cast<const double2 *>(s_w) + lb;
-#pragma unroll
-    for (int m = 0; m < 18; ++m) {
-      const double2 a = ki[m * NL], b = ki[(18 + m) * NL];
-      A[(2 * m) / 6][(2 * m) % 6] = a.x; A[(2 * m + 1) / 6][(2 * m + 1) % 6] = a.y;
-      Bk[(2 * m) / 6][(2 * m) % 6] = b.x; Bk[(2 * m + 1) / 6][(2 * m + 1) % 6] = b.y;
-    }
-  }
-  const int rr = R.r < NB ? R.r : NB - 1;
-  double xr[6], xa[6], xb[6];
-  if (FROM_P) {
-#pragma unroll
-    for (int m = 0; m < 6; ++m) { xr[m] = v[6 * rr + m]; xa[m] = v[6 * R.cA + m]; xb[m] = v[6 * R.cB + m]; }
-  } else {
-    const double2 *pr = reinterpret_cast<const double2 *>(v + 6 * rr), *pa = reinterpret_cast<const double2 *>(v + 6 * R.cA),
-                  *pb = reinterpret_cast<const double2 *>(v + 6 * R.cB);
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      const double2 a = pr[m], b = pa[m], c = pb[m];
-      xr[2 * m] = a.x; xr[2 * m + 1] = a.y; xa[2 * m] = b.x; xa[2 * m + 1] = b.y; xb[2 * m] = c.x; xb[2 * m + 1] = c.y;
-    }
+  for (int k = 0; k < 9; ++k) {
+    const double2 a = *reinterpret_cast<const double2 *>(s_w + a1[k]);
+    v[k][0] = a.x; v[k][1] = a.y; v[k][2] = s_w[a1[k] + 2];
   }
   WAVE_LDS_PHASE();
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const double t = (((v[0][c] + v[1][c]) + (v[2][c] + v[3][c])) + ((v[4][c] + v[5][c]) + (v[6][c] + v[7][c]))) + v[8][c];
+    out[c] = t + dpp<DPP_XOR1>(t);
+  }
+}
+// LDS addresses of the records a lane consumes: its step istep = 5 I + e, kept rows 3h..3h+2 (stage 3); its pair's half of the
+// block diagonal D = istep / 5 (stage 1): lag blocks 3 par .. 3 par + 2, row pairs 0..2
+struct Consume { int a3[6], a1[9]; };
+__device__ __forceinline__ Consume consume_addresses(const Role &R) {
+  Consume Q;
+  const bool in = R.istep < 6 * TB;
+  const int i = in ? R.istep : 0, I = i / TB, e = i - TB * I;
+#pragma unroll
+  for (int T = 0; T < 6; ++T) Q.a3[T] = (in && T <= I) ? P3_OFF + (I * (I + 1) / 2 + T) * P3_REC + 6 * e + 3 * R.h : ZP_OFF;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int T = 3 * R.par + k / 3, sp = k % 3, II = I + T;              // (I = the diagonal D of the variable's step here)
+    Q.a1[k] = (in && II <= 5) ? P1_OFF + (21 * sp + II * (II + 1) / 2 + T) * P1_REC + 4 * e : ZP_OFF;
+  }
+  return Q;
+}
+
+// ---- y = M v for a symmetric block image: lane (r, s) holds blocks A = (r, cA) and Bk = (r, cB) and uses each twice -- y_r += B x_c
+// and y_c += B' x_r, the second fetched by its owner with ds_bpermute.  All four lanes of quad r receive y[6r..6r+5].
+__device__ __forceinline__ void sym_matvec_core(const double (&A)[6][6], const double (&Bk)[6][6], const double (&xr)[6],
+                                                const double (&xa)[6], const double (&xb)[6], const Role &R, double (&y)[6]) {
+  const int rr = R.r < NB ? R.r : NB - 1;
   double yd[6], ytA[6], ytB[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
@@ -334,6 +333,71 @@ __device__ __forceinline__ void sym_matvec(const double *Pg, int n, const double
     sm += dpp<DPP_XOR2>(sm);
     y[j] = sm;
   }
+}
+// the A blocks of the KKT inverse: LDS image (chunks 0..17, as the factorisation's scatter leaves them) -> workspace
+// ([18][64] double2, lane-major), once per factorisation; workspace -> registers at every entry of the hot loop
+__device__ __forceinline__ void store_KA_image(double *kimg, int l) {
+  const int lb = l < NL ? l : NL - 1;
+  const double2 *ki = reinterpret_cast<const double2 *>(s_w) + lb;
+  double2 *dst = reinterpret_cast<double2 *>(kimg) + l;
+#pragma unroll
+  for (int m = 0; m < 18; ++m) dst[m * 64] = ki[m * NL];
+}
+__device__ __forceinline__ void load_KA_image(double (&A)[6][6], const double *kimg, int l) {
+  typedef double dbl2_t __attribute__((ext_vector_type(2)));
+  typedef const dbl2_t __attribute__((address_space(1))) *g2ptr_t;
+  const g2ptr_t gp = (g2ptr_t)kimg + l;
+#pragma unroll
+  for (int m = 0; m < 18; ++m) {
+    const dbl2_t a = gp[m * 64];
+    A[(2 * m) / 6][(2 * m) % 6] = a.x; A[(2 * m + 1) / 6][(2 * m + 1) % 6] = a.y;
+  }
+}
+// x~ = K^-1 rhs in the hot loop: A blocks in registers, B blocks from LDS (chunks 18..35 of the image), rhs in natural order (LDS)
+__device__ __forceinline__ void kkt_matvec(const double (&A)[6][6], const double *v, const Role &R, double (&y)[6]) {
+  const int lb = R.l < NL ? R.l : NL - 1;
+  const int rr = R.r < NB ? R.r : NB - 1;
+  double Bk[6][6];
+  const double2 *ki = reinterpret_cast<const double2 *>(s_w) + lb;
+#pragma unroll
+  for (int m = 0; m < 18; ++m) {
+    const double2 b = ki[(18 + m) * NL];
+    Bk[(2 * m) / 6][(2 * m) % 6] = b.x; Bk[(2 * m + 1) / 6][(2 * m + 1) % 6] = b.y;
+  }
+  double xr[6], xa[6], xb[6];
+  const double2 *pr = reinterpret_cast<const double2 *>(v + 6 * rr), *pa = reinterpret_cast<const double2 *>(v + 6 * R.cA),
+                *pb = reinterpret_cast<const double2 *>(v + 6 * R.cB);
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const double2 a = pr[m], b = pa[m], c = pb[m];
+    xr[2 * m] = a.x; xr[2 * m + 1] = a.y; xa[2 * m] = b.x; xa[2 * m + 1] = b.y; xb[2 * m] = c.x; xb[2 * m + 1] = c.y;
+  }
+  WAVE_LDS_PHASE();
+  sym_matvec_core(A, Bk, xr, xa, xb, R, y);
+}
+// P x in the termination test: both blocks from the block image of P in the workspace (36 coalesced 16-byte loads), x from the
+// iteration's variable vector in LDS (four per step behind XPADS zero steps)
+__device__ __forceinline__ void p_matvec(const double *Pg, const Role &R, double (&y)[6]) {
+  typedef double dbl2_t __attribute__((ext_vector_type(2)));
+  typedef const dbl2_t __attribute__((address_space(1))) *g2ptr_t;
+  const g2ptr_t pb = (g2ptr_t)Pg + R.l;
+  double A[6][6], Bk[6][6];
+#pragma unroll
+  for (int m = 0; m < 18; ++m) {
+    const dbl2_t a = pb[m * 64], b = pb[(18 + m) * 64];
+    A[(2 * m) / 6][(2 * m) % 6] = a.x; A[(2 * m + 1) / 6][(2 * m + 1) % 6] = a.y;
+    Bk[(2 * m) / 6][(2 * m) % 6] = b.x; Bk[(2 * m + 1) / 6][(2 * m + 1) % 6] = b.y;
+  }
+  const int rr = R.r < NB ? R.r : NB - 1;
+  const double *x4 = s_w + XT_OFF + 4 * XPADS;
+  double xr[6], xa[6], xb[6];
+#pragma unroll
+  for (int m = 0; m < 6; ++m) {
+    const int o = 4 * (m / 3) + m % 3;                      // block row = two steps of four doubles
+    xr[m] = x4[8 * rr + o]; xa[m] = x4[8 * R.cA + o]; xb[m] = x4[8 * R.cB + o];
+  }
+  WAVE_LDS_PHASE();
+  sym_matvec_core(A, Bk, xr, xa, xb, R, y);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -508,7 +572,7 @@ __device__ __forceinline__ void sweep_tile_row(d4_t (&acc)[NTILES], double *c0, 
 
 // One KKT factorisation: K = c P + sigma D^-2 + rho A'WA as lower-triangular tiles (identity on the padding), the sweep, and
 // the scatter of the inverse into the symmetric block image in LDS (table KSCAT).  sg2v: sigma D^-2 per variable (LDS).
-__device__ __noinline__ bool factorise(const double *Pg, const double *gw, const double *sg2v, int N, double cs, double rho) {
+__device__ __noinline__ bool factorise(const double *Pg, const double *gw, const double *sg2v, double *kimg, int N, double cs, double rho) {
   const int n = 3 * N, l = threadIdx.x, lc = l & 15, lq = l >> 4;
   d4_t acc[NTILES];
   {
@@ -574,6 +638,8 @@ __device__ __noinline__ bool factorise(const double *Pg, const double *gw, const
       }
   }
   wave_lds_sync();
+  store_KA_image(kimg, l);                                  // the A blocks: to the workspace (registers of the hot loop); their half
+  wave_lds_sync();                                          // of the LDS image is the iterations' partial-sum space from here on
   return __ballot(!ok) == 0;
 }
 
@@ -612,41 +678,47 @@ struct RowOps {                                  // per-row rho and 1 / rho of a
   __device__ __forceinline__ double riB(int c) const { return ANYEQ ? (((eqB >> c) & 1) ? rinvE : rinv1) : rinv1; }
 };
 struct RowSlots {                                // where a lane's rows live in the LDS vectors
-  double *wsn, *wsr, *wB;
+  double *wsn, *wB;
   bool act;
   __device__ __forceinline__ RowSlots(const Role &R) {
-    double *const ws = s_w + WS_OFF;
-    wsn = ws + WS_REC * R.istep + 3 * R.h; wsr = ws + WS_REC * R.istep + 6 + 3 * (1 - R.h);
+    wsn = s_w + WS_OFF + 6 * R.istep + 3 * R.h;
     wB = s_w + (R.par ? WR_OFF : WC_OFF) + 3 * R.istep;
     act = R.act;
   }
   __device__ __forceinline__ void put(const double (&vA)[3], const double (&vB)[3]) const {      // row vectors -> LDS
     if (act) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { wsn[c] = vA[c]; wsr[c] = vA[c]; wB[c] = vB[c]; }
+      for (int c = 0; c < 3; ++c) { wsn[c] = vA[c]; wB[c] = vB[c]; }
     }
   }
 };
+// the lane's variable step (and the one before it) of the x vector in LDS: four doubles per step behind XPADS zero steps
+__device__ __forceinline__ double *x4_step(int step) { return s_w + XT_OFF + 4 * (step + XPADS); }
 
 // nrun >= 1 iterations from the state in *st (w of that point is in LDS); leaves the state, the dual step of the last
 // iteration and w of the new point.
 template <bool ANYEQ>
-__device__ __noinline__ void run_iterations(SolveState *st, const LaneConst *lcp, const double *Gg, int N, double alpha, int nrun) {
+__device__ __noinline__ void run_iterations(SolveState *st, const LaneConst *lcp, const double *Gg, const double *kimg, int N, double alpha, int nrun) {
   const Role R = role(N);
-  const int n = 3 * N;
+  const TJob J = tjob();
+  const Consume Q = consume_addresses(R);
   const LaneConst C = *lcp;
-  double Gd[4][6][3];
+  double Gd[TB][2][3], KA[6][6];
   load_G_image(Gd, Gg, R.l);                                // (Gg: the per-lane image)
+  load_KA_image(KA, kimg, R.l);
   double x[3], zA[3], yA[3], zB[3], yB[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) { x[c] = st->x[c]; zA[c] = st->zA[c]; yA[c] = st->yA[c]; zB[c] = st->zB[c]; yB[c] = st->yB[c]; }
   const RowOps<ANYEQ> ro(st->rho, C);
   const RowSlots slots(R);
-  double *const ws = s_w + WS_OFF, *const wc = s_w + WC_OFF, *const wr = s_w + WR_OFF, *const xt = s_w + XT_OFF;
+  double *const wc = s_w + WC_OFF, *const wr = s_w + WR_OFF;
   double *const rhs = wc;                                   // (the owner of k reads wc[k] before it writes rhs[k])
   const int kx = 3 * R.istep, kxa = R.act ? kx : 0;         // first owned variable / command / rate row
   const bool wrx = R.act && R.par == 0;                     // one lane of the pair writes what both own
+  const double *const xk4 = x4_step(R.act ? R.istep : 0);
   double dyA[3] = {0.0, 0.0, 0.0}, dyB[3] = {0.0, 0.0, 0.0};
+  if (R.l < 8) s_w[ZP_OFF + R.l] = 0.0;                     // (the factorisation's scratch: the zero block is ours from here)
+  wave_lds_sync();
 #ifdef F16_EXP_STAMPW
   unsigned long long tS[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -654,9 +726,11 @@ __device__ __noinline__ void run_iterations(SolveState *st, const LaneConst *lcp
     constexpr bool KEEP = decltype(keep)::value;
     WSTAMP(7)
     // A: rhs = sigma D^-2 x - c q + A' W (rho z - y)
+    stage1_partials(Gd, J);
+    wave_lds_sync();
     {
       double t1[3];
-      stage1(Gd, ws, R, N, t1);
+      stage1_totals(Q.a1, t1);
       double wce[3], wre[3], wrn[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) { wce[c] = wc[kxa + c]; wre[c] = wr[kxa + c]; wrn[c] = wr[kxa + c + 3]; }
@@ -672,22 +746,27 @@ __device__ __noinline__ void run_iterations(SolveState *st, const LaneConst *lcp
     // B: x~ = K^-1 rhs
     {
       double y6[6];
-      sym_matvec<false>(nullptr, n, rhs, R, y6);
+      kkt_matvec(KA, rhs, R, y6);
       WSTAMP(2)
       if (R.s == 0 && R.r < NB) {                           // (x~ has a buffer of its own: nothing to wait for)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) xt[XT_PAD + 6 * R.r + j] = y6[j];
+        double *const o = x4_step(2 * R.r);
+        *reinterpret_cast<double2 *>(o) = make_double2(y6[0], y6[1]); o[2] = y6[2];
+        *reinterpret_cast<double2 *>(o + 4) = make_double2(y6[3], y6[4]); o[6] = y6[5];
       }
     }
     wave_lds_sync();
     WSTAMP(3)
     // C: z~ = A x~, relaxation, projection, dual update (unscaled z, y = yb / E); w of the new point
+    stage3_partials(Gd, J);
+    wave_lds_sync();
     {
       double z3[3], xk[3], xkm[3];
-      stage3(Gd, xt, R, z3);
+      stage3_totals(Q.a3, z3);
       WSTAMP(4)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { xk[c] = xt[XT_PAD + kxa + c]; xkm[c] = xt[XT_PAD + kxa + c - 3]; }
+      {
+        const double2 a = *reinterpret_cast<const double2 *>(xk4), b = *reinterpret_cast<const double2 *>(xk4 - 4);
+        xk[0] = a.x; xk[1] = a.y; xk[2] = xk4[2]; xkm[0] = b.x; xkm[1] = b.y; xkm[2] = xk4[-2];
+      }
       WAVE_LDS_PHASE();
       double wA[3], wBv[3];
 #pragma unroll
@@ -752,7 +831,8 @@ template <bool ANYEQ>
 __device__ __noinline__ int terminate_test(SolveState *st, const LaneConst *lcp, const double *Pg, const double *Gg, const double *qv,
                                            const double *Dv, int N, IterSettings o) {
   const Role R = role(N);
-  const int n = 3 * N;
+  const TJob J = tjob();
+  const Consume Q = consume_addresses(R);
   const LaneConst C = *lcp;
   double x[3], zA[3], yA[3], zB[3], yB[3], dyA[3], dyB[3];
 #pragma unroll
@@ -762,24 +842,25 @@ __device__ __noinline__ int terminate_test(SolveState *st, const LaneConst *lcp,
   const RowOps<ANYEQ> ro(rho, C);
   const RowSlots slots(R);
   const int it = st->it;
-  double *const ws = s_w + WS_OFF, *const wc = s_w + WC_OFF, *const wr = s_w + WR_OFF, *const xt = s_w + XT_OFF;
+  double *const wc = s_w + WC_OFF, *const wr = s_w + WR_OFF;
   const int kx = 3 * R.istep, kxa = R.act ? kx : 0;
   const bool wrx = R.act && R.par == 0;
+  double *const xk4 = x4_step(R.act ? R.istep : 0);
   bool done = false, converged = false, infeasible = false, refactor = false;
 #ifdef F16_EXP_STAMPW
   unsigned long long tt0_ = __builtin_amdgcn_s_memtime();
 #endif
-  // x behind the zero pad (operand of P x and A x); P x first, while the 72 Toeplitz doubles are not live yet: its 72 gathered
-  // matrix elements want the registers
+  if (R.l < 8) s_w[ZP_OFF + R.l] = 0.0;
+  // x behind the zero pad (operand of P x and A x); P x first, while the Toeplitz doubles are not live yet: its 72 matrix
+  // elements want the registers
   if (wrx) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) xt[XT_PAD + kx + c] = x[c];
+    *reinterpret_cast<double2 *>(xk4) = make_double2(x[0], x[1]); xk4[2] = x[2];
   }
   wave_lds_sync();
   double px[3];
   {
     double p6[6];
-    sym_matvec<true>(Pg, n, xt + XT_PAD, R, p6);
+    p_matvec(Pg, R, p6);
     wave_lds_sync();                                          // (the command-row buffer still holds w: nobody reads it any more)
     if (R.s == 0 && R.r < NB) {
 #pragma unroll
@@ -801,19 +882,22 @@ __device__ __noinline__ int terminate_test(SolveState *st, const LaneConst *lcp,
   double qu[3], cD[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) { qu[c] = R.act ? qv[kx + c] : 0.0; cD[c] = C.cs * (R.act ? Dv[kx + c] : 1.0); }
-  double Gd[4][6][3];
+  double Gd[TB][2][3];
   load_G_image(Gd, Gg, R.l);                                // (Gg: the per-lane image)
   TSTAMP(1)
   double ax3[3], aty3[3], axB[3];
-  stage3(Gd, xt, R, ax3);
-  stage1(Gd, ws, R, N, aty3);
+  stage3_partials(Gd, J);
+  stage1_partials(Gd, J);
+  wave_lds_sync();
+  stage3_totals(Q.a3, ax3);
+  stage1_totals(Q.a1, aty3);
   TSTAMP(2)
   double aty[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const int k = kxa + c;
     aty[c] = C.cinv * (aty3[c] + wc[k] + (wr[k] - wr[k + 3]));
-    const double xkk = xt[XT_PAD + k], xkm = xt[XT_PAD + k - 3];
+    const double xkk = xk4[c], xkm = xk4[c - 4];
     axB[c] = R.par ? xkk - xkm : xkk;
   }
   double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                // r1, |Ax|, |z|, r2, |Px|, |A'y|, |q|, |E dyb|, support(dyb)
@@ -849,7 +933,9 @@ __device__ __noinline__ int terminate_test(SolveState *st, const LaneConst *lcp,
       }
       wave_lds_sync();
       double t3[3];
-      stage1(Gd, ws, R, N, t3);
+      stage1_partials(Gd, J);
+      wave_lds_sync();
+      stage1_totals(Q.a1, t3);
       double wmax = 0.0;
       if (R.act) {
 #pragma unroll
@@ -916,7 +1002,7 @@ __device__ __forceinline__ bool solve_loop(SolveState *st, const LaneConst *lcp,
 #else
 #define WSTAMPK(i, j)
 #endif
-    ok = factorise(Pg, gw, xt + XT_PAD, N, cs, st->rho) && ok;
+    ok = factorise(Pg, gw, xt + XT_PAD, const_cast<double *>(Gg) + GIMG_DOUBLES, N, cs, st->rho) && ok;
     WSTAMPK(10, 12)
     if (!ok) break;
     start_point<ANYEQ>(st, lcp, N);
@@ -925,7 +1011,7 @@ __device__ __forceinline__ bool solve_loop(SolveState *st, const LaneConst *lcp,
       const int left = o.max_iter - st->it;
       const int nrun = left < st->to_check ? left : st->to_check;       // iterations up to the next test (>= 1)
       WSTAMPK(14, 15)
-      run_iterations<ANYEQ>(st, lcp, Gg, N, o.alpha, nrun);
+      run_iterations<ANYEQ>(st, lcp, Gg, Gg + GIMG_DOUBLES, N, o.alpha, nrun);
       WSTAMPK(13, 15)
       st->it += nrun; st->to_check -= nrun;
       if (st->to_check == 0) st->to_check = o.check_every;
@@ -1181,8 +1267,8 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
   p_block_image(Pg, pb, n);                                  // P as the symmetric block image (equilibration, termination test)
   double *const gimg = pb + WAVE_PBLK_DOUBLES / 2;            // the lanes' Toeplitz operands, lane-major
   {
-    double Gd[4][6][3];
-    load_G(Gd, Gg, R, N);
+    double Gd[TB][2][3];
+    load_G(Gd, Gg, tjob(), N);
     store_G_image(Gd, gimg, l);
   }
   wave_lds_sync();
