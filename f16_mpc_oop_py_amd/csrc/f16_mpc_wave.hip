@@ -54,7 +54,8 @@ static_assert(6 * 34 <= WS_SIZE && 4 * (XPADS + WN + 5) <= XT_SIZE && XT_PAD + 3
 // their half of the image holds the partial sums of the two Toeplitz stages:
 constexpr int KB_OFF = 18 * NL * 2;                    // 2160
 constexpr int P3_OFF = 0, P3_REC = 30, P3_SIZE = 22 * P3_REC;             // stage 3: record (block) = [5 steps][6 kept rows]; record 21: the idle lane's
-constexpr int P1_OFF = P3_OFF + P3_SIZE, P1_REC = 20, P1_SIZE = 64 * P1_REC;   // stage 1: record (lane) = [5 steps][3 sums + 1 pad]
+constexpr int P1_OFF = P3_OFF + P3_SIZE, P1_REC = 22, P1_SIZE = 64 * P1_REC;   // stage 1: record (lane) = [5 steps][3 sums + 1 pad] + 2: a record
+                                                       // stride of 44 banks puts the 16 lanes of an LDS pass on 16 different groups of four banks (40: on 8)
 constexpr int ZP_OFF = P1_OFF + P1_SIZE;               // eight zeros: what an absent partial sum reads
 static_assert(ZP_OFF + 8 <= KB_OFF && (P1_OFF & 1) == 0 && (ZP_OFF & 1) == 0, "partial-sum records");
 // scratch of the factorisation phases inside [0, KI_SIZE)
