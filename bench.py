@@ -258,6 +258,7 @@ def run(args):
     tr, src = recorded_traffic(B, T)
     out["roofline"]["traffic"] = tr
     out["roofline"]["traffic_source"] = src
+    out["roofline"]["issue"] = recorded_issue("k_rollout_q", kern_ms * 1e-3, batch=B, euler_steps=T)
     if grouped:
         # the one data-path collective -- all-gather of the trajectory shards -- timed on its own
         barrier()
@@ -282,6 +283,7 @@ def run(args):
             out["allgather"]["direct_p2p"] = {"ms": td * 1e3, "GB/s_per_gpu": full.numel() * 8 / td / 1e9}
             del full
     del traj
+    out["lqr_closed_loop"] = bench_lqr(args, dev, rank, world, fdist, barrier, value)
     if not args.no_large:
         out["roofline_large_batch"] = bench_large(args, dev, rank)
     if not args.no_mpc:
@@ -304,6 +306,27 @@ def run(args):
         dist.destroy_process_group()
 
 
+SIMDS, ISSUE_PER_SIMD = 1024, 0.6e9       # 256 CUs x 4 SIMDs; one VALU wave-instruction per 4 cycles at 2.4 GHz (MI355X_MICROARCH.md)
+
+
+def recorded_issue(kernel, seconds, **match):
+    """Secondary roofline for kernels that are bound by instruction issue, not by HBM: VALU wave-instructions per launch
+    (SQ_INSTS_VALU of a rocprofv3 --pmc pass of this same command, RECORDED in profiles/issue_valu.json by tools/*_pmc_summary.py)
+    over what 1024 SIMDs can issue in the launch's measured duration.  None if the recorded run was another workload."""
+    try:
+        rec = json.load(open(os.path.join(REPO, "profiles", "issue_valu.json")))[kernel]
+    except Exception:
+        return None
+    if any(rec.get(k) != v for k, v in match.items()):
+        return None
+    insts = rec["insts_valu_per_launch"]
+    return {"bound": "VALU issue", "achieved": insts / seconds / 1e9, "peak": SIMDS * ISSUE_PER_SIMD / 1e9, "unit": "G wave-instructions/s",
+            "frac": insts / seconds / (SIMDS * ISSUE_PER_SIMD), "insts_valu_per_launch": insts,
+            "source": "recorded: profiles/issue_valu.json (" + str(rec.get("source")) + ")",
+            "note": "an fp64 FMA with three register operands occupies a SIMD for 6 cycles, not 4, when one wavefront is resident "
+                    "(tools/micro/issue_mix.hip, profiles/r04_issue_mix.log): 1.0 is not reachable by fp64 code at one wave per SIMD"}
+
+
 def recorded_traffic(B, T):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of this same command
     (FETCH_SIZE/WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), RECORDED under profiles/ by
@@ -317,6 +340,41 @@ def recorded_traffic(B, T):
     except Exception:
         pass
     return None, None
+
+
+def bench_lqr(args, dev, rank, world, fdist, barrier, open_loop_value):
+    """The reference's running controller (flight_sim.py:139,181; test_env_mk2.py:70-85): closed loop under the LQR law, the action
+    of env.py:360-371 computed inside the rollout kernel every step (f16_rollout_lqr).  Same batch, steps and stored trajectory as
+    the headline open-loop leg; gains from each aircraft's own linearisation (outside the timed region)."""
+    import numpy as np
+    import torch
+    from f16_mpc_oop_py_amd import F16Batch
+    from f16_mpc_oop_py_amd.workload import config2_states
+    from f16_mpc_oop_py_amd.env import _vp
+    B, T = args.batch, args.euler_steps
+    x0, u0 = config2_states(B * world)
+    env = F16Batch(x0[rank * B:(rank + 1) * B], u0[rank * B:(rank + 1) * B], device=dev)
+    K = env._calc_LQR_gain().reshape(B, 27).t().contiguous()
+    dem = torch.zeros((3, B), dtype=torch.float64, device=dev)
+    traj = torch.empty((T, 18, B), dtype=torch.float64, device=dev)
+    n = max(3, args.steps // 2)
+
+    def one():
+        env._x.copy_(env._x_init)
+        rc = env.lib.f16_rollout_lqr(env.ctx.handle, _vp(env._x), _vp(env._u_init), _vp(K), _vp(dem), _vp(traj), _vp(env._u), _vp(env.status),
+                                     B, B, T, 1, env.dt, env.xcg, env.fi_flag, env.flags, env._stream)
+        assert rc == 0
+    one()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one()
+    barrier()
+    dt = fdist.max_over_ranks(time.perf_counter() - t0, dev) / n
+    v = world * B * T / dt
+    return {"value": v, "unit": "aircraft-steps/s", "ms_per_rollout": dt * 1e3, "ratio_to_open_loop": v / open_loop_value,
+            "frozen_aircraft": int(((env.status & 16) != 0).sum()), "finite": bool(torch.isfinite(traj[-1]).all()),
+            "note": "f16_rollout_lqr: u[1:4] = -K (x_ref - x9) + u0[1:4] per step inside the kernel, thrust held; K per aircraft"}
 
 
 def bench_large(args, dev, rank):
@@ -353,6 +411,7 @@ def bench_large(args, dev, rank):
            "steps_per_s": B * T / (ms * 1e-3), "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": B * T * BYTES_PER_STORED_STEP, "traffic": None,
            "note": "two waves per SIMD on all 256 CUs; fp64/VALU issue-bound"}
+    res["issue"] = recorded_issue("k_rollout_i", ms * 1e-3, batch=B, euler_steps=T)
     try:
         rec = json.load(open(os.path.join(REPO, "profiles", "traffic_k_rollout_large.json")))
         if rec.get("batch") == B and rec.get("euler_steps") == T:
@@ -441,6 +500,14 @@ def bench_mpc(args, dev, rank, world, fdist, barrier):
     del os.environ["F16_MPC_DISPATCH_ORDER"]
     res["dispatch"] = {"order": "longest-first by the previous call's iteration counts (any order gives the same results)",
                        "value_in_caller_order": world * B / dco, "ms_per_batch_in_caller_order": dco * 1e3}
+    res["first_call_value"] = world * B / dco
+    res["call_pattern_note"] = ("`value` is a REPEATED call of the same batch (workgroups ordered longest-first by the previous call's "
+                                "iteration counts: the closed loops' pattern); BASELINE config 4 as written is ONE call per aircraft on "
+                                "an unseen batch: `first_call_value` (no history; a stride spreads the aircraft over the chip)")
+    iss = recorded_issue("k_mpc_wave", legs[head]["ms_per_batch"] * 1e-3, batch=B, hzn=args.mpc_hzn)
+    if iss:
+        iss["note"] = "seconds = build + solve of this run; " + iss["note"]
+        res["roofline"]["issue"] = iss
     # linearise + ZOH + LQR chain (BASELINE config 3)
     env._calc_LQR_gain()
     barrier()
@@ -525,13 +592,13 @@ def bench_hzn_sweep(dev, B=64, max_hzn=150):
         return 8.0 * (2048 * q * (q + 1) + (n - 64 * q) * (q + 1) * 64 + 64)
     itn = it.sum(dim=1).cpu().numpy()                      # iterations per horizon, all aircraft
     stream = float(sum(itn[N - 1] * half_bytes(N) for N in range(33, max_hzn + 1)))
-    roof = {"bound": "hbm", "kernel": "k_mpc_big (one launch over the pairs N = 33..%d)" % max_hzn, "achieved": stream / dt2 / 1e9,
-            "peak": 8000.0, "unit": "GB/s", "frac": stream / dt2 / 8e12, "bytes_per_launch": stream,
-            "traffic": None, "note": "achieved = iterations x padded-half bytes of the KKT inverse over the whole REPEATED call (upper bound "
-            "on the launch time; N <= 32 included in the time, not in the bytes); counters: profiles/r03_sweep.json (FETCH_SIZE 2.8-5.5 TB "
-            "+ WRITE_SIZE 0.5 TB per launch: factorisations and set-up included)"}
+    roof = {"bound": "Infinity-Cache stream (NOT an HBM roofline)", "kernel": "k_mpc_big (one launch over the pairs N = 33..%d)" % max_hzn,
+            "achieved": stream / dt2 / 1e9, "peak": None, "unit": "GB/s", "frac": None, "bytes_per_launch": stream, "traffic": None,
+            "note": "achieved = iterations x padded-half bytes of the KKT inverse over the whole REPEATED call; the 256 inverses in flight "
+                    "(<= 0.93 MB each, 238 MB) sit in the 256 MB Infinity Cache, so this is a cache-stream rate set by what ONE CU can take "
+                    "in (tools/micro/cu_stream.hip), not a fraction of HBM bandwidth; counters: profiles/r03_sweep.json"}
     return {"aircraft": B, "max_hzn": max_hzn, "seconds": dt, "seconds_repeated_call": dt2, "solves": int(it.numel()),
-            "solves_per_s": it.numel() / dt, "roofline": roof,
+            "solves_per_s": it.numel() / dt, "stream": roof,
             "aircraft_iterations": float(it.sum()), "iterations_max": int(it.max()),
             "certified_infeasible": int((inf["status"] & 128).ne(0).sum()), "settings": "osqp_defaults",
             "note": "horizons <= 32 one call after the other; 33..150: one build launch per horizon, then ONE launch of the "
@@ -554,10 +621,8 @@ def bench_closed_loop(args, dev, rank, world, fdist, barrier):
     sl = slice(rank * B, (rank + 1) * B)
     res = {}
     short = max(4, T // 5)
-    for name, use_plan, steps in (("prepared_plan", True, T), ("one_shot", False, max(4, short // 2)),
-                                  ("prepared_plan_warm_start", True, short), ("prepared_plan_warm_start_check5", True, short),
-                                  ("prepared_plan_builder_rule", True, short),
-                                  ("prepared_plan_builder_rule_warm_start", True, short)):
+
+    def leg(name, use_plan, steps, keep_traj=False):
         env = F16Batch(x0[sl], u0[sl], xcg=0.35, device=dev)
         env.build_ssr()
         if use_plan:
@@ -567,29 +632,45 @@ def bench_closed_loop(args, dev, rank, world, fdist, barrier):
             env.prepare_MPC(args.mpc_hzn, settings=st or None, warm_start="warm_start" in name)
         fdist.closed_loop_mpc_rollout(env, steps=2, hzn=args.mpc_hzn, gather=False, use_plan=use_plan)
         env.reset()
+        stats = {}
         barrier()
         t0 = time.perf_counter()
-        traj = fdist.closed_loop_mpc_rollout(env, steps=steps, hzn=args.mpc_hzn, gather=False, use_plan=use_plan)
+        traj = fdist.closed_loop_mpc_rollout(env, steps=steps, hzn=args.mpc_hzn, gather=False, use_plan=use_plan, stats=stats)
         barrier()
         dt = fdist.max_over_ranks(time.perf_counter() - t0, dev)
         assert bool(torch.isfinite(traj).all()) and fdist.or_status(env.status) & ~(64 | 128) == 0
-        res[name] = {"aircraft_steps_per_s": world * B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps}
-        if name == "prepared_plan":
-            barrier()
-            t0 = time.perf_counter()
-            full = fdist.all_gather_trajectories(traj, layout="ranks")
-            barrier()
-            tg = fdist.max_over_ranks(time.perf_counter() - t0, dev)
-            res["allgather"] = {"ms": tg * 1e3, "bytes_received_per_gpu": int(full.numel() * 8) if fdist.group_active() else 0,
-                                "shape": list(full.shape), "world": fdist.world_size()}
-            res["aircraft_steps_per_s"] = world * B * steps / dt
-            res["aircraft_steps_per_s_including_collation"] = world * B * steps / (dt + tg)
-            del full
-        del env, traj
+        r = {"aircraft_steps_per_s": world * B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
+             "iters_mean": stats["iters_mean"]}
+        return (r, traj, dt) if keep_traj else (r, None, dt)
+
+    # every variant over the SAME number of steps (the first steps of a closed loop need the most iterations: legs of different
+    # length are not comparable)
+    for name, use_plan in (("prepared_plan", True), ("one_shot", False), ("prepared_plan_warm_start", True),
+                           ("prepared_plan_warm_start_check5", True), ("prepared_plan_builder_rule", True),
+                           ("prepared_plan_builder_rule_warm_start", True)):
+        res[name] = leg(name, use_plan, short)[0]
+    # the headline: the faster of the two legs that solve as the reference does (cold start per call, OSQP defaults), over all T steps
+    head = "prepared_plan" if res["prepared_plan"]["ms_per_step"] <= res["one_shot"]["ms_per_step"] else "one_shot"
+    r, traj, dt = leg(head, head == "prepared_plan", T, keep_traj=True)
+    res["headline_leg"] = head
+    res["headline"] = r
+    barrier()
+    t0 = time.perf_counter()
+    full = fdist.all_gather_trajectories(traj, layout="ranks")
+    barrier()
+    tg = fdist.max_over_ranks(time.perf_counter() - t0, dev)
+    res["allgather"] = {"ms": tg * 1e3, "bytes_received_per_gpu": int(full.numel() * 8) if fdist.group_active() else 0,
+                        "shape": list(full.shape), "world": fdist.world_size()}
+    res["aircraft_steps_per_s"] = world * B * T / dt
+    res["aircraft_steps_per_s_including_collation"] = world * B * T / (dt + tg)
+    del full, traj
     res["batch_per_gpu"] = B
     res["steps"] = T
     res["hzn"] = args.mpc_hzn
-    res["note"] = ("prepared_plan / one_shot start every solve cold, as the reference does (a new OSQP object per call); "
+    res["short_leg_steps"] = short
+    res["note"] = ("every variant runs the same `short_leg_steps`; `headline` = the faster reference-settings leg over all `steps`.  "
+                   "prepared_plan / one_shot start every solve cold, as the reference does (a new OSQP object per call; with OSQP's "
+                   "defaults a plan saves the QP build only -- the equilibration depends on q); "
                    "warm_start is the opt-in extension (OSQP's in-object default); check5 = the same with the termination test "
                    "every 5 iterations instead of OSQP's 25 (a warm-started solve needs fewer than 25); builder_rule = the opt-in "
                    "solver settings (no equilibration, start value of rho from the traces; KKT factorisation cached in the plan)")

@@ -318,7 +318,8 @@ __device__ __forceinline__ bool inverse9_tile(const d4_t &M, d4_t &W, double *Wl
   return ok;
 }
 
-__device__ __forceinline__ int dare_sda_wave(const double *A0, const double *Bm, const double *Q, double *X, double *scr) {
+// Rinv: null = R is the identity (env.py:405-407), else the inverse of the input weight, 3 x 3 row-major (utils.py:219 `dlqr(A, B, Q, R)`)
+__device__ __forceinline__ int dare_sda_wave(const double *A0, const double *Bm, const double *Q, double *X, double *scr, const double *Rinv = nullptr) {
   const int l = lane_id(), lc = l & 15, lq = l >> 4;
   const d4_t zero = {0.0, 0.0, 0.0, 0.0};
   d4_t A = tile9(A0, false), At = tile9(A0, true), H = tile9(Q, false);
@@ -326,7 +327,9 @@ __device__ __forceinline__ int dare_sda_wave(const double *A0, const double *Bm,
   {
     d4_t Bt = zero;                                  // tile of B' (3x9): element (k, i) = B[i][k]
     if (lq < 3 && lc < 9) Bt[0] = Bm[lc * 3 + lq];
-    G = __builtin_amdgcn_mfma_f64_16x16x4f64(Bt[0], Bt[0], zero, 0, 0, 0);     // G0 = B R^-1 B', R = I
+    double br = Bt[0];                               // element (lc, lq) of B R^-1
+    if (Rinv && lq < 3 && lc < 9) br = Bm[lc * 3] * Rinv[lq] + Bm[lc * 3 + 1] * Rinv[3 + lq] + Bm[lc * 3 + 2] * Rinv[6 + lq];
+    G = __builtin_amdgcn_mfma_f64_16x16x4f64(br, Bt[0], zero, 0, 0, 0);        // G0 = B R^-1 B'  (R = I: B B')
   }
   d4_t eye = zero;
 #pragma unroll
@@ -388,20 +391,21 @@ __device__ __forceinline__ int dare_sda_wave(const double *A0, const double *Bm,
   return it;
 }
 
-// K = (B'XB + R)^-1 (B'XA), R = I  (utils.py:244); scr >= 27+27+9+18+3 (+pad)
-__device__ void lqr_gain_wave(const double *A, const double *Bm, const double *X, double *K, double *scr) {
+// K = (B'XB + R)^-1 (B'XA)  (utils.py:244; Rw: null = R is the identity); scr >= 27+27+9+18+3 (+pad)
+__device__ void lqr_gain_wave(const double *A, const double *Bm, const double *X, double *K, double *scr, const double *Rw = nullptr) {
   Bump al{scr};
   double *XB = al.take(27), *BXA = al.take(27), *S = al.take(9), *Wx = al.take(18), *f = al.take(3);
   mm<false, false>(XB, X, Bm, 9, 9, 3);        // X B   (9x3)
   mm<true, false>(S, Bm, XB, 3, 9, 3);         // B' X B
-  for (int e = lane_id(); e < 3; e += F16_WAVE) S[e * 4] += 1.0;
+  if (Rw) { for (int e = lane_id(); e < 9; e += F16_WAVE) S[e] += Rw[e]; }
+  else { for (int e = lane_id(); e < 3; e += F16_WAVE) S[e * 4] += 1.0; }
   __syncthreads();
   mm<true, false>(BXA, XB, A, 3, 9, 9);        // (X B)' A = B' X A   (X symmetric)
   inverse(S, 3, Wx, f);
   mm<false, false>(K, S, BXA, 3, 3, 9);
 }
 
-struct LqrArgs { const double *Ad, *Bd, *Cd; double *K, *Pare; int32_t *status; long B, ld; };
+struct LqrArgs { const double *Ad, *Bd, *Cd; double *K, *Pare; int32_t *status; long B, ld; MpcProb pb; };
 
 __global__ __launch_bounds__(64, 3) void k_lqr(LqrArgs a) {
   __shared__ double smem[82 * 5 + 28 * 2 + DARE_SCRATCH + 100];   // DARE scratch also serves lqr_gain_wave
@@ -412,9 +416,10 @@ __global__ __launch_bounds__(64, 3) void k_lqr(LqrArgs a) {
     load_soa(A, a.Ad, 81, a.ld, b);
     load_soa(Bm, a.Bd, 27, a.ld, b);
     load_soa(C, a.Cd, 81, a.ld, b);
-    mm<true, false>(Q, C, C, 9, 9, 9);                 // Q = C'C (env.py:353)
-    const int it = dare_sda_wave(A, Bm, Q, X, scr);
-    lqr_gain_wave(A, Bm, X, K, scr);
+    if (a.pb.custom_q) { for (int e = lane_id(); e < 81; e += F16_WAVE) Q[e] = a.pb.Q[e]; __syncthreads(); }      // utils.py:219 `Q`
+    else mm<true, false>(Q, C, C, 9, 9, 9);            // Q = C'C (env.py:353)
+    const int it = dare_sda_wave(A, Bm, Q, X, scr, a.pb.custom_r ? a.pb.Rinv : nullptr);
+    lqr_gain_wave(A, Bm, X, K, scr, a.pb.custom_r ? a.pb.R : nullptr);
     for (int e = lane_id(); e < 27; e += F16_WAVE) a.K[e * a.ld + b] = -K[e];   // K = -dlqr(...) (env.py:356)
     if (a.Pare) store_soa(a.Pare, X, 81, a.ld, b);
     if (a.status && it >= 60 && lane_id() == 0) a.status[b] |= F16_ST_QP_MAXITER;
@@ -515,18 +520,20 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
       if (l < 27) Bm[l] = b0;
       __syncthreads();
     }
-    mm<true, false>(Q, Qb, Qb, 9, 9, 9);              // Q = C'C (env.py:389)
+    if (a.pb.custom_q) { for (int e = l; e < 81; e += F16_WAVE) Q[e] = a.pb.Q[e]; __syncthreads(); }       // utils.py:21 `Q`
+    else mm<true, false>(Q, Qb, Qb, 9, 9, 9);         // Q = C'C (env.py:389)
     }
     if (l < 9) {
       const int MX[9] = {3, 4, 7, 8, 9, 10, 11, 17, 16};
       const double v = a.x ? a.x[MX[l] * a.ld + b] : 0.0;            // (no state when a plan is prepared)
       x9[l] = v;
-      xref[l] = (l >= 5 && l < 8 && a.dem) ? a.dem[(l - 5) * a.ld + b] : v;   // env.py:380-383 (x_ref[5:8] = demands)
+      xref[l] = a.xref ? a.xref[l * a.ld + b]                                  // utils.py:21 `x_ref` as the caller gives it
+                       : ((l >= 5 && l < 8 && a.dem) ? a.dem[(l - 5) * a.ld + b] : v);   // env.py:380-383 (x_ref[5:8] = demands)
     }
     __syncthreads();
     BSTAMP(0)
     if (!update_only) {
-    dare_sda_wave(A, Bm, Q, X, scr);
+    dare_sda_wave(A, Bm, Q, X, scr, a.pb.custom_r ? a.pb.Rinv : nullptr);
     BSTAMP(1)
     // (the gain K = -dlqr of utils.py:96 is not needed itself: it only enters through Q_bar)
     // Q_bar (utils.py:100) solves X = Phi' X Phi + Q + K'RK with Phi = A + B K: for the LQR gain K that equation IS the
@@ -633,7 +640,9 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
 #pragma unroll
             for (int p = 0; p < 9; ++p) sb += QbGk[p * 3 + ra] * gc[p];
             const int gi = 3 * j + ra, gj = 3 * lcol + cb;
-            if (gi >= gj) Pg[tri(gi, gj)] = 2.0 * (tq[t] + sb + ((gi == gj) ? 1.0 : 0.0));      // RR = I (env.py:405-407)
+            // RR = blkdiag(R, ..., R) (utils.py:108-111); R = I (env.py:405-407) unless the caller gave one
+            const double rr_ = a.pb.custom_r ? (d == 0 ? a.pb.R[ra * 3 + cb] : 0.0) : ((gi == gj) ? 1.0 : 0.0);
+            if (gi >= gj) Pg[tri(gi, gj)] = 2.0 * (tq[t] + sb + rr_);
           }
         }
         __syncthreads();                                                    // jit is rewritten by the next step
@@ -655,19 +664,19 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
       if (row < ms) {
         const int i = row / 6, rr = row - 6 * i;
         const double pm = pred[i * 9 + SROW[rr]];
-        lo[ri] = SLB[rr] - pm;
-        hi[ri] = SUB[rr] - pm;
+        lo[ri] = a.pb.slb[rr] - pm;
+        hi[ri] = a.pb.sub[rr] - pm;
       } else if (row < ms + n) {
         const int c = (row - ms) % 3;
-        lo[ri] = ULB[c]; hi[ri] = UUB[c];
+        lo[ri] = a.pb.ulb[c]; hi[ri] = a.pb.uub[c];
       } else if (row < m) {
         const int k = row - ms - n, c = k % 3;
         if (k < 3) {
           const double act = a.x[(13 + c) * a.ld + b];
-          lo[ri] = act + RLB[c] * a.dt;
-          hi[ri] = act + RUB[c] * a.dt;
+          lo[ri] = act + a.pb.rlb[c] * a.dt;
+          hi[ri] = act + a.pb.rub[c] * a.dt;
         } else {
-          lo[ri] = RLB[c]; hi[ri] = RUB[c];              // reference quirk: not multiplied by dt (utils.py:151-152)
+          lo[ri] = a.pb.rlb[c]; hi[ri] = a.pb.rub[c];              // reference quirk: not multiplied by dt (utils.py:151-152)
         }
       }
     }
@@ -975,13 +984,86 @@ extern "C" int f16_c2d_full_batch(f16_ctx *ctx, const double *Ac, const double *
   return hip_check(hipGetLastError(), "f16_c2d_full_batch launch");
 }
 
-extern "C" int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, double *K, double *Pare,
-                             int32_t *status, long B, long ld, void *stream) {
+// Weights and bounds as the caller gives them (utils.py:21, :219) -> the kernels' MpcProb; null = env.py's constants.
+// +-INFINITY (or anything beyond OSQP's infinity 1e30) becomes +-1e30, as OSQP itself reads it.  The solvers keep the six state
+// rows the reference bounds (alpha, beta, p, q, r, lf2: parameters.py:59-95) and leave phi, theta, lf1 out of the iteration, so
+// THAT pattern is fixed: a finite bound on one of the three, or no bound at all on one of the six, is refused (the QP-build
+// entry f16_mpc_qp_debug_w takes any pattern).
+int f16::mpc_fill_prob(MpcProb *p, const f16_mpc_weights *w) {
+  mpc_default_prob(p);
+  if (!w) return F16_OK;
+  auto inf = [](double v) { return !(fabs(v) < 1e20); };
+  auto clip = [](double v) { return v > 1e30 ? 1e30 : (v < -1e30 ? -1e30 : v); };
+  if (!w->q_from_cd) {
+    for (int i = 0; i < 9; ++i)
+      for (int j = 0; j < 9; ++j) {
+        if (!isfinite(w->Q[i * 9 + j]) || fabs(w->Q[i * 9 + j] - w->Q[j * 9 + i]) > 1e-12 * (fabs(w->Q[i * 9 + j]) + fabs(w->Q[j * 9 + i])))
+          return set_error(F16_EINVAL, "f16_mpc_weights: Q must be finite and symmetric");
+        p->Q[i * 9 + j] = 0.5 * (w->Q[i * 9 + j] + w->Q[j * 9 + i]);
+      }
+    p->custom_q = 1;
+  }
+  {
+    const double *R = w->R;
+    bool ident = true;
+    for (int i = 0; i < 9; ++i) {
+      if (!isfinite(R[i])) return set_error(F16_EINVAL, "f16_mpc_weights: R must be finite");
+      ident = ident && R[i] == ((i % 4 == 0) ? 1.0 : 0.0);
+    }
+    if (!ident) {
+      if (fabs(R[1] - R[3]) + fabs(R[2] - R[6]) + fabs(R[5] - R[7]) > 1e-12 * (fabs(R[0]) + fabs(R[4]) + fabs(R[8])))
+        return set_error(F16_EINVAL, "f16_mpc_weights: R must be symmetric");
+      const double c00 = R[4] * R[8] - R[5] * R[7], c01 = R[5] * R[6] - R[3] * R[8], c02 = R[3] * R[7] - R[4] * R[6];
+      const double det = R[0] * c00 + R[1] * c01 + R[2] * c02;
+      if (!(R[0] > 0) || !(R[0] * R[4] - R[1] * R[3] > 0) || !(det > 0)) return set_error(F16_EINVAL, "f16_mpc_weights: R must be positive definite");
+      const double inv[9] = {c00, R[2] * R[7] - R[1] * R[8], R[1] * R[5] - R[2] * R[4],
+                             c01, R[0] * R[8] - R[2] * R[6], R[2] * R[3] - R[0] * R[5],
+                             c02, R[1] * R[6] - R[0] * R[7], R[0] * R[4] - R[1] * R[3]};
+      for (int i = 0; i < 9; ++i) { p->R[i] = R[i]; p->Rinv[i] = inv[i] / det; }
+      p->custom_r = 1;
+    }
+  }
+  static const int srow[6] = {2, 3, 4, 5, 6, 8}, free_rows[3] = {0, 1, 7};
+  for (int k = 0; k < 3; ++k)
+    if (!inf(w->x_lb[free_rows[k]]) || !inf(w->x_ub[free_rows[k]]))
+      return set_error(F16_EINVAL, "f16_mpc_weights: phi, theta and lf1 (MPC states 0, 1, 7) carry no bounds in the solvers (use f16_mpc_qp_debug_w for the QP alone)");
+  for (int k = 0; k < 6; ++k) {
+    const double lo = w->x_lb[srow[k]], hi = w->x_ub[srow[k]];
+    if (lo != lo || hi != hi || (inf(lo) && inf(hi)) || lo > hi) return set_error(F16_EINVAL, "f16_mpc_weights: a bounded state row needs lb <= ub and at least one finite bound");
+    p->slb[k] = clip(lo); p->sub[k] = clip(hi);
+  }
+  for (int c = 0; c < 3; ++c) {
+    const double v[4] = {w->u_lb[c], w->u_ub[c], w->udot_lb[c], w->udot_ub[c]};
+    if (v[0] != v[0] || v[1] != v[1] || v[2] != v[2] || v[3] != v[3] || v[0] > v[1] || v[2] > v[3] || (inf(v[0]) && inf(v[1])) || (inf(v[2]) && inf(v[3])))
+      return set_error(F16_EINVAL, "f16_mpc_weights: command and rate rows need lb <= ub and at least one finite bound");
+    p->ulb[c] = clip(v[0]); p->uub[c] = clip(v[1]); p->rlb[c] = clip(v[2]); p->rub[c] = clip(v[3]);
+  }
+  return F16_OK;
+}
+
+extern "C" void f16_mpc_default_weights(f16_mpc_weights *w) {
+  if (!w) return;
+  *w = f16_mpc_weights{};
+  w->q_from_cd = 1;
+  static const double xlb[9] = {-INFINITY, -INFINITY, -20., -30., -300., -100., -50., -INFINITY, 0.};      // parameters.py:59-95 in MPC-state order
+  static const double xub[9] = {INFINITY, INFINITY, 90., 30., 300., 100., 50., INFINITY, 25.};
+  static const double ulb[3] = {-25., -21.5, -30.}, uub[3] = {25., 21.5, 30.}, rlb[3] = {-60., -80., -120.}, rub[3] = {60., 80., 120.};
+  for (int i = 0; i < 9; ++i) { w->Q[i * 10] = 1.0; w->x_lb[i] = xlb[i]; w->x_ub[i] = xub[i]; }
+  for (int i = 0; i < 3; ++i) { w->R[i * 4] = 1.0; w->u_lb[i] = ulb[i]; w->u_ub[i] = uub[i]; w->udot_lb[i] = rlb[i]; w->udot_ub[i] = rub[i]; }
+}
+
+extern "C" int f16_lqr_batch_w(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const f16_mpc_weights *h_w,
+                               double *K, double *Pare, int32_t *status, long B, long ld, void *stream) {
   if (!ctx || !Ad || !Bd || !Cd || !K || B < 0 || ld < B) return set_error(F16_EINVAL, "bad argument to f16_lqr_batch");
   if (B == 0) return F16_OK;
-  LqrArgs a{Ad, Bd, Cd, K, Pare, status, B, ld};
+  LqrArgs a{Ad, Bd, Cd, K, Pare, status, B, ld, MpcProb{}};
+  if (int rc = mpc_fill_prob(&a.pb, h_w)) return rc;
   hipLaunchKernelGGL(k_lqr, dim3(wave_grid(B)), dim3(64), 0, (hipStream_t)stream, a);
   return hip_check(hipGetLastError(), "f16_lqr_batch launch");
+}
+extern "C" int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, double *K, double *Pare,
+                             int32_t *status, long B, long ld, void *stream) {
+  return f16_lqr_batch_w(ctx, Ad, Bd, Cd, nullptr, K, Pare, status, B, ld, stream);
 }
 
 extern "C" void f16_qp_default_settings(f16_qp_settings *s) {
@@ -1138,11 +1220,19 @@ static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream, int mode, void **k
 extern "C" int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
                              const double *dem, double *u_cmd, double *u_seq, double *info, int32_t *status, long B,
                              long ld, int hzn, double dt, const f16_qp_settings *s, void *stream) {
-  if (!ctx || !Ad || !Bd || !Cd || !x || !dem || !u_cmd || B < 0 || ld < B) return set_error(F16_EINVAL, "bad argument to f16_mpc_batch");
+  return f16_mpc_batch_w(ctx, Ad, Bd, Cd, x, dem, nullptr, nullptr, u_cmd, u_seq, info, status, B, ld, hzn, dt, s, stream);
+}
+
+extern "C" int f16_mpc_batch_w(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
+                               const double *dem, const double *x_ref, const f16_mpc_weights *h_w, double *u_cmd, double *u_seq,
+                               double *info, int32_t *status, long B, long ld, int hzn, double dt, const f16_qp_settings *s,
+                               void *stream) {
+  if (!ctx || !Ad || !Bd || !Cd || !x || (!dem && !x_ref) || !u_cmd || B < 0 || ld < B) return set_error(F16_EINVAL, "bad argument to f16_mpc_batch");
   if (B == 0) return F16_OK;
   MpcArgs a{};
-  a.Ad = Ad; a.Bd = Bd; a.Cd = Cd; a.x = x; a.dem = dem; a.ucmd = u_cmd; a.useq = u_seq; a.info = info; a.status = status;
+  a.Ad = Ad; a.Bd = Bd; a.Cd = Cd; a.x = x; a.dem = dem; a.xref = x_ref; a.ucmd = u_cmd; a.useq = u_seq; a.info = info; a.status = status;
   a.B = B; a.ld = ld; a.N = hzn; a.dt = dt;
+  if (int rc = mpc_fill_prob(&a.pb, h_w)) return rc;
   if (s) a.s = *s; else f16_qp_default_settings(&a.s);
   if (a.s.check_every < 1 || a.s.rho_every < 1 || !(a.s.rho >= 0) || !(a.s.sigma > 0) || a.s.scaling < 0 || a.s.scaling > 100 ||
       (a.s.scaling > 0 && !(a.s.rho > 0)))
@@ -1181,6 +1271,7 @@ extern "C" int f16_mpc_hzn_sweep(f16_ctx *ctx, const double *Ad, const double *B
   }
   if (N > hzn_hi) return F16_OK;
   MpcArgs a{};
+  mpc_default_prob(&a.pb);
   a.Ad = Ad; a.Bd = Bd; a.Cd = Cd; a.x = x; a.dem = dem; a.B = B; a.ld = ld; a.dt = dt; a.s = st;
   if (a.s.check_every < 1 || a.s.rho_every < 1 || !(a.s.rho >= 0) || !(a.s.sigma > 0) || a.s.scaling < 0 || a.s.scaling > 100 ||
       (a.s.scaling > 0 && !(a.s.rho > 0)) || (a.s.adaptive_rho && a.s.rho_every % a.s.check_every != 0))
@@ -1256,6 +1347,7 @@ struct f16_mpc_plan {
   bool warm_on, have_prev;
   int32_t *sched;      // [2][B]: iteration counts of the last solve | dispatch order of the next (longest first)
   bool have_order;
+  void *last_stream;   // the stream of the creation / the last solve: what f16_mpc_plan_destroy waits for
   MpcArgs a;
 };
 
@@ -1270,11 +1362,19 @@ static int plan_launch_build(f16_mpc_plan *p, MpcArgs &a, void *stream) {
 
 extern "C" int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const double *Ad, const double *Bd, const double *Cd,
                                    long B, long ld, int hzn, double dt, const f16_qp_settings *s, void *stream) {
+  return f16_mpc_plan_create_w(ctx, plan, Ad, Bd, Cd, nullptr, B, ld, hzn, dt, s, stream);
+}
+
+extern "C" int f16_mpc_plan_create_w(f16_ctx *ctx, f16_mpc_plan **plan, const double *Ad, const double *Bd, const double *Cd,
+                                     const f16_mpc_weights *h_w, long B, long ld, int hzn, double dt, const f16_qp_settings *s,
+                                     void *stream) {
   if (!ctx || !plan || !Ad || !Bd || !Cd || B < 1 || ld < B) return set_error(F16_EINVAL, "bad argument to f16_mpc_plan_create");
+  MpcProb pb;
+  if (int rc = mpc_fill_prob(&pb, h_w)) return rc;
   if (hzn < 1 || hzn > MAXN) return set_error(F16_EINVAL, "prepared plans need 1 <= hzn <= 40");
   f16_mpc_plan *p = new f16_mpc_plan();
   p->ctx = ctx; p->B = B; p->ld = ld; p->N = hzn; p->dt = dt;
-  p->warm = nullptr; p->warm_on = false; p->have_prev = false; p->sched = nullptr; p->have_order = false;
+  p->warm = nullptr; p->warm_on = false; p->have_prev = false; p->sched = nullptr; p->have_order = false; p->last_stream = stream;
   if (s) p->s = *s; else f16_qp_default_settings(&p->s);
   if (p->s.check_every < 1 || p->s.rho_every < 1 || !(p->s.rho >= 0) || !(p->s.sigma > 0) || p->s.max_iter < 1 || p->s.scaling < 0 ||
       p->s.scaling > 100 || (p->s.scaling > 0 && !(p->s.rho > 0)) || (p->s.adaptive_rho && p->s.rho_every % p->s.check_every != 0)) {
@@ -1291,6 +1391,7 @@ extern "C" int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const doub
   if (int rc = hip_check(hipMalloc(&p->sched, 2 * (size_t)B * sizeof(int32_t)), "hipMalloc MPC plan")) { (void)hipFree(p->buf); delete p; return rc; }
   MpcArgs &a = p->a;
   a = MpcArgs{};
+  a.pb = pb;
   a.Ad = Ad; a.Bd = Bd; a.Cd = Cd; a.B = B; a.ld = ld; a.N = hzn; a.dt = dt; a.s = p->s;
   a.Ppk = p->buf; a.ext = a.Ppk + np * (size_t)B;
   a.tiles = a.ext + mpc_ext_doubles(hzn) * (size_t)B;
@@ -1311,9 +1412,15 @@ extern "C" int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const doub
 
 extern "C" int f16_mpc_plan_solve(f16_mpc_plan *p, const double *x, const double *dem, double *u_cmd, double *u_seq,
                                   double *info, int32_t *status, void *stream) {
-  if (!p || !x || !dem || !u_cmd) return set_error(F16_EINVAL, "bad argument to f16_mpc_plan_solve");
+  return f16_mpc_plan_solve_w(p, x, dem, nullptr, u_cmd, u_seq, info, status, stream);
+}
+
+extern "C" int f16_mpc_plan_solve_w(f16_mpc_plan *p, const double *x, const double *dem, const double *x_ref, double *u_cmd,
+                                    double *u_seq, double *info, int32_t *status, void *stream) {
+  if (!p || !x || (!dem && !x_ref) || !u_cmd) return set_error(F16_EINVAL, "bad argument to f16_mpc_plan_solve");
   MpcArgs a = p->a;
-  a.x = x; a.dem = dem; a.ucmd = u_cmd; a.useq = u_seq; a.info = info; a.status = status;
+  a.x = x; a.dem = dem; a.xref = x_ref; a.ucmd = u_cmd; a.useq = u_seq; a.info = info; a.status = status;
+  p->last_stream = stream;
   a.mode = 2;
   a.warm = p->warm_on ? p->warm : nullptr;
   a.warm_load = p->warm_on && p->have_prev;
@@ -1344,7 +1451,8 @@ extern "C" int f16_mpc_plan_warm_start(f16_mpc_plan *p, int on) {
 
 extern "C" void f16_mpc_plan_destroy(f16_mpc_plan *p) {
   if (!p) return;
-  (void)hipDeviceSynchronize();
+  // wait for the plan's own work only (the stream of its creation / last solve), not for every stream of the device
+  (void)hipStreamSynchronize((hipStream_t)p->last_stream);
   (void)hipFree(p->buf);
   if (p->sched) (void)hipFree(p->sched);
   if (p->warm) (void)hipFree(p->warm);
@@ -1354,8 +1462,20 @@ extern "C" void f16_mpc_plan_destroy(f16_mpc_plan *p) {
 extern "C" int f16_mpc_qp_debug(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
                                 const double *dem, long b, long ld, int hzn, double dt, double *h_P, double *h_q, double *h_A,
                                 double *h_l, double *h_u) {
-  if (!ctx || !Ad || !Bd || !Cd || !x || !dem || b < 0 || b >= ld || !h_P || !h_q || !h_A || !h_l || !h_u)
+  return f16_mpc_qp_debug_w(ctx, Ad, Bd, Cd, x, dem, nullptr, nullptr, b, ld, hzn, dt, h_P, h_q, h_A, h_l, h_u);
+}
+
+extern "C" int f16_mpc_qp_debug_w(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
+                                  const double *dem, const double *x_ref, const f16_mpc_weights *h_w, long b, long ld, int hzn,
+                                  double dt, double *h_P, double *h_q, double *h_A, double *h_l, double *h_u) {
+  if (!ctx || !Ad || !Bd || !Cd || !x || (!dem && !x_ref) || b < 0 || b >= ld || !h_P || !h_q || !h_A || !h_l || !h_u)
     return set_error(F16_EINVAL, "bad argument to f16_mpc_qp_debug");
+  f16_mpc_weights wd;
+  f16_mpc_default_weights(&wd);
+  const f16_mpc_weights *wq = h_w ? h_w : &wd;          // (the bounds of the dense QP below: any pattern)
+  f16_mpc_weights wk = *wq;                              // (for the kernel: cost only -- its bounds are not used by the build)
+  for (int i = 0; i < 9; ++i) { wk.x_lb[i] = wd.x_lb[i]; wk.x_ub[i] = wd.x_ub[i]; }
+  for (int i = 0; i < 3; ++i) { wk.u_lb[i] = wd.u_lb[i]; wk.u_ub[i] = wd.u_ub[i]; wk.udot_lb[i] = wd.udot_lb[i]; wk.udot_ub[i] = wd.udot_ub[i]; }
   const int N = hzn, n = 3 * N, rows = 15 * N;
   if (N < 1 || N > BIG_MAXN) return set_error(F16_EINVAL, "horizon must be 1..150");
   const size_t np = (size_t)n * (n + 1) / 2;
@@ -1364,7 +1484,8 @@ extern "C" int f16_mpc_qp_debug(f16_ctx *ctx, const double *Ad, const double *Bd
   int rc;
   if ((rc = hip_check(hipMalloc(&d_u, 3 * ld * sizeof(double)), "hipMalloc dbg u"))) return rc;
   MpcArgs a{};
-  a.Ad = Ad; a.Bd = Bd; a.Cd = Cd; a.x = x; a.dem = dem; a.ucmd = d_u; a.B = b + 1; a.ld = ld; a.N = N; a.dt = dt;
+  a.Ad = Ad; a.Bd = Bd; a.Cd = Cd; a.x = x; a.dem = dem; a.xref = x_ref; a.ucmd = d_u; a.B = b + 1; a.ld = ld; a.N = N; a.dt = dt;
+  if ((rc = mpc_fill_prob(&a.pb, &wk))) { (void)hipFree(d_u); return rc; }
   f16_qp_default_settings(&a.s);
   void *block = nullptr;
   rc = mpc_launch(ctx, a, nullptr, 1, &block);      // build only; the workspace stays ours until read back
@@ -1392,9 +1513,7 @@ extern "C" int f16_mpc_qp_debug(f16_ctx *ctx, const double *Ad, const double *Bd
     h_A[(size_t)(12 * N + k) * n + k] = 1.0;
     if (k >= 3) h_A[(size_t)(12 * N + k) * n + k - 3] = -1.0;
   }
-  static const double xlb[9] = {-INFINITY, -INFINITY, -20., -30., -300., -100., -50., -INFINITY, 0.};
-  static const double xub[9] = {INFINITY, INFINITY, 90., 30., 300., 100., 50., INFINITY, 25.};
-  static const double ulb[3] = {-25., -21.5, -30.}, uub[3] = {25., 21.5, 30.}, rlb[3] = {-60., -80., -120.}, rub[3] = {60., 80., 120.};
+  const double *xlb = wq->x_lb, *xub = wq->x_ub, *ulb = wq->u_lb, *uub = wq->u_ub, *rlb = wq->udot_lb, *rub = wq->udot_ub;
   for (int i = 0; i < N; ++i)
     for (int r = 0; r < 9; ++r) {
       h_l[9 * i + r] = xlb[r] - pred[9 * i + r];

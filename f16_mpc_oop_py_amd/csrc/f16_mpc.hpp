@@ -21,19 +21,35 @@ __host__ __device__ inline double osqp_limit_scaling(double v) {
   v = v < OSQP_MIN_SCALING ? 1.0 : v;
   return v > OSQP_MAX_SCALING ? OSQP_MAX_SCALING : v;
 }
-static __constant__ double XLB9[9] = {-1e30, -1e30, -20., -30., -300., -100., -50., -1e30, 0.};   // all nine MPC state rows
 constexpr int MAXN = 40;                         // horizon limit of the LDS-resident solver
 constexpr int MAXT = (12 * MAXN + 63) / 64;      // constraint rows per lane
 constexpr int BIG_MAXN = 150;                    // horizon limit of the slow path (row values and KKT inverse in HBM): the
                                                  // reference's own sweep range, env.py:426-436
-static __constant__ int SROW[6] = {2, 3, 4, 5, 6, 8};   // MPC states with finite bounds: alpha,beta,p,q,r,lf2 (parameters.py:59-95,135)
-static __constant__ double SLB[6] = {-20., -30., -300., -100., -50., 0.};
-static __constant__ double SUB[6] = {90., 30., 300., 100., 50., 25.};
-static __constant__ double ULB[3] = {-25., -21.5, -30.}, UUB[3] = {25., 21.5, 30.};      // parameters.py:125-126
-static __constant__ double RLB[3] = {-60., -80., -120.}, RUB[3] = {60., 80., 120.};      // parameters.py:128-129
+static __constant__ int SROW[6] = {2, 3, 4, 5, 6, 8};   // MPC states that carry bounds: alpha,beta,p,q,r,lf2 (parameters.py:59-95,135)
+
+// Weights and bounds of the QP -- the arguments utils.py:21 `setup_OSQP(x_ref, A, B, Q, R, hzn, dt, x, act_states, x_lb, x_ub,
+// u_lb, u_ub, udot_lb, udot_ub)` takes, which env.py:373-424 fills with constants.  By value in the kernel arguments (uniform over
+// the batch); mpc_default_prob = env.py's constants: Q = Cd'Cd per aircraft (env.py:389), R = I (env.py:405-407), the bounds of
+// parameters.py:59-129.  Infinite bounds arrive as +-1e30 (OSQP's own infinity); the rows phi, theta, lf1 carry none.
+struct MpcProb {
+  int custom_q, custom_r;   // 0: Q = Cd'Cd formed per aircraft / R = I (the default path, bit for bit what it always was)
+  double Q[81], R[9], Rinv[9];
+  double slb[6], sub[6];    // kept state rows (SROW order)
+  double ulb[3], uub[3], rlb[3], rub[3];
+};
+inline void mpc_default_prob(MpcProb *p) {
+  *p = MpcProb{};
+  const double slb[6] = {-20., -30., -300., -100., -50., 0.}, sub[6] = {90., 30., 300., 100., 50., 25.};
+  const double ulb[3] = {-25., -21.5, -30.}, uub[3] = {25., 21.5, 30.}, rlb[3] = {-60., -80., -120.}, rub[3] = {60., 80., 120.};
+  for (int i = 0; i < 6; ++i) { p->slb[i] = slb[i]; p->sub[i] = sub[i]; }
+  for (int i = 0; i < 3; ++i) { p->ulb[i] = ulb[i]; p->uub[i] = uub[i]; p->rlb[i] = rlb[i]; p->rub[i] = rub[i]; p->R[4 * i] = 1.0; p->Rinv[4 * i] = 1.0; }
+}
+int mpc_fill_prob(MpcProb *p, const f16_mpc_weights *w);      // host: validation + OSQP's infinity; F16_OK / F16_EINVAL
 
 struct MpcArgs {
   const double *Ad, *Bd, *Cd, *x, *dem;
+  const double *xref;         // [9][ld] reference of the tracking cost (utils.py:21 `x_ref`), or null: x with x[5:8] = dem (env.py:380-383)
+  MpcProb pb;
   double *ucmd, *useq, *info;
   int32_t *status;
   double *Ppk;                // workspace [B][np] packed P (A'A is never stored: the solvers form the weighted Gram themselves)

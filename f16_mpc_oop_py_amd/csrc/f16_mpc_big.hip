@@ -649,16 +649,16 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
       if (row < ms) {
         const int i = row / 6, rr = row - 6 * i;
         const double pm = pred[i * 9 + SROW[rr]];
-        lo[t] = SLB[rr] - pm; hi[t] = SUB[rr] - pm;
+        lo[t] = a.pb.slb[rr] - pm; hi[t] = a.pb.sub[rr] - pm;
       } else if (row < ms + n) {
         const int c = (row - ms) % 3;
-        lo[t] = ULB[c]; hi[t] = UUB[c];
+        lo[t] = a.pb.ulb[c]; hi[t] = a.pb.uub[c];
       } else if (row < m) {
         const int k = row - ms - n, c = k % 3;
         if (k < 3) {
           const double act = a.x[(13 + c) * a.ld + b];
-          lo[t] = act + RLB[c] * a.dt; hi[t] = act + RUB[c] * a.dt;
-        } else { lo[t] = RLB[c]; hi[t] = RUB[c]; }          // reference quirk: not multiplied by dt (utils.py:151-152)
+          lo[t] = act + a.pb.rlb[c] * a.dt; hi[t] = act + a.pb.rub[c] * a.dt;
+        } else { lo[t] = a.pb.rlb[c]; hi[t] = a.pb.rub[c]; }          // reference quirk: not multiplied by dt (utils.py:151-152)
       }
     }
     // ---------------- equilibration (scaling.c:scale_data on the original entries and the running D, E, c)

@@ -1200,14 +1200,14 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
   double lo = 0.0, hi = 0.0;
   if (kind == 1) {
     const double pm = pred[blk * 9 + SROW[sub]];
-    lo = SLB[sub] - pm; hi = SUB[sub] - pm;
+    lo = a.pb.slb[sub] - pm; hi = a.pb.sub[sub] - pm;
   } else if (kind == 2) {
-    lo = ULB[sub]; hi = UUB[sub];
+    lo = a.pb.ulb[sub]; hi = a.pb.uub[sub];
   } else if (kind == 3) {
     if (blk == 0) {
       const double act = a.x ? a.x[(13 + sub) * a.ld + b] : 0.0;      // (no state when a plan is prepared)
-      lo = act + RLB[sub] * a.dt; hi = act + RUB[sub] * a.dt;
-    } else { lo = RLB[sub]; hi = RUB[sub]; }               // reference quirk: not scaled by dt (utils.py:151-152)
+      lo = act + a.pb.rlb[sub] * a.dt; hi = act + a.pb.rub[sub] * a.dt;
+    } else { lo = a.pb.rlb[sub]; hi = a.pb.rub[sub]; }               // reference quirk: not scaled by dt (utils.py:151-152)
   }
   // rho vector (osqp auxil.c:set_rho_vec): an equality row (E (u - l) < 1e-4, i.e. after scaling) carries 1e3 rho
   const double eqf = (kind && Eo * (hi - lo) < OSQP_RHO_TOL) ? OSQP_RHO_EQ_OVER_RHO_INEQ : 1.0;

@@ -1308,7 +1308,7 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
       const int kk = 3 * R.h + c;
       const double Eo = R.act ? rz.EA[c] : 0.0;
       const double pm = R.act ? pred[R.istep * 9 + SROW[kk]] : 0.0;
-      const double lo = R.act ? SLB[kk] - pm : 0.0, hi = R.act ? SUB[kk] - pm : 0.0;
+      const double lo = R.act ? a.pb.slb[kk] - pm : 0.0, hi = R.act ? a.pb.sub[kk] - pm : 0.0;
       const bool eq = R.act && Eo * (hi - lo) < OSQP_RHO_TOL;
       C.loA[c] = lo; C.hiA[c] = hi; C.WA[c] = Eo * Eo; C.eqA |= eq ? (1 << c) : 0;
       if (R.act) s_w[WG_OFF + 6 * R.istep + kk] = Eo * Eo * (eq ? OSQP_RHO_EQ_OVER_RHO_INEQ : 1.0);
@@ -1316,11 +1316,11 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
     {   // command row (par = 0, utils.py:139-140) or rate row (par = 1, utils.py:148-152) of variable k
       const double Eo = R.act ? rz.EB[c] : 0.0;
       double lo, hi;
-      if (R.par == 0) { lo = ULB[c]; hi = UUB[c]; }
+      if (R.par == 0) { lo = a.pb.ulb[c]; hi = a.pb.uub[c]; }
       else if (R.istep == 0) {
         const double act = a.x ? a.x[(13 + c) * a.ld + b] : 0.0;
-        lo = act + RLB[c] * a.dt; hi = act + RUB[c] * a.dt;
-      } else { lo = RLB[c]; hi = RUB[c]; }                 // reference quirk: not scaled by dt (utils.py:151-152)
+        lo = act + a.pb.rlb[c] * a.dt; hi = act + a.pb.rub[c] * a.dt;
+      } else { lo = a.pb.rlb[c]; hi = a.pb.rub[c]; }                 // reference quirk: not scaled by dt (utils.py:151-152)
       if (!R.act) { lo = 0.0; hi = 0.0; }
       const bool eq = R.act && Eo * (hi - lo) < OSQP_RHO_TOL;
       C.loB[c] = lo; C.hiB[c] = hi; C.WB[c] = Eo * Eo; C.eqB |= eq ? (1 << c) : 0;

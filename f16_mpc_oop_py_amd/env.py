@@ -306,13 +306,15 @@ class F16Batch:
         self.ssr = (Ad, Bd, self._lin[2])
         return self.ssr
 
-    def _calc_LQR_gain(self):
-        """env.py:344-358: linearise -> ZOH -> K = -dlqr(Ad,Bd,Cd'Cd,I).  Returns K [B,3,9]."""
+    def _calc_LQR_gain(self, Q=None, R=None):
+        """env.py:344-358: linearise -> ZOH -> K = -dlqr(Ad,Bd,Cd'Cd,I).  Returns K [B,3,9].
+        Q [9,9] / R [3,3]: the weights utils.py:219 `dlqr(A, B, Q, R)` takes (default: env.py's Q = Cd'Cd, R = I)."""
         Ad, Bd, Cd = self.build_ssr()
         K = torch.empty((27, self.B), dtype=torch.float64, device=self.device)
         st = torch.zeros(self.B, dtype=torch.int32, device=self.device)
-        self._check(self.lib.f16_lqr_batch(self.ctx.handle, _vp(Ad), _vp(Bd), _vp(Cd), _vp(K), None, _vp(st), self.B,
-                                           self.B, self._stream))
+        w = _lib.make_weights(Q=Q, R=R)
+        self._check(self.lib.f16_lqr_batch_w(self.ctx.handle, _vp(Ad), _vp(Bd), _vp(Cd), ctypes.byref(w) if w else None, _vp(K), None,
+                                             _vp(st), self.B, self.B, self._stream))
         self.last_status = st
         return K.t().reshape(self.B, 3, 9)
 
@@ -350,7 +352,7 @@ class F16Batch:
         return traj
 
     # ------------------------------------------------------------------ env.py:373-424
-    def prepare_MPC(self, hzn, settings=None, warm_start=False):
+    def prepare_MPC(self, hzn, settings=None, warm_start=False, weights=None):
         """Prepare the model-only part of calc_MPC_action for horizon hzn from the frozen reduced model self.ssr
         (env.py:49-60 freezes it; the reference still rebuilds the QP on every call): DARE, terminal weight, prediction
         blocks, P, A'A, start rho and the KKT factorisation stay on the device.  `_calc_MPC_action(..., use_plan=True)`
@@ -364,8 +366,10 @@ class F16Batch:
         for k, v in (settings or {}).items():
             setattr(s, k, v)
         h = ctypes.c_void_p()
-        self._check(self.lib.f16_mpc_plan_create(self.ctx.handle, ctypes.byref(h), _vp(Ad), _vp(Bd), _vp(Cd), self.B, self.B,
-                                                 int(hzn), self.dt, ctypes.byref(s), self._stream))
+        w = _lib.make_weights(**weights) if weights else None           # (utils.py:21 Q, R and the six bound vectors; fixed for the plan)
+        self._check(self.lib.f16_mpc_plan_create_w(self.ctx.handle, ctypes.byref(h), _vp(Ad), _vp(Bd), _vp(Cd),
+                                                   ctypes.byref(w) if w else None, self.B, self.B, int(hzn), self.dt, ctypes.byref(s),
+                                                   self._stream))
         self._plan, self._plan_hzn = h, int(hzn)
         if warm_start:      # OSQP's in-object default; the reference starts cold on every call (new object), so: opt-in
             self._check(self.lib.f16_mpc_plan_warm_start(h, 1))
@@ -390,11 +394,14 @@ class F16Batch:
                 "builder_rule": dict(scaling=0, rho=0.0),                     # no equilibration, rho0 = 2 sqrt(tr P / tr A'A)
                 "rho_0p1_unscaled": dict(scaling=0, rho=0.1)}
 
-    def setup_OSQP(self, p_dem, q_dem, r_dem, hzn, b=0):
+    def setup_OSQP(self, p_dem, q_dem, r_dem, hzn, b=0, weights=None, x_ref=None):
         """The QP of aircraft b in the reference's own form (utils.py:21-167 `setup_OSQP`): dense host arrays
         (P [n,n], q [n], A [15 hzn, n], l, u) with n = 3 hzn and the reference's row order (9 hzn state rows, 3 hzn
         command rows, 3 hzn rate rows; unbounded rows carry +-inf), built on the device from the frozen reduced
-        model and the current state -- for callers that hand the QP to a solver of their own, and for the tests."""
+        model and the current state -- for callers that hand the QP to a solver of their own, and for the tests.
+        weights: dict(Q=, R=, x_lb=, x_ub=, u_lb=, u_ub=, udot_lb=, udot_ub=) -- the arguments of utils.py:21 that env.py fills
+        with constants (any subset; any bound pattern); x_ref [B,9] (or [9]): the reference itself instead of "x with
+        x[5:8] = demands" (env.py:380-383)."""
         if self.ssr is None:
             self.build_ssr()
         Ad, Bd, Cd = self.ssr
@@ -405,15 +412,20 @@ class F16Batch:
         P, q, A = np.zeros((n, n)), np.zeros(n), np.zeros((rows, n))
         l, u = np.zeros(rows), np.zeros(rows)
         hp = lambda a: ctypes.c_void_p(a.ctypes.data)
-        self._check(self.lib.f16_mpc_qp_debug(self.ctx.handle, _vp(Ad), _vp(Bd), _vp(Cd), _vp(self._x), _vp(dem), int(b), self.B,
-                                              int(hzn), self.dt, hp(P), hp(q), hp(A), hp(l), hp(u)))
+        w = _lib.make_weights(**weights) if weights else None
+        xr = self._soa(x_ref, 9) if x_ref is not None else None
+        self._check(self.lib.f16_mpc_qp_debug_w(self.ctx.handle, _vp(Ad), _vp(Bd), _vp(Cd), _vp(self._x), _vp(dem), _vp(xr),
+                                                ctypes.byref(w) if w else None, int(b), self.B, int(hzn), self.dt, hp(P), hp(q), hp(A),
+                                                hp(l), hp(u)))
         return P, q, A, l, u
 
     def _calc_MPC_action(self, p_dem, q_dem, r_dem, hzn, settings=None, return_info=False, relinearise=False,
-                         use_plan=False):
+                         use_plan=False, weights=None, x_ref=None):
         """First MPC move [B,3] (dh,da,dr commands) for demands p,q,r (scalars or [B]) over horizon hzn, from the
         frozen reduced model self.ssr (env.py:385-387) and the current state.  The QP of utils.py:21-167 is solved
-        on the GPU by OSQP-style ADMM (the reference calls the `osqp` package, env.py:420-422)."""
+        on the GPU by OSQP-style ADMM (the reference calls the `osqp` package, env.py:420-422).
+        weights / x_ref: as in setup_OSQP (the solvers keep the reference's pattern of bounded rows; a plan fixes its weights at
+        prepare_MPC, x_ref is per call)."""
         # relinearise=True: SURVEY.md 8f-2 -- the reduced model is re-derived at the CURRENT state on every call (the
         # reference freezes it at construction, env.py:49-60; its test_env.py:625-687 loops re-linearise per step)
         if self.ssr is None or relinearise:
@@ -433,13 +445,14 @@ class F16Batch:
         useq = torch.empty((3 * hzn, self.B), dtype=torch.float64, device=self.device) if return_info else None
         st = torch.zeros(self.B, dtype=torch.int32, device=self.device)
         if use_plan:
-            if relinearise or settings:
-                raise ValueError("a prepared plan fixes the model and the QP settings (prepare_MPC)")
+            if relinearise or settings or weights:
+                raise ValueError("a prepared plan fixes the model, the QP settings and the weights (prepare_MPC)")
             if getattr(self, "_plan", None) is None or self._plan_hzn != int(hzn):
                 self.prepare_MPC(hzn)
-            self._check(self.lib.f16_mpc_plan_solve(self._plan, _vp(self._x), _vp(dem), _vp(ucmd), _vp(useq), _vp(info), _vp(st),
-                                                    self._stream))
-            self.last_status = st
+            xr = self._soa(x_ref, 9) if x_ref is not None else None
+            self._check(self.lib.f16_mpc_plan_solve_w(self._plan, _vp(self._x), _vp(dem), _vp(xr), _vp(ucmd), _vp(useq), _vp(info),
+                                                      _vp(st), self._stream))
+            self.last_status, self.last_iters = st, info[0]
             if return_info:
                 return ucmd.t(), dict(iters=info[0], r_prim=info[1], r_dual=info[2], rho=info[3], u_seq=useq.t(), status=st)
             return ucmd.t()
@@ -447,10 +460,12 @@ class F16Batch:
         self.lib.f16_qp_default_settings(ctypes.byref(s))
         for k, v in (settings or {}).items():
             setattr(s, k, v)
-        self._check(self.lib.f16_mpc_batch(self.ctx.handle, _vp(Ad), _vp(Bd), _vp(Cd), _vp(self._x), _vp(dem), _vp(ucmd),
-                                           _vp(useq), _vp(info), _vp(st), self.B, self.B, int(hzn), self.dt,
-                                           ctypes.byref(s), self._stream))
-        self.last_status = st
+        w = _lib.make_weights(**weights) if weights else None
+        xr = self._soa(x_ref, 9) if x_ref is not None else None
+        self._check(self.lib.f16_mpc_batch_w(self.ctx.handle, _vp(Ad), _vp(Bd), _vp(Cd), _vp(self._x), _vp(dem), _vp(xr),
+                                             ctypes.byref(w) if w else None, _vp(ucmd), _vp(useq), _vp(info), _vp(st), self.B, self.B,
+                                             int(hzn), self.dt, ctypes.byref(s), self._stream))
+        self.last_status, self.last_iters = st, info[0]
         if return_info:
             return ucmd.t(), dict(iters=info[0], r_prim=info[1], r_dual=info[2], rho=info[3], u_seq=useq.t(), status=st)
         return ucmd.t()

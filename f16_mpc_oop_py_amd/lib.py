@@ -43,6 +43,32 @@ class QPSettings(ctypes.Structure):
                 ("scaling", ctypes.c_int)]
 
 
+class MPCWeights(ctypes.Structure):
+    """include/f16_hip.h `f16_mpc_weights`: the arguments of utils.py:21 setup_OSQP / utils.py:219 dlqr that env.py fills with
+    constants."""
+    _fields_ = [("q_from_cd", ctypes.c_int), ("Q", ctypes.c_double * 81), ("R", ctypes.c_double * 9),
+                ("x_lb", ctypes.c_double * 9), ("x_ub", ctypes.c_double * 9), ("u_lb", ctypes.c_double * 3), ("u_ub", ctypes.c_double * 3),
+                ("udot_lb", ctypes.c_double * 3), ("udot_ub", ctypes.c_double * 3)]
+
+
+def make_weights(Q=None, R=None, x_lb=None, x_ub=None, u_lb=None, u_ub=None, udot_lb=None, udot_ub=None):
+    """MPCWeights from env.py's constants with the given entries replaced (None = all defaults -> None: the plain entry points)."""
+    if all(v is None for v in (Q, R, x_lb, x_ub, u_lb, u_ub, udot_lb, udot_ub)):
+        return None
+    import numpy as np
+    w = MPCWeights()
+    load().f16_mpc_default_weights(ctypes.byref(w))
+    if Q is not None:
+        w.q_from_cd = 0
+        w.Q[:] = list(np.asarray(Q, dtype=np.float64).reshape(81))
+    if R is not None:
+        w.R[:] = list(np.asarray(R, dtype=np.float64).reshape(9))
+    for name, v, n in (("x_lb", x_lb, 9), ("x_ub", x_ub, 9), ("u_lb", u_lb, 3), ("u_ub", u_ub, 3), ("udot_lb", udot_lb, 3), ("udot_ub", udot_ub, 3)):
+        if v is not None:
+            getattr(w, name)[:] = list(np.asarray(v, dtype=np.float64).reshape(n))
+    return w
+
+
 def _fingerprint():
     """Hash of everything the binary depends on: every source / header under csrc/, the public header, the compiler
     flags (F16_STRICT, F16_HIPCC_EXTRA included).  Stored beside the .so at build time; load() refuses a stale binary."""
@@ -211,6 +237,14 @@ def load():
         L.f16_debug_spd_inverse.argtypes = [vp, vp, vp, i, l, vp]
         L.f16_mpc_plan_create.argtypes = [vp, ctypes.POINTER(vp), vp, vp, vp, l, l, i, d, ctypes.POINTER(QPSettings), vp]
         L.f16_mpc_plan_solve.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+        wp = ctypes.POINTER(MPCWeights)
+        L.f16_mpc_default_weights.argtypes = [wp]
+        L.f16_mpc_default_weights.restype = None
+        L.f16_lqr_batch_w.argtypes = [vp, vp, vp, vp, wp, vp, vp, vp, l, l, vp]
+        L.f16_mpc_batch_w.argtypes = [vp, vp, vp, vp, vp, vp, vp, wp, vp, vp, vp, vp, l, l, i, d, ctypes.POINTER(QPSettings), vp]
+        L.f16_mpc_plan_create_w.argtypes = [vp, ctypes.POINTER(vp), vp, vp, vp, wp, l, l, i, d, ctypes.POINTER(QPSettings), vp]
+        L.f16_mpc_plan_solve_w.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.f16_mpc_qp_debug_w.argtypes = [vp, vp, vp, vp, vp, vp, vp, wp, l, l, i, d, vp, vp, vp, vp, vp]
         L.f16_mpc_plan_warm_start.argtypes = [vp, i]
         L.f16_mpc_plan_destroy.argtypes = [vp]
         L.f16_mpc_plan_destroy.restype = None

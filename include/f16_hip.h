@@ -168,6 +168,28 @@ int f16_lqr_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double
  * f16_mpc_plan_solve instead, whose workspace lives with the plan.
  * Scheduling only: workgroups are dispatched longest-first by the iteration counts of the previous call of the same
  * batch size on the same stream (results do not depend on it; F16_MPC_DISPATCH_ORDER=0 keeps the caller's order). */
+/* Weights, reference and bounds of the QP as ARGUMENTS -- what utils.py:21 `setup_OSQP(x_ref, A, B, Q, R, hzn, dt, x, act_states,
+ * x_lb, x_ub, u_lb, u_ub, udot_lb, udot_ub)` and utils.py:219 `dlqr(A, B, Q, R)` take; env.py:373-424 fills them with
+ * constants (Q = Cd'Cd, R = I, x_ref = x with x_ref[5:8] = demands, the boxes of parameters.py:59-129), and the entry points without
+ * the `_w` suffix do the same.  The `_w` entry points take a HOST pointer h_w to this struct (NULL = env.py's constants, bit for
+ * bit the plain entry point) and, where a reference enters, a DEVICE pointer x_ref[9][ld] (NULL = env.py:380-383 from `dem`; with
+ * x_ref given `dem` may be NULL).  Weights and bounds are uniform over the batch; x_ref is per aircraft.  MPC-state order:
+ * phi, theta, alpha, beta, p, q, r, lf1, lf2 (parameters.py:135); +-INFINITY = no bound.
+ * Solvers: the six state rows the reference bounds (alpha, beta, p, q, r, lf2) stay the bounded ones -- their VALUES are free
+ * (one side may be infinite), but a finite bound on phi / theta / lf1 or no bound at all on one of the six is F16_EINVAL;
+ * f16_mpc_qp_debug_w (the QP alone, dense, in the reference's form) takes any pattern. */
+typedef struct f16_mpc_weights {
+  int q_from_cd;                 /* 1: Q = Cd'Cd per aircraft (env.py:389) and Q[] is ignored */
+  double Q[81];                  /* 9 x 9 row-major, symmetric positive semidefinite (the author's own alternative: env.py:391-401) */
+  double R[9];                   /* 3 x 3 row-major, symmetric positive definite (env.py:403-407) */
+  double x_lb[9], x_ub[9];       /* parameters.py _vec_mpc_x_lb / _ub */
+  double u_lb[3], u_ub[3];       /* _vec_mpc_u_lb / _ub */
+  double udot_lb[3], udot_ub[3]; /* _vec_mpc_udot_lb / _ub */
+} f16_mpc_weights;
+void f16_mpc_default_weights(f16_mpc_weights *w);      /* env.py's constants */
+int f16_lqr_batch_w(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const f16_mpc_weights *h_w, double *K,
+                    double *Pare, int32_t *status, long B, long ld, void *stream);        /* utils.py:219: Q, R of h_w */
+
 typedef struct f16_qp_settings {
   double rho, sigma, alpha, eps_abs, eps_rel, eps_prim_inf;
   int max_iter, check_every, rho_every, adaptive_rho;
@@ -177,6 +199,9 @@ void f16_qp_default_settings(f16_qp_settings *s);
 int f16_mpc_batch(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
                   const double *dem, double *u_cmd, double *u_seq, double *info, int32_t *status,
                   long B, long ld, int hzn, double dt, const f16_qp_settings *s, void *stream);
+int f16_mpc_batch_w(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x, const double *dem,
+                    const double *x_ref, const f16_mpc_weights *h_w, double *u_cmd, double *u_seq, double *info, int32_t *status,
+                    long B, long ld, int hzn, double dt, const f16_qp_settings *s, void *stream);
 /* env.py:426-436 `_calc_constr_checking_hzn`: the first move of calc_MPC_action for the SAME states, demands and model at
  * every horizon hzn_lo..hzn_hi (1 <= hzn_lo <= hzn_hi <= 150) as one call.  u_cmd [hzn_hi - hzn_lo + 1][3][ld], info (may be
  * NULL) [..][4][ld], status (may be NULL, OR-ed into) [..][ld]; slice k = hzn - hzn_lo holds exactly what f16_mpc_batch returns
@@ -202,18 +227,26 @@ int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const double *Ad, con
                         long B, long ld, int hzn, double dt, const f16_qp_settings *s, void *stream);
 int f16_mpc_plan_solve(f16_mpc_plan *plan, const double *x, const double *dem, double *u_cmd, double *u_seq,
                        double *info, int32_t *status, void *stream);
+int f16_mpc_plan_create_w(f16_ctx *ctx, f16_mpc_plan **plan, const double *Ad, const double *Bd, const double *Cd,
+                          const f16_mpc_weights *h_w, long B, long ld, int hzn, double dt, const f16_qp_settings *s, void *stream);
+int f16_mpc_plan_solve_w(f16_mpc_plan *plan, const double *x, const double *dem, const double *x_ref, double *u_cmd,
+                         double *u_seq, double *info, int32_t *status, void *stream);
 /* Optional: start each solve of the plan from the previous solve's x, z, y (what OSQP does by default inside ONE
  * solver object; the reference builds a new object per call, i.e. always starts cold -- so this is off by default and
  * results then differ from the cold start within the termination tolerance).  Switching it on or off forgets the
  * stored solution; a solve that did not converge is not reused. */
 int f16_mpc_plan_warm_start(f16_mpc_plan *plan, int on);
-void f16_mpc_plan_destroy(f16_mpc_plan *plan);
+void f16_mpc_plan_destroy(f16_mpc_plan *plan);      /* waits for the plan's own stream only */
 
 /* utils.py:21-167 setup_OSQP alone for aircraft b (tests): h_P[n*n] h_q[n] h_A[(m rows)*n] h_l h_u on the
  * host, n = 3*hzn, rows = 15*hzn, reference row order. */
 int f16_mpc_qp_debug(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x,
                      const double *dem, long b, long ld, int hzn, double dt,
                      double *h_P, double *h_q, double *h_A, double *h_l, double *h_u);
+
+int f16_mpc_qp_debug_w(f16_ctx *ctx, const double *Ad, const double *Bd, const double *Cd, const double *x, const double *dem,
+                       const double *x_ref, const f16_mpc_weights *h_w, long b, long ld, int hzn, double dt,
+                       double *h_P, double *h_q, double *h_A, double *h_l, double *h_u);
 
 /* Tests: inverse of B packed (lower triangle, row-major) SPD n x n matrices, n <= 96, on the device through the
  * KKT-inverse routine of the MPC solver (blocked sweep on the fp64 matrix cores, v_mfma_f64_16x16x4_f64).

@@ -664,6 +664,92 @@ def test_plan_solves_replay_from_a_hip_graph_and_one_shot_calls_refuse_capture()
     assert torch.equal(env._calc_MPC_action(0, 0, 0, 30), u_eager)       # the context is still usable afterwards
 
 
+def _g8b_env(g, xcg, B=4):
+    x = np.tile(g[f"x_full_xcg{xcg}"], (B, 1))
+    env = make_env(x, xcg=xcg / 100)
+    env.ssr = tuple(soa(np.tile(g[f"{k}_xcg{xcg}"], (B, 1, 1))) for k in ("Ad", "Bd", "Cd"))
+    return env
+
+
+def _g8b_weights(g, tag):
+    return dict(Q=g[f"Q{tag}"], R=g[f"R{tag}"], x_lb=g[f"xlb_{tag}"], x_ub=g[f"xub_{tag}"], u_lb=g[f"ulb_{tag}"], u_ub=g[f"uub_{tag}"],
+                udot_lb=g[f"rlb_{tag}"], udot_ub=g[f"rub_{tag}"])
+
+
+@pytest.mark.parametrize("xcg", [25, 35])
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g8b_qp_build_with_weights_reference_and_bounds_as_arguments(xcg, tag):
+    """utils.py:21 `setup_OSQP(x_ref, A, B, Q, R, hzn, dt, x, act_states, x_lb, ...)` takes weights, reference and bounds as
+    ARGUMENTS; env.py fills them with constants, and so did this library until round 4.  G8b = the reference's setup_OSQP run by
+    tools/make_golden.py --g12 with (a) the weights its author left commented out at env.py:391-403 and R = 0.01 I, (b) dense SPD
+    Q / R, a free reference and other boxes.  The device build (f16_mpc_qp_debug_w through F16Batch.setup_OSQP) reproduces P, q,
+    A, l, u; with no arguments it is bit for bit the plain entry point; utils.py:219 dlqr with the same weights too."""
+    g = golden("g8b_mpc_qp_weights.npz")
+    env = _g8b_env(g, xcg)
+    w = _g8b_weights(g, tag)
+    xref = np.tile(g[f"xref_{tag}_xcg{xcg}"], (env.B, 1))
+    for N in (4, 10, 30):
+        P, q, A, l, u = env.setup_OSQP(0.0, 0.0, 0.0, N, b=2, weights=w, x_ref=xref)
+        t = f"{tag}_xcg{xcg}_N{N}"
+        assert np.abs(P - g[f"P_{t}"]).max() / np.abs(g[f"P_{t}"]).max() < 1e-9
+        assert np.abs(q - g[f"q_{t}"]).max() / np.abs(g[f"q_{t}"]).max() < 1e-7
+        for got, ref in ((l, g[f"l_{t}"]), (u, g[f"u_{t}"])):
+            fin = np.isfinite(ref)
+            assert np.array_equal(np.isfinite(got), fin)
+            np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-12, atol=1e-12)
+        if N < 30:
+            np.testing.assert_allclose(A, g[f"A_{t}"], rtol=1e-12, atol=1e-18)
+    # defaults through the new entry point == the plain one, bit for bit
+    for got, ref in zip(env.setup_OSQP(0.1, -0.05, 0.02, 10, b=1, weights=dict(R=np.eye(3))), env.setup_OSQP(0.1, -0.05, 0.02, 10, b=1)):
+        assert np.array_equal(got, ref)
+    Kt = torch.empty((27, env.B), dtype=torch.float64, device=env.device)
+    st = torch.zeros(env.B, dtype=torch.int32, device=env.device)
+    from f16_mpc_oop_py_amd import lib as L
+    from f16_mpc_oop_py_amd.env import _vp
+    ww = L.make_weights(Q=w["Q"], R=w["R"])
+    Ad, Bd, Cd = env.ssr
+    L.check(env.lib.f16_lqr_batch_w(env.ctx.handle, _vp(Ad), _vp(Bd), _vp(Cd), ctypes.byref(ww), _vp(Kt), None, _vp(st), env.B, env.B,
+                                    env._stream))
+    Kd = -Kt.t().reshape(env.B, 3, 9)[0].cpu().numpy()       # the library returns K = -dlqr (env.py:356)
+    np.testing.assert_allclose(Kd, g[f"K_{tag}_xcg{xcg}"], rtol=1e-6, atol=1e-10)
+    assert int(st.max()) == 0
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_solves_with_weights_as_arguments_follow_the_cpu_twin_and_reach_the_minimiser(tag):
+    """The solvers with the caller's weights / reference / bound values (the pattern of bounded rows stays the reference's): same
+    QP as the reference builds (G8b), the solve iterate for iterate with the numpy twin of the same rules, the first move inside
+    the solver band of the KKT-verified exact minimiser; one-shot call == prepared plan; N = 10 and 30 (wavefront solver),
+    36 (long-horizon solver); a pattern the solvers do not keep is refused."""
+    from f16_mpc_oop_py_amd import lib as L
+    g = golden("g8b_mpc_qp_weights.npz")
+    xcg = 35
+    env = _g8b_env(g, xcg)
+    w = _g8b_weights(g, tag)
+    xref = np.tile(g[f"xref_{tag}_xcg{xcg}"], (env.B, 1))
+    for N in (10, 30):
+        t = f"{tag}_xcg{xcg}_N{N}"
+        P, q, l, u = (g[f"{k}_{t}"] for k in ("P", "q", "l", "u"))
+        A = g[f"A_{t}"] if N < 30 else env.setup_OSQP(0, 0, 0, N, weights=w, x_ref=xref)[2]
+        uu, info = env._calc_MPC_action(0.0, 0.0, 0.0, N, return_info=True, weights=w, x_ref=xref)
+        ref = mo.admm_osqp(P, q, A, l, u, drop_unbounded_rows=True)
+        assert int(info["status"].max()) == 0 and int(info["iters"][0]) == ref["iters"]
+        assert np.abs(info["u_seq"][0].cpu().numpy() - ref["x"]).max() < 1e-7
+        xs, lam = mo.qp_exact(P, q, A, l, u)
+        assert np.abs(uu[0].cpu().numpy() - xs[:3]).max() < 2e-2
+        env.prepare_MPC(N, weights=w)
+        up = env._calc_MPC_action(0.0, 0.0, 0.0, N, use_plan=True, x_ref=xref)
+        assert torch.equal(up, uu)
+    uu36, info36 = env._calc_MPC_action(0.0, 0.0, 0.0, 36, return_info=True, weights=w, x_ref=xref)
+    P, q, A, l, u = env.setup_OSQP(0, 0, 0, 36, weights=w, x_ref=xref)
+    ref = mo.admm_osqp(P, q, A, l, u, drop_unbounded_rows=True)
+    assert int(info36["iters"][0]) == ref["iters"] and np.abs(info36["u_seq"][0].cpu().numpy() - ref["x"]).max() < 1e-7
+    bad = dict(w, x_lb=np.where(np.arange(9) == 0, -1.0, w["x_lb"]))       # a bound on phi: not a row the solvers carry
+    with pytest.raises(L.F16HipError):
+        env._calc_MPC_action(0.0, 0.0, 0.0, 10, weights=bad)
+    env.setup_OSQP(0.0, 0.0, 0.0, 10, weights=bad)                        # ... the QP alone: any pattern
+
+
 def test_first_solve_of_a_wide_plan_inside_a_capture():
     """Plans accept horizons 33..40 (every solve runs the long-horizon workgroup solver) and plan solves are capturable: the
     kernel's dynamic-LDS opt-in (hipFuncSetAttribute, not legal under capture) must therefore have happened in

@@ -241,6 +241,32 @@ def test_g8_prediction_matrices_and_qp():
 
 
 @pytest.mark.parametrize("xcg", [25, 35])
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g8b_setup_osqp_with_other_weights_reference_and_bounds(xcg, tag):
+    """G8b: the reference's setup_OSQP (utils.py:21-167) run with arguments OTHER than the ones env.py:373-424 hard-wires --
+    (a) the weights its author left commented out at env.py:391-403 with R = 0.01 I; (b) a dense SPD Q / R, a free reference and
+    tightened / widened boxes -- against the restated setup_OSQP / dlqr (oracle.mpc_oracle)."""
+    g = golden("g8b_mpc_qp_weights.npz")
+    Q, R = g[f"Q{tag}"], g[f"R{tag}"]
+    x_full = g[f"x_full_xcg{xcg}"]
+    x9, act = x_full[mo.MPC_X_IDX], x_full[mo.MPC_U_IN_X_IDX]
+    Ad, Bd = g[f"Ad_xcg{xcg}"], g[f"Bd_xcg{xcg}"]
+    bnds = [g[f"{nm}_{tag}"] for nm in ("xlb", "xub", "ulb", "uub", "rlb", "rub")]
+    np.testing.assert_allclose(mo.dlqr(Ad, Bd, Q, R), g[f"K_{tag}_xcg{xcg}"], rtol=1e-8, atol=1e-12)
+    for N in (4, 10, 30):
+        P, q, A, l, u = mo.setup_OSQP(g[f"xref_{tag}_xcg{xcg}"], Ad, Bd, Q, R, N, 0.001, x9, act, *bnds)
+        t = f"{tag}_xcg{xcg}_N{N}"
+        assert np.abs(P - g[f"P_{t}"]).max() / np.abs(g[f"P_{t}"]).max() < 1e-9
+        assert np.abs(q.ravel() - g[f"q_{t}"]).max() / np.abs(g[f"q_{t}"]).max() < 1e-8
+        for got, ref in ((l.ravel(), g[f"l_{t}"]), (u.ravel(), g[f"u_{t}"])):
+            fin = np.isfinite(ref)
+            assert np.array_equal(np.isfinite(got), fin)
+            np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-12, atol=1e-12)
+        if N < 30:
+            np.testing.assert_allclose(A, g[f"A_{t}"], rtol=1e-12, atol=1e-18)
+
+
+@pytest.mark.parametrize("xcg", [25, 35])
 def test_g9_admm_reaches_exact_minimiser_band(xcg):
     """OSQP-style ADMM at OSQP's default tolerances lands within the solver band of the exact
     minimiser (first-block rate rows active at trim, first move ~ act-0.06, act+0.08)."""

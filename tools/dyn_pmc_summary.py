@@ -36,4 +36,18 @@ for k in kern:
         print("%-28s LDS bank-conflict cycles / LDS index-active cycles %.3f | address conflicts / index-active %.3f | fp64 FMA+ADD+MUL wave-instr %.3e = %.1f %% of VALU"
               % ("", g("SQ_LDS_BANK_CONFLICT") / max(g("SQ_LDS_IDX_ACTIVE"), 1), g("SQ_LDS_ADDR_CONFLICT") / max(g("SQ_LDS_IDX_ACTIVE"), 1), fp,
                  100 * fp / max(g("SQ_INSTS_VALU"), 1)))
-print("wrote", out)
+# VALU wave-instructions per launch of the two benchmark kernels -> profiles/issue_valu.json (bench.py: roofline.issue)
+import json
+ip = os.path.join(REPO, "profiles", "issue_valu.json")
+try:
+    rec = json.load(open(ip))
+except Exception:
+    rec = {}
+for key, pat, meta in (("k_rollout_q", "k_rollout_q<1, false>", dict(batch=4096, euler_steps=1000)),
+                       ("k_rollout_i", "k_rollout_i<512, false>", dict(batch=262144, euler_steps=200))):
+    ks = [k for k in kern if pat in k and (k, "SQ_INSTS_VALU") in acc]
+    if ks:
+        a = acc[(ks[0], "SQ_INSTS_VALU")]
+        rec[key] = dict(meta, kernel=ks[0], insts_valu_per_launch=a[0] / a[1], source=f"profiles/{tag}_pmc_dyn.csv")
+json.dump(rec, open(ip, "w"), indent=1)
+print("wrote", out, ip)

@@ -74,3 +74,14 @@ for k in ("k_mpc_wave", "k_mpc_fast", "k_mpc<true> (build)"):
         rec["solve_kernel"] = r
 json.dump(rec, open(os.path.join(REPO, "profiles", "mfma_mpc.json"), "w"), indent=1)
 print(json.dumps(rec, indent=1))
+# VALU wave-instructions per launch of the solver (build kernel added: bench.py times the two together) -> profiles/issue_valu.json
+ip = os.path.join(REPO, "profiles", "issue_valu.json")
+try:
+    iv = json.load(open(ip))
+except Exception:
+    iv = {}
+if "k_mpc_wave" in rec:
+    n = rec["k_mpc_wave"]["valu_instructions_per_launch"] + rec.get("k_mpc<true> (build)", {}).get("valu_instructions_per_launch", 0.0)
+    iv["k_mpc_wave"] = dict(batch=4096, hzn=30, kernel="k_mpc<true> (build) + k_mpc_wave", insts_valu_per_launch=n,
+                            per_aircraft_iteration=None, source=f"profiles/{tag}_pmc_mpc.csv")
+    json.dump(iv, open(ip, "w"), indent=1)

@@ -39,7 +39,7 @@ with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
 def counter(d, name, kern="k_rollout_q"):
     vals, meta = [], None
     for r in csv.DictReader(open(one(d, "*counter_collection.csv"))):
-        if kern in r["Kernel_Name"] and r["Counter_Name"] == name:
+        if kern in r["Kernel_Name"] and ", true>" not in r["Kernel_Name"] and r["Counter_Name"] == name:      # (", true>": the LQR closed-loop instantiation)
             vals.append(float(r["Counter_Value"]))
             meta = r
     return vals, meta
@@ -48,7 +48,7 @@ def counter(d, name, kern="k_rollout_q"):
 fetch, meta = counter(fetch_dir, "FETCH_SIZE")
 kname = meta["Kernel_Name"].replace("void ", "").split("(")[0].replace(",", ";")
 write, _ = counter(write_dir, "WRITE_SIZE")
-kern = [r for r in rows if kname.split("::")[-1].split("<")[0] in r["Name"] and ("4w" in kname) == ("4w" in r["Name"])][0]
+kern = [r for r in rows if kname.split("::")[-1].split("<")[0] in r["Name"] and ("4w" in kname) == ("4w" in r["Name"]) and ", true>" not in r["Name"]][0]
 with open(os.path.join(out, f"{tag}_pmc_k_rollout.csv"), "w") as f:
     f.write("kernel,counter,launches,mean_KiB,min_KiB,max_KiB,VGPR,LDS_bytes,workgroup\n")
     for nm, v in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
