@@ -118,7 +118,7 @@ __device__ __forceinline__ void rollout_lanes(const DynArgs &a, TP T, double (*u
     int until_store = a.traj_every;
     for (int t = 0; t < a.nsteps; ++t) {
       // env.py:117-124: the reference exit()s; here the aircraft is frozen and flagged
-      if (!(a.flags & FLAG_NO_ENVELOPE) && outside_envelope(x)) st |= ST_ENVELOPE;
+      if (!(a.flags & FLAG_NO_ENVELOPE) && !(st & ST_ENVELOPE) && outside_envelope(x)) st |= ST_ENVELOPE | envelope_state_bits(x);
       if (!(st & ST_ENVELOPE)) {
         double xd[18], u[4];
 #pragma unroll
@@ -264,12 +264,13 @@ __global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
         tr += 18 * a.ld;
       }
       if (last) break;
-      if (xenv[0][lane] | xenv[1][lane] | xenv[2][lane]) st |= ST_ENVELOPE;
-      const bool live = !(st & ST_ENVELOPE);
+      const bool newly_out = (xenv[0][lane] | xenv[1][lane] | xenv[2][lane]) && !(st & ST_ENVELOPE);
       // every wave sees the full published state (its own part is identical to its registers)
       double xa[17];
 #pragma unroll
       for (int k = 0; k < 17; ++k) xa[k] = xs[k][lane];
+      if (newly_out) st |= ST_ENVELOPE | envelope_state_bits(xa);      // (which states: once, from the published copy)
+      const bool live = !(st & ST_ENVELOPE);
       Pre p;
       double xd[18], o[3];
       int sa = 0;
@@ -464,11 +465,12 @@ __global__ __launch_bounds__(256 * GROUPS) void k_rollout_q(DynArgs a) {
         tr += 18 * a.ld;
       }
       if (t == a.nsteps) break;
-      if (xenv[0][ac] | xenv[1][ac] | xenv[2][ac]) st |= ST_ENVELOPE;
-      const bool live = !(st & ST_ENVELOPE);
+      const bool newly_out = (xenv[0][ac] | xenv[1][ac] | xenv[2][ac]) && !(st & ST_ENVELOPE);
       double xa[17];
 #pragma unroll
       for (int k = 0; k < 17; ++k) xa[k] = xs[k][ac];
+      if (newly_out) st |= ST_ENVELOPE | envelope_state_bits(xa);      // (which states: once, from the published copy)
+      const bool live = !(st & ST_ENVELOPE);
       // first-half results wave 2 keeps in registers for the second half
       double xd[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       double U = 0, V = 0, W = 0, s_t = 0, c_t = 0, s_phi = 0, c_phi = 0, cb = 0, vtc = 0, r1 = 0, r2 = 0, r3 = 0;

@@ -824,6 +824,24 @@ F16_DEV void calc_xdot_na(TP T, const double *__restrict__ LT, const double *sv,
 }
 
 // env.py:117-124 box check (parameters.py:122-123, mixed units as in the reference)
+// Which states are outside their box (env.py:117-124 tests all eighteen; six of them carry no finite limit): bit 8 + k for state
+// k -- evaluated only once an aircraft has been found outside (outside_envelope), not in the per-step path
+F16_DEV int envelope_state_bits(const double *x) {
+  int m = 0;
+  m |= (x[2] < 0 || x[2] > 100000) ? 1 << (8 + 2) : 0;
+  m |= (x[6] < 0 || x[6] > 900) ? 1 << (8 + 6) : 0;
+  m |= (x[7] < -20. || x[7] > 90) ? 1 << (8 + 7) : 0;
+  m |= (x[8] < -30. || x[8] > 30) ? 1 << (8 + 8) : 0;
+  m |= (x[9] < -300 || x[9] > 300) ? 1 << (8 + 9) : 0;
+  m |= (x[10] < -100 || x[10] > 100) ? 1 << (8 + 10) : 0;
+  m |= (x[11] < -50 || x[11] > 50) ? 1 << (8 + 11) : 0;
+  m |= (x[12] < 1000 || x[12] > 19000) ? 1 << (8 + 12) : 0;
+  m |= (x[13] < -25 || x[13] > 25) ? 1 << (8 + 13) : 0;
+  m |= (x[14] < -21.5 || x[14] > 21.5) ? 1 << (8 + 14) : 0;
+  m |= (x[15] < -30. || x[15] > 30) ? 1 << (8 + 15) : 0;
+  m |= (x[16] < 0. || x[16] > 25) ? 1 << (8 + 16) : 0;
+  return m;
+}
 F16_DEV bool outside_envelope(const double *x) {
   bool bad = x[2] < 0 || x[2] > 100000 || x[6] < 0 || x[6] > 900 || x[7] < -20. || x[7] > 90 || x[8] < -30. || x[8] > 30 ||
              x[9] < -300 || x[9] > 300 || x[10] < -100 || x[10] > 100 || x[11] < -50 || x[11] > 50 || x[12] < 1000 ||

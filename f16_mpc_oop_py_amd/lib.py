@@ -27,6 +27,7 @@ else:
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result"] + _NUMERICS
 
 F16_ST = dict(ALPHA1=1, ALPHA2=2, BETA=4, EL=8, ENVELOPE=16, NONFINITE=32, QP_MAXITER=64, QP_INFEASIBLE=128)
+F16_ST_ENV_STATE = lambda k: 1 << (8 + k)      # with ENVELOPE: state k was outside its box (env.py:117-124)
 F16_FLAG_FIX_CLR = 1
 F16_FLAG_NO_ENVELOPE = 2
 

@@ -44,6 +44,8 @@ typedef struct f16_ctx f16_ctx;
 #define F16_ST_BETA 4       /* |beta| > 30 deg: clamped                                       */
 #define F16_ST_EL 8         /* |el| > 25 deg: clamped                                         */
 #define F16_ST_ENVELOPE 16  /* env.py:117-124 box check failed: aircraft frozen from then on  */
+#define F16_ST_ENV_STATE(k) (1 << (8 + (k))) /* ... and WHICH of the 18 states were outside their box at that step (set with
+                                                F16_ST_ENVELOPE; the reference prints the offending state before it exits)       */
 #define F16_ST_NONFINITE 32 /* a state became NaN/Inf                                         */
 #define F16_ST_QP_MAXITER 64 /* ADMM hit max_iter before meeting the OSQP termination test    */
 #define F16_ST_QP_INFEASIBLE 128 /* OSQP primal-infeasibility certificate met: command = NaN  */

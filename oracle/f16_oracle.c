@@ -470,8 +470,10 @@ static const double X_UB[18] = {INFINITY, INFINITY, 100000, INFINITY, INFINITY, 
                                 19000, 25, 21.5, 30, 25, INFINITY};
 
 int f16o_step(double *x, const double *u, double dt, int fi_flag, double xcg) { /* env.py:105-130 */
+  int out = 0;
   for (int i = 0; i < 18; ++i)
-    if (x[i] < X_LB[i] || x[i] > X_UB[i]) return F16O_ST_ENVELOPE;
+    if (x[i] < X_LB[i] || x[i] > X_UB[i]) out |= F16O_ST_ENVELOPE | (1 << (8 + i));      /* bit 8 + i: state i was outside (env.py:121-123 prints it) */
+  if (out) return out;
   double xd[18];
   f16o_calc_xdot(x, u, xd, fi_flag, xcg);
   int st = t_status;
