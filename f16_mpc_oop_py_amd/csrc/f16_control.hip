@@ -1202,10 +1202,18 @@ static int mpc_launch(f16_ctx *ctx, MpcArgs &a, void *stream, int mode, void **k
       // Dispatch order (see k_plan_order): the reference's closed loops call calc_MPC_action once per step on states that
       // move little, so the iteration counts of the previous call of the same batch size ON THE SAME STREAM predict this
       // one's; any order is valid, a stale one only loses the gain.  F16_MPC_DISPATCH_ORDER=0 keeps the caller's order.
+      // A first call has no such counts: its order comes from the QPs themselves (mpc_first_order_launch: by ||q||_inf).
+      // F16_MPC_DISPATCH_ORDER=first treats every call as a first one (benchmarks: what BASELINE config 4, one call on an unseen
+      // batch, costs); =0 switches every ordering off.
       const char *ev = getenv("F16_MPC_DISPATCH_ORDER");
+      const bool always_first = ev && ev[0] == 'f';
       f16_ctx::sched_entry *se = (ev && ev[0] == '0') ? nullptr : mpc_sched_entry(ctx, stream, a.B);
-      if (se) { a.iters_out = se->buf; a.order = se->valid ? se->buf + a.B : nullptr; }
-      rc = mpc_solve_dispatch(ctx, a, stream);
+      if (se) { a.iters_out = se->buf; a.order = (se->valid && !always_first) ? se->buf + a.B : nullptr; }
+      if (se && !a.order && a.B > 1024) {
+        rc = mpc_first_order_launch(a, se->buf, se->buf + a.B, stream);
+        if (!rc) a.order = se->buf + a.B;
+      }
+      if (!rc) rc = mpc_solve_dispatch(ctx, a, stream);
       if (!rc && se) {
         rc = mpc_plan_order_launch(se->buf, se->buf + a.B, a.B, a.s.check_every, stream);
         if (!rc) se->valid = 1;
@@ -1427,6 +1435,10 @@ extern "C" int f16_mpc_plan_solve_w(f16_mpc_plan *p, const double *x, const doub
   a.iters_out = p->sched;
   a.order = p->have_order ? p->sched + p->B : nullptr;
   if (int rc = plan_launch_build(p, a, stream)) return rc;
+  if (!a.order && p->B > 1024 && p->N <= FAST_MAXN) {      // first solve of the plan: longest-first by ||q||_inf of the QPs just built
+    if (int rc = mpc_first_order_launch(a, p->sched, p->sched + p->B, stream)) return rc;
+    a.order = p->sched + p->B;
+  }
   if (p->s.scaling > 0 || p->N > FAST_MAXN) a.mode = 0;   // nothing cached beyond the model part: full solver prologue
   if (p->N > FAST_MAXN) {
     a.warm = nullptr;

@@ -111,5 +111,6 @@ int mpc_big_sweep_order_launch(const int32_t *iters, int32_t *order, long pairs,
 constexpr int FAST_MAXN = 32;
 int mpc_fast_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream);
 int mpc_plan_order_launch(const int32_t *iters, int32_t *order, long B, int check_every, void *stream);
+int mpc_first_order_launch(const MpcArgs &a, int32_t *scratch, int32_t *order, void *stream);      // first call: longest-first by ||q||_inf
 
 }  // namespace f16

@@ -827,6 +827,9 @@ F16_DEV void calc_xdot_na(TP T, const double *__restrict__ LT, const double *sv,
 // Which states are outside their box (env.py:117-124 tests all eighteen; six of them carry no finite limit): bit 8 + k for state
 // k -- evaluated only once an aircraft has been found outside (outside_envelope), not in the per-step path
 F16_DEV int envelope_state_bits(const double *x) {
+#ifdef F16_NO_ENV_BITS      // (A/B builds: what the which-state bits cost the rollout kernels)
+  return 0;
+#endif
   int m = 0;
   m |= (x[2] < 0 || x[2] > 100000) ? 1 << (8 + 2) : 0;
   m |= (x[6] < 0 || x[6] > 900) ? 1 << (8 + 6) : 0;

@@ -711,7 +711,8 @@ def test_g8b_qp_build_with_weights_reference_and_bounds_as_arguments(xcg, tag):
     L.check(env.lib.f16_lqr_batch_w(env.ctx.handle, _vp(Ad), _vp(Bd), _vp(Cd), ctypes.byref(ww), _vp(Kt), None, _vp(st), env.B, env.B,
                                     env._stream))
     Kd = -Kt.t().reshape(env.B, 3, 9)[0].cpu().numpy()       # the library returns K = -dlqr (env.py:356)
-    np.testing.assert_allclose(Kd, g[f"K_{tag}_xcg{xcg}"], rtol=1e-6, atol=1e-10)
+    Kref = g[f"K_{tag}_xcg{xcg}"]
+    assert np.abs(Kd - Kref).max() / np.abs(Kref).max() < 1e-8          # (entries span seven decades: relative to the gain's scale)
     assert int(st.max()) == 0
 
 
