@@ -118,7 +118,7 @@ __device__ __forceinline__ void rollout_lanes(const DynArgs &a, TP T, double (*u
     int until_store = a.traj_every;
     for (int t = 0; t < a.nsteps; ++t) {
       // env.py:117-124: the reference exit()s; here the aircraft is frozen and flagged
-      if (!(a.flags & FLAG_NO_ENVELOPE) && !(st & ST_ENVELOPE) && outside_envelope(x)) st |= ST_ENVELOPE | envelope_state_bits(x);
+      if (!(a.flags & FLAG_NO_ENVELOPE) && outside_envelope(x)) st |= ST_ENVELOPE;
       if (!(st & ST_ENVELOPE)) {
         double xd[18], u[4];
 #pragma unroll
@@ -144,6 +144,8 @@ __device__ __forceinline__ void rollout_lanes(const DynArgs &a, TP T, double (*u
 #pragma unroll
     for (int k = 0; k < 18; ++k) finite = finite && isfinite(x[k]);
     if (!finite) st |= ST_NONFINITE;
+    // WHICH states were outside: a frozen aircraft keeps the state it was frozen with, so the bits are formed here, once
+    if (st & ST_ENVELOPE) st |= envelope_state_bits(x);
 #pragma unroll
     for (int k = 0; k < 18; ++k) a.out[k * a.ld + b] = x[k];
     if (a.status) a.status[b] = st;
@@ -264,13 +266,12 @@ __global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
         tr += 18 * a.ld;
       }
       if (last) break;
-      const bool newly_out = (xenv[0][lane] | xenv[1][lane] | xenv[2][lane]) && !(st & ST_ENVELOPE);
+      if (xenv[0][lane] | xenv[1][lane] | xenv[2][lane]) st |= ST_ENVELOPE;
+      const bool live = !(st & ST_ENVELOPE);
       // every wave sees the full published state (its own part is identical to its registers)
       double xa[17];
 #pragma unroll
       for (int k = 0; k < 17; ++k) xa[k] = xs[k][lane];
-      if (newly_out) st |= ST_ENVELOPE | envelope_state_bits(xa);      // (which states: once, from the published copy)
-      const bool live = !(st & ST_ENVELOPE);
       Pre p;
       double xd[18], o[3];
       int sa = 0;
@@ -364,6 +365,8 @@ __global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
 #pragma unroll
       for (int k = 0; k < 18; ++k)
         if (k >= k0 && k < k1) { finite = finite && isfinite(x[k]); a.out[k * a.ld + b] = x[k]; }
+      // (which states were outside: a frozen aircraft keeps the state it was frozen with; every owner reports its own states)
+      if (st & ST_ENVELOPE) st |= envelope_state_bits(x) & (((1 << k1) - (1 << k0)) << 8);
       if (a.status) atomicOr(&a.status[b], st | (finite ? 0 : ST_NONFINITE));
       if (LQR && wave == 3 && a.u_out) {
         a.u_out[b] = u[0];
@@ -465,12 +468,11 @@ __global__ __launch_bounds__(256 * GROUPS) void k_rollout_q(DynArgs a) {
         tr += 18 * a.ld;
       }
       if (t == a.nsteps) break;
-      const bool newly_out = (xenv[0][ac] | xenv[1][ac] | xenv[2][ac]) && !(st & ST_ENVELOPE);
+      if (xenv[0][ac] | xenv[1][ac] | xenv[2][ac]) st |= ST_ENVELOPE;
+      const bool live = !(st & ST_ENVELOPE);
       double xa[17];
 #pragma unroll
       for (int k = 0; k < 17; ++k) xa[k] = xs[k][ac];
-      if (newly_out) st |= ST_ENVELOPE | envelope_state_bits(xa);      // (which states: once, from the published copy)
-      const bool live = !(st & ST_ENVELOPE);
       // first-half results wave 2 keeps in registers for the second half
       double xd[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       double U = 0, V = 0, W = 0, s_t = 0, c_t = 0, s_phi = 0, c_phi = 0, cb = 0, vtc = 0, r1 = 0, r2 = 0, r3 = 0;
@@ -616,16 +618,24 @@ __global__ __launch_bounds__(256 * GROUPS) void k_rollout_q(DynArgs a) {
         bool finite = true;
 #pragma unroll
         for (int k = 0; k < 9; ++k) { finite = finite && isfinite(x[k]); a.out[k * a.ld + b] = x[k]; }
+        // (which states were outside: a frozen aircraft keeps the state it was frozen with; every owner reports its own states)
+        if (st & ST_ENVELOPE) st |= envelope_state_bits(x) & (0x1FF << 8);
         if (a.status) atomicOr(&a.status[b], st | (finite ? 0 : ST_NONFINITE));
       } else if (wave == 1 && s == 0) {
         bool finite = true;
 #pragma unroll
         for (int k = 9; k < 12; ++k) { finite = finite && isfinite(x[k]); a.out[k * a.ld + b] = x[k]; }
+        if (st & ST_ENVELOPE) st |= envelope_state_bits(x) & (0x7 << 17);
         if (a.status) atomicOr(&a.status[b], st | (finite ? 0 : ST_NONFINITE));
       } else if (wave == 3) {
         a.out[(12 + s) * a.ld + b] = xact;
         bool finite = isfinite(xact);
         if (s < 2) { const double v = s == 0 ? x[16] : x[17]; finite = finite && isfinite(v); a.out[(16 + s) * a.ld + b] = v; }
+        if (st & ST_ENVELOPE) {
+          const double lim = s == 1 ? 25.0 : (s == 2 ? 21.5 : 30.0);
+          if (s == 0 ? (xact < 1000 || xact > 19000) : (xact < -lim || xact > lim)) st |= 1 << (8 + 12 + s);
+          if (s == 0 && (x[16] < 0. || x[16] > 25)) st |= 1 << (8 + 16);
+        }
         if (a.status) atomicOr(&a.status[b], st | (finite ? 0 : ST_NONFINITE));
         if (LQR && a.u_out) a.u_out[s * a.ld + b] = ulast;
       }
