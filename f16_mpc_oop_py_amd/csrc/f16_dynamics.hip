@@ -96,8 +96,17 @@ __global__ __launch_bounds__(BLOCK) void k_nlplant(DynArgs a) {
 
 // One lane = one aircraft, the whole rollout in registers.  TP = the table image the lookups read (plant header: fp64
 // values or scaled integers).
-template <int BLOCK, int FI, typename TP, bool LQR = false>
-__device__ __forceinline__ void rollout_lanes(const DynArgs &a, TP T, double (*us)[BLOCK], double (*kq)[BLOCK] = nullptr) {
+// INCT (default numerics only; the strict build and every single-evaluation kernel keep the full sincos): the five sin / cos pairs
+// of a step are carried from step to step (trig_advance: rotated by the exact increment of their angles, re-evaluated exactly every
+// 32nd step) instead of evaluated from scratch -- ~155 of the ~1,555 wave-instructions of a hifi step.  tgs: lane-indexed LDS slots.
+#if defined(F16_FAST_TRIG) && !defined(F16_NO_INC_TRIG)
+constexpr bool INC_TRIG = true;
+#else
+constexpr bool INC_TRIG = false;
+#endif
+template <int BLOCK, int FI, typename TP, bool LQR = false, bool INCT = false>
+__device__ __forceinline__ void rollout_lanes(const DynArgs &a, TP T, double (*us)[BLOCK], double (*kq)[BLOCK] = nullptr,
+                                              double (*tgs)[BLOCK] = nullptr) {
   for (long b = (long)blockIdx.x * BLOCK + threadIdx.x; b < a.B; b += (long)gridDim.x * BLOCK) {
     double x[18];
 #pragma unroll
@@ -116,6 +125,7 @@ __device__ __forceinline__ void rollout_lanes(const DynArgs &a, TP T, double (*u
     int st = a.status ? a.status[b] : 0;
     double *tr = a.traj ? a.traj + b : nullptr;
     int until_store = a.traj_every;
+    bool stale = true;                                   // (INCT) the first step evaluates the five pairs exactly
     for (int t = 0; t < a.nsteps; ++t) {
       // env.py:117-124: the reference exit()s; here the aircraft is frozen and flagged
       if (!(a.flags & FLAG_NO_ENVELOPE) && outside_envelope(x)) st |= ST_ENVELOPE;
@@ -129,9 +139,19 @@ __device__ __forceinline__ void rollout_lanes(const DynArgs &a, TP T, double (*u
           for (int i = 0; i < 3; ++i)
             ul[i] = u[1 + i] = lqr_action(kq[3 * i][threadIdx.x], kq[3 * i + 1][threadIdx.x], kq[3 * i + 2][threadIdx.x], e0, e1, e2, u[1 + i]);
         }
+        if (INCT) {
+          const TrigSlots ts{&tgs[0][threadIdx.x], BLOCK};
+          if (stale || (t & 31) == 0) { Trig5 g; trig_exact(x, g); trig_store(ts, g); }
+          calc_xdot<FI, TP, true>(T, a.lofi, x, u, xd, a.xcg, a.fi, a.flags, st, &ts);
+          const double xo5[5] = {x[7], x[8], x[4], x[3], x[5]};
+#pragma unroll
+          for (int k = 0; k < 18; ++k) x[k] += xd[k] * a.dt;   // env.py:126
+          stale = trig_advance(xo5, x, ts);
+        } else {
         calc_xdot<FI>(T, a.lofi, x, u, xd, a.xcg, a.fi, a.flags, st);
 #pragma unroll
         for (int k = 0; k < 18; ++k) x[k] += xd[k] * a.dt;   // env.py:126
+        }
       }
       if (tr && --until_store == 0) {
         until_store = a.traj_every;
@@ -164,8 +184,11 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(DynArgs a) {
   // slots rather than in eight registers that the 512-lane instantiation (256 registers per lane) spilled and reloaded per step
   __shared__ double us[4][BLOCK];
   __shared__ double kq[LQR ? 12 : 1][LQR ? BLOCK : 1];
+  constexpr bool INCT = INC_TRIG && BLOCK <= 256 && !(LQR && BLOCK == 256);      // (the ten slots must fit beside the fp64 table image and, closed loop, the gain slots)
+  __shared__ double tgs[INCT ? 10 : 1][INCT ? BLOCK : 1];
   if (a.fi == 1) stage_tables(tab, a.tab);
-  rollout_lanes<BLOCK, FI, const double *, LQR>(a, (const double *)tab, us, reinterpret_cast<double (*)[BLOCK]>(kq));
+  rollout_lanes<BLOCK, FI, const double *, LQR, INCT>(a, (const double *)tab, us, reinterpret_cast<double (*)[BLOCK]>(kq),
+                                                      reinterpret_cast<double (*)[BLOCK]>(tgs));
 }
 
 // The same rollout on the scaled-integer table image (hifi, default numerics; large batches: the LDS pipe -- 1.5 KB of
@@ -176,13 +199,15 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_i(DynArgs a) {
   __shared__ __attribute__((aligned(16))) int tab[i32::IMAGE_INTS];
   __shared__ double us[4][BLOCK];
   __shared__ double kq[LQR ? 12 : 1][LQR ? BLOCK : 1];
+  constexpr bool INCT = INC_TRIG && !LQR;              // (closed loop: the gain slots take the room)
+  __shared__ double tgs[INCT ? 10 : 1][INCT ? BLOCK : 1];
   {
     const int4 *src = reinterpret_cast<const int4 *>(a.tab32);
     int4 *dst = reinterpret_cast<int4 *>(tab);
     for (int i = threadIdx.x; i < i32::IMAGE_INTS / 4; i += BLOCK) dst[i] = src[i];
     __syncthreads();
   }
-  rollout_lanes<BLOCK, 1, TabI32, LQR>(a, TabI32{tab}, us, reinterpret_cast<double (*)[BLOCK]>(kq));
+  rollout_lanes<BLOCK, 1, TabI32, LQR, INCT>(a, TabI32{tab}, us, reinterpret_cast<double (*)[BLOCK]>(kq), reinterpret_cast<double (*)[BLOCK]>(tgs));
 }
 
 // Four-wavefront rollout (latency regime, hifi): one workgroup = 64 aircraft on the four SIMDs of a CU; the state is

@@ -649,19 +649,70 @@ F16_DEV void compose_totals(const double *ls, const double *ld, const double *ts
 }
 
 // Trigonometry, atmosphere, navigation + kinematic equations (C/nlplant.c:90-176): xdot[0..5].
-template <bool ATMOS = true>
-F16_DEV void plant_pre(const double *xu, Pre &p, double *xdot) {
+// sin / cos of alpha, beta, theta, phi, psi handed in by a caller that keeps them up to date itself (rollout kernels: trig_advance)
+struct Trig5 { double sa, ca, sb, cb, st, ct, sphi, cphi, spsi, cpsi; };
+F16_DEV void trig_exact(const double *x, Trig5 &g) {
+  F16_SINCOS(x[7], &g.sa, &g.ca);
+  F16_SINCOS(x[8], &g.sb, &g.cb);
+  F16_SINCOS(x[4], &g.st, &g.ct);
+  F16_SINCOS(x[3], &g.sphi, &g.cphi);
+  F16_SINCOS(x[5], &g.spsi, &g.cpsi);
+}
+// (sin, cos)(a + d) from (sin, cos)(a) by the angle-sum formulas with sin d, cos d from their series: for |d| <= 4e-3 rad (an Euler
+// step of 1 ms moves an angle by |rate| x 1e-3) the terms dropped are d^7 / 5040 < 4e-21 and d^6 / 720 < 6e-18.  11 operations per
+// angle against ~42 for the full evaluation (range reduction, two polynomials, quadrant selects).
+F16_DEV void trig_rotate(double &s, double &c, double d) {
+  const double d2 = d * d;
+  const double sd = d * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+  const double cd = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
+  const double s1 = fma(c, sd, s * cd), c1 = fma(-s, sd, c * cd);
+  s = s1; c = c1;
+}
+// The rollout kernels carry the five pairs from step to step in lane-indexed LDS slots (TrigSlots: slot k of this lane at
+// base[k * stride]).  A stale set (every 32nd step, or after an increment beyond the series' range) is re-evaluated exactly INTO the
+// slots at the top of the step -- a block of its own with nothing live behind it -- and plant_pre always loads the ten doubles where
+// it needs them (behind the lookups): a merge of "evaluated" and "loaded" values in front of the lookups was spilled across them.
+struct TrigSlots { double *base; int stride; };
+F16_DEV void trig_store(const TrigSlots &ts, const Trig5 &g) {
+  double *b = ts.base; const int n = ts.stride;
+  b[0] = g.sa; b[n] = g.ca; b[2 * n] = g.sb; b[3 * n] = g.cb; b[4 * n] = g.st; b[5 * n] = g.ct; b[6 * n] = g.sphi; b[7 * n] = g.cphi;
+  b[8 * n] = g.spsi; b[9 * n] = g.cpsi;
+}
+// after an Euler step: the pairs follow their angles by the EXACT increment of the stored state (xn - xo: a difference of
+// neighbouring doubles), so nothing but the rounding of the rotations (~1e-16 a step) separates them from the state.  Returns
+// whether an increment left the series' range (the caller then marks the slots stale: the next step evaluates exactly).
+F16_DEV bool trig_advance(const double *xo5, const double *xn, const TrigSlots &ts) {
+  const double da = xn[7] - xo5[0], db = xn[8] - xo5[1], dt = xn[4] - xo5[2], dp = xn[3] - xo5[3], ds = xn[5] - xo5[4];
+  const double big = fmax(fmax(fabs(da), fabs(db)), fmax(fmax(fabs(dt), fabs(dp)), fabs(ds)));
+  double *b = ts.base; const int n = ts.stride;
+  { double s = b[0], c = b[n]; trig_rotate(s, c, da); b[0] = s; b[n] = c; }
+  { double s = b[2 * n], c = b[3 * n]; trig_rotate(s, c, db); b[2 * n] = s; b[3 * n] = c; }
+  { double s = b[4 * n], c = b[5 * n]; trig_rotate(s, c, dt); b[4 * n] = s; b[5 * n] = c; }
+  { double s = b[6 * n], c = b[7 * n]; trig_rotate(s, c, dp); b[6 * n] = s; b[7 * n] = c; }
+  { double s = b[8 * n], c = b[9 * n]; trig_rotate(s, c, ds); b[8 * n] = s; b[9 * n] = c; }
+  return !(big <= 4e-3);
+}
+
+template <bool ATMOS = true, bool GIVEN = false>
+F16_DEV void plant_pre(const double *xu, Pre &p, double *xdot, const TrigSlots *tg = nullptr) {
   const double alt = xu[2], phi = xu[3], theta = xu[4], psi = xu[5];
   const double P = xu[9], Q = xu[10], R = xu[11];
   double vt = xu[6];
   if (vt <= 0.01) vt = 0.01;
   p.vt = vt;
   double spsi, cpsi;
-  F16_SINCOS(xu[7], &p.sa, &p.ca);
-  F16_SINCOS(xu[8], &p.sb, &p.cb);
-  F16_SINCOS(theta, &p.st, &p.ct);
-  F16_SINCOS(phi, &p.sphi, &p.cphi);
-  F16_SINCOS(psi, &spsi, &cpsi);
+  if (GIVEN) {        // (the slots are current: the caller has refreshed them where they were stale)
+    const double *b = tg->base; const int n = tg->stride;
+    p.sa = b[0]; p.ca = b[n]; p.sb = b[2 * n]; p.cb = b[3 * n]; p.st = b[4 * n]; p.ct = b[5 * n]; p.sphi = b[6 * n]; p.cphi = b[7 * n];
+    spsi = b[8 * n]; cpsi = b[9 * n];
+    (void)phi; (void)psi;
+  } else {
+    F16_SINCOS(xu[7], &p.sa, &p.ca);
+    F16_SINCOS(xu[8], &p.sb, &p.cb);
+    F16_SINCOS(theta, &p.st, &p.ct);
+    F16_SINCOS(phi, &p.sphi, &p.cphi);
+    F16_SINCOS(psi, &spsi, &cpsi);
+  }
 #ifdef F16_FAST_DIV
   const double rct = f16_rcp(p.ct);
   const double tt = p.st * rct;
@@ -754,13 +805,13 @@ F16_DEV void plant_post(const double *xu, const Pre &p, const Totals &t, double 
 // C/nlplant.c:23-457.  xu[0..16] in, xdot[0..11] out (+ xdot[12..17] = nx,ny,nz,mach,qbar,ps when OUTPUTS).
 // Returns qbar/ps of the clamped-vt atmosphere call for reuse by the lef model.  The lookups and the six coefficient
 // totals come FIRST: the 45 interpolated values collapse to 6 doubles before the register-hungry sincos/pow code runs.
-template <bool OUTPUTS, int FI = -1, typename TP>
+template <bool OUTPUTS, int FI = -1, typename TP, bool GIVEN = false>
 F16_DEV void plant(TP T, const double *__restrict__ LT, const double *xu, double *xdot, double xcg, int fi_flag,
-                   unsigned flags, int &status, double &qbar_out, double &ps_out) {
+                   unsigned flags, int &status, double &qbar_out, double &ps_out, const TrigSlots *tg = nullptr) {
   Totals t;
   aero_totals<FI>(T, LT, xu, xcg, fi_flag, flags, t, status);
   Pre p;
-  plant_pre(xu, p, xdot);
+  plant_pre<true, GIVEN>(xu, p, xdot, tg);
   qbar_out = p.qbar; ps_out = p.ps;
   plant_post<OUTPUTS>(xu, p, t, xdot);
 }
@@ -799,11 +850,11 @@ F16_DEV void actuators_dev(const double *x, const double *u, double qbar, double
 }
 
 // env.py:65-103: xdot[18] of the full actuated model.
-template <int FI = -1, typename TP>
+template <int FI = -1, typename TP, bool GIVEN = false>
 F16_DEV void calc_xdot(TP T, const double *__restrict__ LT, const double *x, const double *u, double *xdot, double xcg,
-                       int fi_flag, unsigned flags, int &status) {
+                       int fi_flag, unsigned flags, int &status, const TrigSlots *tg = nullptr) {
   double qbar, ps;
-  plant<false, FI>(T, LT, x, xdot, xcg, fi_flag, flags, status, qbar, ps);
+  plant<false, FI, TP, GIVEN>(T, LT, x, xdot, xcg, fi_flag, flags, status, qbar, ps, tg);
   actuators_dev(x, u, qbar, ps, xdot);
 }
 
