@@ -1045,19 +1045,22 @@ __device__ __forceinline__ double octet_allreduce(double v) {
   return v;
 }
 
-// npm[k] = D_k max_j |P_kj| D_j for every variable (natural order, LDS) from the block image of P in HBM and D in LDS
-__device__ __forceinline__ void p_row_norms(const double *pb, const double *Dn, double *npm, const Role &R) {
+// the lane's two blocks of |P| (block image in the workspace): loaded ONCE per equilibration -- every pass re-read them before (11 x 36
+// loads of 16 bytes, each batch a round trip to the Infinity Cache)
+__device__ __forceinline__ void p_abs_blocks(const double *pb, const Role &R, double (&A)[6][6], double (&Bk)[6][6]) {
   typedef double dbl2_t __attribute__((ext_vector_type(2)));
   typedef const dbl2_t __attribute__((address_space(1))) *g2ptr_t;
   const g2ptr_t pp = (g2ptr_t)pb + R.l;
-  const int rr = R.r < NB ? R.r : NB - 1;
-  double A[6][6], Bk[6][6];
 #pragma unroll
   for (int m = 0; m < 18; ++m) {
     const dbl2_t a = pp[m * 64], b = pp[(18 + m) * 64];
     A[(2 * m) / 6][(2 * m) % 6] = fabs(a.x); A[(2 * m + 1) / 6][(2 * m + 1) % 6] = fabs(a.y);
     Bk[(2 * m) / 6][(2 * m) % 6] = fabs(b.x); Bk[(2 * m + 1) / 6][(2 * m + 1) % 6] = fabs(b.y);
   }
+}
+// npm[k] = D_k max_j |P_kj| D_j for every variable (natural order, LDS) from the lane's blocks of |P| and D in LDS
+__device__ __forceinline__ void p_row_norms(const double (&A)[6][6], const double (&Bk)[6][6], const double *Dn, double *npm, const Role &R) {
+  const int rr = R.r < NB ? R.r : NB - 1;
   double dr[6], da[6], db[6];
 #pragma unroll
   for (int m = 0; m < 6; ++m) { dr[m] = Dn[6 * rr + m]; da[m] = Dn[6 * R.cA + m]; db[m] = Dn[6 * R.cB + m]; }
@@ -1114,7 +1117,9 @@ __device__ __noinline__ void ruiz_wave(const double *pb, const double *qv, int N
     }
   }
   wave_lds_sync();
-  p_row_norms(pb, Dn, npm, R);
+  double PA[6][6], PB[6][6];
+  p_abs_blocks(pb, R, PA, PB);
+  p_row_norms(PA, PB, Dn, npm, R);
   wave_lds_sync();
   const int base1 = 4 * (R.o + R.t), wb = base1 < N ? base1 : N;          // first operand step of the stage-1 pattern
   const int s0 = 4 * (R.o - R.t) - 3, sb = s0 > -7 ? s0 : -7;              // ... of the stage-3 pattern
@@ -1195,7 +1200,7 @@ __device__ __noinline__ void ruiz_wave(const double *pb, const double *qv, int N
       }
     }
     wave_lds_sync();
-    p_row_norms(pb, Dn, npm, R);                            // with the new D: cost scaling now, column norms of the next pass
+    p_row_norms(PA, PB, Dn, npm, R);                        // with the new D: cost scaling now, column norms of the next pass
     wave_lds_sync();
     double sm = 0.0, qn = 0.0;
     if (wrx) {
