@@ -755,6 +755,73 @@ def test_solves_with_weights_as_arguments_follow_the_cpu_twin_and_reach_the_mini
     env.setup_OSQP(0.0, 0.0, 0.0, 10, weights=bad)                        # ... the QP alone: any pattern
 
 
+def test_weights_argument_validation_and_defaults():
+    """f16_mpc_weights: the default struct IS env.py's constants (the `_w` entry points with it are bit for bit the plain ones, the
+    LQR gain included); Q must be finite and symmetric, R symmetric positive definite, every box lb <= ub with a finite side, and
+    the pattern of bounded state rows is the reference's -- anything else is F16_EINVAL, not a silently different problem."""
+    from f16_mpc_oop_py_amd import lib as L
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(96, seed=3)
+    env = make_env(x0, u0, xcg=0.35)
+    env.build_ssr()
+    w = L.MPCWeights()
+    env.lib.f16_mpc_default_weights(ctypes.byref(w))
+    assert w.q_from_cd == 1 and list(w.R) == [1, 0, 0, 0, 1, 0, 0, 0, 1] and list(w.u_lb) == [-25.0, -21.5, -30.0]
+    assert list(w.x_lb)[2:7] == [-20.0, -30.0, -300.0, -100.0, -50.0] and w.x_lb[0] == -np.inf and w.x_ub[8] == 25.0
+    u_plain = env._calc_MPC_action(0.02, -0.01, 0.0, 12)
+    u_w = env._calc_MPC_action(0.02, -0.01, 0.0, 12, weights=dict(R=np.eye(3), u_lb=[-25.0, -21.5, -30.0]))
+    assert torch.equal(u_plain, u_w)
+    assert torch.equal(env._calc_LQR_gain(), env._calc_LQR_gain(R=np.eye(3)))
+    Qc = (env.ssr[2].t()[0].reshape(9, 9).t() @ env.ssr[2].t()[0].reshape(9, 9)).cpu().numpy()      # Cd'Cd of aircraft 0
+    Kq = env._calc_LQR_gain(Q=Qc)[0]
+    assert torch.allclose(Kq, env._calc_LQR_gain()[0], rtol=1e-9, atol=1e-12)
+    bad = [dict(Q=np.triu(np.ones((9, 9)))), dict(Q=np.full((9, 9), np.nan)), dict(R=-np.eye(3)), dict(R=np.array([[1, 2, 0], [0, 1, 0], [0, 0, 1.0]])),
+           dict(u_lb=[30.0, 0, 0]), dict(udot_lb=[-np.inf] * 3, udot_ub=[np.inf] * 3), dict(x_ub=[np.inf] * 9, x_lb=[-np.inf] * 9),
+           dict(x_lb=[-1.0] + [-np.inf] * 8)]
+    for kw in bad:
+        with pytest.raises(L.F16HipError):
+            env._calc_MPC_action(0.0, 0.0, 0.0, 8, weights=kw)
+    # one-sided boxes are fine (OSQP's infinity on the other side): same solve as a box far away
+    u1 = env._calc_MPC_action(0.0, 0.0, 0.0, 8, weights=dict(u_ub=[np.inf] * 3))
+    u2 = env._calc_MPC_action(0.0, 0.0, 0.0, 8, weights=dict(u_ub=[1e30] * 3))
+    assert torch.equal(u1, u2) and torch.isfinite(u1).all()
+
+
+def test_dispatch_orders_do_not_change_results():
+    """Scheduling only: the same batch with no ordering, with the first-call order (by ||q||_inf) and with the order of a previous
+    call returns the same commands, iteration counts and status words, bit for bit.  Fresh processes (the switch is read per call,
+    the history lives in the context)."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        from f16_mpc_oop_py_amd import F16Batch
+        from f16_mpc_oop_py_amd.workload import config4_states
+        x0, u0 = config4_states(2048, seed=11)
+        env = F16Batch(x0, u0, xcg=0.35)
+        env.build_ssr()
+        out = []
+        for _ in range(2):
+            u, info = env._calc_MPC_action(0.0, 0.0, 0.0, 30, return_info=True)
+            out.append((u.cpu().numpy(), info["iters"].cpu().numpy(), info["status"].cpu().numpy()))
+        assert all(np.array_equal(a, b) for a, b in zip(out[0], out[1]))
+        np.savez(sys.argv[1], u=out[0][0], it=out[0][1], st=out[0][2])
+    """)
+    import tempfile
+    res = []
+    with tempfile.TemporaryDirectory() as d:
+        for mode in ("0", "first", "1"):
+            f = os.path.join(d, f"o_{mode}.npz")
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, PYTHONPATH=REPO, F16_MPC_DISPATCH_ORDER=mode),
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res.append(np.load(f))
+    for k in ("u", "it", "st"):
+        assert np.array_equal(res[0][k], res[1][k], equal_nan=True) and np.array_equal(res[0][k], res[2][k], equal_nan=True)
+    assert res[0]["it"].min() >= 25 and res[0]["it"].max() > res[0]["it"].min()
+
+
 def test_first_solve_of_a_wide_plan_inside_a_capture():
     """Plans accept horizons 33..40 (every solve runs the long-horizon workgroup solver) and plan solves are capturable: the
     kernel's dynamic-LDS opt-in (hipFuncSetAttribute, not legal under capture) must therefore have happened in
