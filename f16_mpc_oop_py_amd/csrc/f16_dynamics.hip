@@ -875,3 +875,9 @@ extern "C" int f16_xdot_na_batch(f16_ctx *ctx, const double *x_full, const doubl
   LAUNCH_BY_BLOCK(k_xdot_na, g, (hipStream_t)stream, a);
   return hip_check(hipGetLastError(), "f16_xdot_na_batch launch");
 }
+
+#ifdef F16_EXP_STAMPQ2
+extern "C" int f16_debug_qstamps(unsigned long long *h_out) {     // diagnostic build only
+  return hip_check(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(f16::g_qstamp), 8 * sizeof(unsigned long long)), "read stamps");
+}
+#endif

@@ -85,15 +85,26 @@ F16_DEV QuadIn quad_inputs(const double *xu) {
 // hifi_damping_lef, hifi_other_coeffs).  dZdQ uses delta_Cz_lef exactly as the reference does (:339).
 // latd: the rate-damping part of the LATERAL member k (Cy, Cn, Cl) -- 1-D tables on the same alpha cell, evaluated here
 // to balance the two aerodynamic waves: kb (Cr + dCr_lef dlef) R + kb (Cp + dCp_lef dlef) P (+ dC_beta beta), :353-377.
+#ifdef F16_EXP_STAMPQ2      // diagnostic build: cycles per phase of the longitudinal role (workgroup 0), tools/gpu_dyn_stamps2.py
+__device__ unsigned long long g_qstamp[8];
+#define Q2STAMP(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_qstamp[i] += t1_ - tq_; tq_ = t1_; }
+#else
+#define Q2STAMP(i)
+#endif
 template <typename TP>
 F16_DEV double quad_long(TP T, const double *xu, int s, double xcg, unsigned flags, double &latd, int &status) {
+#ifdef F16_EXP_STAMPQ2
+  unsigned long long tq_ = __builtin_amdgcn_s_memtime();
+#endif
   const QuadIn in = quad_inputs(xu);
+  Q2STAMP(0)
   const int k = s < 2 ? s : 2;
   // (1) breakpoints: one axis per sub-lane
   int nX; double vX;
   const BrRaw rx = quad_br_load<false>(T, in.alpha, in.beta, in.el, s, nX, vX);
   const double a45 = T[OFF_BP_A1 + N_A2 - 1];
   F16_PHASE();
+  Q2STAMP(1)
   const QuadBr qb = quad_br_cells(rx, nX, vX);
   if (qb.offa) status |= ST_ALPHA1 | ST_ALPHA2;
   if (qb.offb) status |= ST_BETA;
@@ -115,6 +126,7 @@ F16_DEV double quad_long(TP T, const double *xu, int s, double xcg, unsigned fla
   const int ir = k == 0 ? 1 : (k == 1 ? 7 : 4), ib = k == 1 ? 9 : 10;     // CYr CYp | CNr CNp | CLr CLp; dCNbeta, dCLbeta
   const double r0 = g[ir], r1 = g[S_G1A + ir], p0 = g[ir + 1], p1 = g[S_G1A + ir + 1], b0 = g[ib], b1 = g[S_G1A + ib];
   const double hr0 = h[ir], hr1 = h[S_G1B + ir], hp0 = h[ir + 1], hp1 = h[S_G1B + ir + 1];
+  Q2STAMP(2)
   F16_PHASE();
   // (3) arithmetic
   Axis a1, b, d1;
@@ -135,6 +147,7 @@ F16_DEV double quad_long(TP T, const double *xu, int s, double xcg, unsigned fla
   const double Cp = lerp(p0, p1, a1), Cb = lerp(b0, b1, a1);
   const double dCr = lerp(hr0, hr1, a2), dCp = lerp(hp0, hp1, a2);
   latd = in.kb * (Cr + dCr * in.dlef) * in.R + in.kb * (Cp + dCp * in.dlef) * in.P + (k == 0 ? 0.0 : Cb * in.beta);
+  Q2STAMP(3)
   return tot;
 }
 
