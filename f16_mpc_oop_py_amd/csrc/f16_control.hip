@@ -1140,12 +1140,22 @@ static f16_ctx::sched_entry *mpc_sched_entry(f16_ctx *ctx, void *stream, long B,
   std::lock_guard<std::mutex> lk(mu);
   for (int i = 0; i < ctx->n_sched; ++i)
     if (ctx->sched[i].stream == stream && ctx->sched[i].B == B && ctx->sched[i].tag == tag) return &ctx->sched[i];
-  if (ctx->n_sched >= F16_MAX_SCHED) return nullptr;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (stream && hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;
   int32_t *buf = nullptr;
   if (hipMalloc(&buf, 2 * (size_t)B * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  f16_ctx::sched_entry &e = ctx->sched[ctx->n_sched++];
+  int slot = ctx->n_sched;
+  if (slot >= F16_MAX_SCHED) {
+    // all history slots taken (more than F16_MAX_SCHED (stream, batch size) pairs on one context): the oldest one is recycled, round
+    // robin -- hipFree waits for whatever still reads its buffer; a caller that cycles through more pairs than slots loses the
+    // ordering gain on the evicted ones, never a result
+    static int victim = 0;
+    slot = victim++ % F16_MAX_SCHED;
+    (void)hipFree(ctx->sched[slot].buf);
+  } else {
+    ctx->n_sched++;
+  }
+  f16_ctx::sched_entry &e = ctx->sched[slot];
   e.stream = stream; e.B = B; e.buf = buf; e.valid = 0; e.tag = tag;
   return &e;
 }

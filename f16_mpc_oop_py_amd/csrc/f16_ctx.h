@@ -17,7 +17,7 @@ struct f16_ctx {
   //    release threshold keeps the memory cached between calls;
   //  * the dispatch-order history (iteration counts of the previous call | order derived from them, [2][B] int32) is
   //    kept per (stream, batch size): calls on one stream are ordered, calls on different streams never touch the same
-  //    buffer.  Beyond F16_MAX_SCHED entries a call simply runs in the caller's order.
+  //    buffer.  Beyond F16_MAX_SCHED entries the oldest entry is recycled (round robin).
   hipMemPool_t pool;
   struct sched_entry { void *stream; long B; int32_t *buf; int valid; int tag; } sched[16];   // tag 0: a batch of B aircraft;
                                                         // (lo << 16) | hi: the pairs of a horizon sweep (B = their number)

@@ -822,6 +822,28 @@ def test_dispatch_orders_do_not_change_results():
     assert res[0]["it"].min() >= 25 and res[0]["it"].max() > res[0]["it"].min()
 
 
+def test_more_batch_sizes_than_history_slots_on_one_context():
+    """The dispatch-order history has F16_MAX_SCHED = 16 slots per context ((stream, batch size) pairs): a 17th pair recycles the oldest
+    slot instead of running unordered for ever; results never depend on it."""
+    from f16_mpc_oop_py_amd import lib
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(64, seed=17)
+    ctx = lib.Context(0)
+    ref = {}
+    for rnd in range(2):
+        for B in range(20, 44):                                 # 24 batch sizes, twice round
+            env = make_env(x0[:B], u0[:B], xcg=0.35, context=ctx)
+            env.build_ssr()
+            u = env._calc_MPC_action(0.0, 0.0, 0.0, 6).cpu().numpy()
+            if rnd == 0:
+                ref[B] = u
+            else:
+                assert np.array_equal(u, ref[B], equal_nan=True)
+    fresh = make_env(x0[:20], u0[:20], xcg=0.35)
+    fresh.build_ssr()
+    assert np.array_equal(fresh._calc_MPC_action(0.0, 0.0, 0.0, 6).cpu().numpy(), ref[20], equal_nan=True)
+
+
 def test_first_solve_of_a_wide_plan_inside_a_capture():
     """Plans accept horizons 33..40 (every solve runs the long-horizon workgroup solver) and plan solves are capturable: the
     kernel's dynamic-LDS opt-in (hipFuncSetAttribute, not legal under capture) must therefore have happened in
