@@ -57,7 +57,8 @@ constexpr int P3_OFF = 0, P3_REC = 30, P3_SIZE = 22 * P3_REC;             // sta
 constexpr int P1_OFF = P3_OFF + P3_SIZE, P1_REC = 22, P1_SIZE = 64 * P1_REC;   // stage 1: record (lane) = [5 steps][3 sums + 1 pad] + 2: a record
                                                        // stride of 44 banks puts the 16 lanes of an LDS pass on 16 different groups of four banks (40: on 8)
 constexpr int ZP_OFF = P1_OFF + P1_SIZE;               // eight zeros: what an absent partial sum reads
-static_assert(ZP_OFF + 8 <= KB_OFF && (P1_OFF & 1) == 0 && (ZP_OFF & 1) == 0, "partial-sum records");
+constexpr int MVX_OFF = 0, MVX_REC = 14;               // mat-vec: the transposed parts of a lane (2 x 6 doubles + 2: 28 banks), in the records' space
+static_assert(ZP_OFF + 8 <= KB_OFF && (P1_OFF & 1) == 0 && (ZP_OFF & 1) == 0 && MVX_OFF + 64 * MVX_REC <= ZP_OFF, "partial-sum records");
 // scratch of the factorisation phases inside [0, KI_SIZE)
 constexpr int GL_OFF = 0, GL_SIZE = 27 * (WN + 1) + 1;                 // all nine rows of every G_k + a zero block
 constexpr int WG_OFF = GL_OFF + GL_SIZE, WG_SIZE = 6 * WN + 8;         // Gram weights of the kept state rows (zero padded)
@@ -306,6 +307,7 @@ __device__ __forceinline__ Consume consume_addresses(const Role &R) {
 
 // ---- y = M v for a symmetric block image: lane (r, s) holds blocks A = (r, cA) and Bk = (r, cB) and uses each twice -- y_r += B x_c
 // and y_c += B' x_r, the second fetched by its owner with ds_bpermute.  All four lanes of quad r receive y[6r..6r+5].
+template <bool VIA_LDS = false>
 __device__ __forceinline__ void sym_matvec_core(const double (&A)[6][6], const double (&Bk)[6][6], const double (&xr)[6],
                                                 const double (&xa)[6], const double (&xb)[6], const Role &R, double (&y)[6]) {
   const int rr = R.r < NB ? R.r : NB - 1;
@@ -326,6 +328,34 @@ __device__ __forceinline__ void sym_matvec_core(const double (&A)[6][6], const d
   }
   // the transposed products belong to block rows cA / cB: their quads fetch them (lane (c, s) from lane (c + k, s))
   const int srcA = 4 * ((rr + 2 * R.s + 1) % NB) + R.s, srcB = 4 * ((rr + 2 * R.s + 2) % NB) + R.s;
+  if (VIA_LDS) {
+    // ... through LDS records of 14 doubles per lane (six 16-byte writes, six 16-byte reads; the partial-sum records of the Toeplitz
+    // stages are dead while the mat-vec runs) instead of 24 ds_bpermute_b32: a bpermute costs the wave ~22 cycles under the
+    // contention of four waves per CU (tools/micro/w2_iteration.hip: 520 cycles of an iteration for the 24, 370 for this form)
+    double *o = s_w + MVX_OFF + R.l * MVX_REC;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      *reinterpret_cast<double2 *>(o + 2 * m) = make_double2(ytA[2 * m], ytA[2 * m + 1]);
+      *reinterpret_cast<double2 *>(o + 6 + 2 * m) = make_double2(ytB[2 * m], ytB[2 * m + 1]);
+    }
+    wave_lds_sync();
+    const double *pa = s_w + MVX_OFF + srcA * MVX_REC, *pb = s_w + MVX_OFF + srcB * MVX_REC + 6;
+    double qa[6], qb[6];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const double2 a = *reinterpret_cast<const double2 *>(pa + 2 * m), b = *reinterpret_cast<const double2 *>(pb + 2 * m);
+      qa[2 * m] = a.x; qa[2 * m + 1] = a.y; qb[2 * m] = b.x; qb[2 * m + 1] = b.y;
+    }
+    WAVE_LDS_PHASE();
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double sm = yd[j] + qa[j] + (R.s < 3 ? qb[j] : 0.0);
+      sm += dpp<DPP_XOR1>(sm);
+      sm += dpp<DPP_XOR2>(sm);
+      y[j] = sm;
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     const double pa = bperm(ytA[j], srcA), pb = bperm(ytB[j], srcB);
@@ -374,7 +404,7 @@ __device__ __forceinline__ void kkt_matvec(const double (&A)[6][6], const double
     xr[2 * m] = a.x; xr[2 * m + 1] = a.y; xa[2 * m] = b.x; xa[2 * m + 1] = b.y; xb[2 * m] = c.x; xb[2 * m + 1] = c.y;
   }
   WAVE_LDS_PHASE();
-  sym_matvec_core(A, Bk, xr, xa, xb, R, y);
+  sym_matvec_core<true>(A, Bk, xr, xa, xb, R, y);
 }
 // P x in the termination test: both blocks from the block image of P in the workspace (36 coalesced 16-byte loads), x from the
 // iteration's variable vector in LDS (four per step behind XPADS zero steps)

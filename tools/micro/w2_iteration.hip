@@ -26,18 +26,27 @@ __device__ __forceinline__ double bperm(double v, int src) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // one wavefront per aircraft (the shipped mapping): per iteration 150 + 144 + 150 FMAs, ~150 other fp64, 18 + 9 + 36 + ... LDS
 // operations, 24 bpermutes, five hand-overs through LDS
+// ABL: ablations of the one-wave model (what each ingredient of an iteration costs under real contention): 1 no ds_bpermute in the
+// mat-vec tail, 2 stage-1 totals from the lane's own sums (no records round trip), 3 the same for stage 3, 4 no projection arithmetic,
+// 5 both halves of the inverse in registers (no 16-byte LDS reads of the B blocks), 6 the transposed mat-vec parts exchanged through LDS
+// records (6 + 6 accesses of 16 bytes) instead of 24 ds_bpermute
+template <int ABL>
 __global__ __launch_bounds__(64, 1) void k_one(double *out, int iters) {
   __shared__ __attribute__((aligned(16))) double lds[5120];
   const int l = threadIdx.x;
   for (int i = l; i < 5120; i += 64) lds[i] = 1e-3 * (i % 97);
   __syncthreads();
-  double G[30], KA[36], x[3] = {0.1, 0.2, 0.3}, z[6] = {0, 0, 0, 0, 0, 0}, y[6] = {0, 0, 0, 0, 0, 0}, lc[24];
+  double G[30], KA[36], KB2[ABL == 5 ? 36 : 1], x[3] = {0.1, 0.2, 0.3}, z[6] = {0, 0, 0, 0, 0, 0}, y[6] = {0, 0, 0, 0, 0, 0}, lc[24];
 #pragma unroll
   for (int i = 0; i < 30; ++i) G[i] = 1e-3 * (i + l);
 #pragma unroll
   for (int i = 0; i < 36; ++i) KA[i] = 1e-3 * (i + 2 * l);
 #pragma unroll
   for (int i = 0; i < 24; ++i) lc[i] = 1.0 + 1e-3 * i;
+  if (ABL == 5) {
+#pragma unroll
+    for (int i = 0; i < 36; ++i) KB2[i] = 2e-3 * (i + l);
+  }
   const int job = l % 21, sp = l / 21;
   double *const rec1 = lds + 660 + l * 22, *const rec3 = lds + (l < 63 ? job : 21) * 30 + 2 * (sp % 3);
   const double *const w1 = lds + 4320 + 30 * (job % 6) + 2 * (sp % 3), *const w3 = lds + 4952 + 4 * (5 * (job % 6) + 3);
@@ -65,13 +74,16 @@ __global__ __launch_bounds__(64, 1) void k_one(double *out, int iters) {
     SYNC1();
     {   // totals: 9 x (16 B + 8 B) reads, 27 adds, one DPP exchange; rhs
       double t[3] = {0, 0, 0};
+      if (ABL == 2) { t[0] = rec1[0]; t[1] = rec1[1]; t[2] = rec1[2]; }
+      else {
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
         const d2_t a = *reinterpret_cast<const d2_t *>(lds + c1 + 22 * (k % 3) + 4 * (k / 3));
         t[0] += a.x; t[1] += a.y; t[2] += lds[c1 + 22 * (k % 3) + 4 * (k / 3) + 2];
       }
+      }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { t[c] += dpp<0xB1>(t[c]); lds[4764 + 3 * (l >> 1) + c] = lc[c] * x[c] - lc[3 + c] + t[c]; }
+      for (int c = 0; c < 3; ++c) { if (ABL != 2) t[c] += dpp<0xB1>(t[c]); lds[4764 + 3 * (l >> 1) + c] = lc[c] * x[c] - lc[3 + c] + t[c]; }
     }
     SYNC1();
     double xk[3];
@@ -79,8 +91,13 @@ __global__ __launch_bounds__(64, 1) void k_one(double *out, int iters) {
         // the allocator itself -- 36 live doubles too many), 24 bpermutes, quad reduction, write x~
       double Bk[36], xr[6], xa[6], xb[6];
       const d2_t *ki = reinterpret_cast<const d2_t *>(lds + 2160) + (l < 60 ? l : 59);
+      if (ABL == 5) {
+#pragma unroll
+        for (int m = 0; m < 36; ++m) Bk[m] = KB2[m];
+      } else {
 #pragma unroll
       for (int m = 0; m < 18; ++m) { const d2_t b = ki[m * 60]; Bk[2 * m] = b.x; Bk[2 * m + 1] = b.y; }
+      }
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
         const d2_t a = *reinterpret_cast<const d2_t *>(lds + 4764 + 6 * (l >> 2) % 84 + 2 * m), b = *reinterpret_cast<const d2_t *>(lds + 4764 + 6 * ((l >> 2) + 3) % 84 + 2 * m),
@@ -101,9 +118,21 @@ __global__ __launch_bounds__(64, 1) void k_one(double *out, int iters) {
         yd[i] = s0 + s1;
       }
       double y6[6];
+      if (ABL == 6) {   // the transposed parts through LDS records (14 doubles per lane: 28 banks) instead of 24 ds_bpermute
+        double *o = lds + l * 14;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { *reinterpret_cast<d2_t *>(o + 2 * m) = d2_t{ta[2 * m], ta[2 * m + 1]}; *reinterpret_cast<d2_t *>(o + 6 + 2 * m) = d2_t{tb[2 * m], tb[2 * m + 1]}; }
+        SYNC1();
+        const double *pa = lds + ((l + 4) & 63) * 14, *pb = lds + ((l + 8) & 63) * 14 + 6;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          const d2_t a = *reinterpret_cast<const d2_t *>(pa + 2 * m), b = *reinterpret_cast<const d2_t *>(pb + 2 * m);
+          ta[2 * m] = a.x; ta[2 * m + 1] = a.y; tb[2 * m] = b.x; tb[2 * m + 1] = b.y;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        double sm = yd[j] + bperm(ta[j], (l + 4) & 63) + bperm(tb[j], (l + 8) & 63);
+        double sm = (ABL == 1 || ABL == 6) ? yd[j] + ta[j] + tb[j] : yd[j] + bperm(ta[j], (l + 4) & 63) + bperm(tb[j], (l + 8) & 63);
         sm += dpp<0xB1>(sm); sm += dpp<0x4E>(sm);
         y6[j] = sm;
       }
@@ -138,10 +167,17 @@ __global__ __launch_bounds__(64, 1) void k_one(double *out, int iters) {
     SYNC1();
     {   // totals (18 reads of 8 B, 15 adds), projection of six rows, w writes
       double z3[3] = {0, 0, 0};
+      if (ABL == 3) { z3[0] = rec3[0]; z3[1] = rec3[1]; z3[2] = rec3[6]; }
+      else {
 #pragma unroll
       for (int T = 0; T < 6; ++T)
 #pragma unroll
         for (int c = 0; c < 3; ++c) z3[c] += lds[c3 + 30 * (T % 3) + c + 6 * (T / 3)];
+      }
+      if (ABL == 4) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { x[c] = xk[c]; z[c] = z3[c]; lds[4320 + 6 * (l >> 1) % 200 + c] = z3[c]; lds[4764 + 96 + 3 * (l >> 1) % 90 + c] = xk[c]; }
+      } else
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         x[c] = 1.6 * xk[c] - 0.6 * x[c];
@@ -317,7 +353,15 @@ static void run(const char *name, F kern, int block, int grid, int iters) {
 
 int main() {
   for (int rep = 0; rep < 2; ++rep) {
-    run("one wavefront per aircraft", k_one, 64, 4096, 400);
+    run("one wavefront per aircraft", k_one<0>, 64, 4096, 400);
+    if (rep == 1) {
+      run("  - without the 24 ds_bpermute", k_one<1>, 64, 4096, 400);
+      run("  - stage-1 totals without records", k_one<2>, 64, 4096, 400);
+      run("  - stage-3 totals without records", k_one<3>, 64, 4096, 400);
+      run("  - without the projection", k_one<4>, 64, 4096, 400);
+      run("  - B blocks in registers too", k_one<5>, 64, 4096, 400);
+      run("  - transposed parts through LDS", k_one<6>, 64, 4096, 400);
+    }
     run("two wavefronts per aircraft", k_two<true>, 128, 4096, 400);
     run("  ... without its six barriers (bound)", k_two<false>, 128, 4096, 400);
   }
