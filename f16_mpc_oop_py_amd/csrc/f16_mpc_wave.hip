@@ -888,6 +888,9 @@ __device__ __noinline__ int terminate_test(SolveState *st, const LaneConst *lcp,
     *reinterpret_cast<double2 *>(xk4) = make_double2(x[0], x[1]); xk4[2] = x[2];
   }
   wave_lds_sync();
+  // the lanes' Toeplitz operands: their loads go out together with the P image's (one round trip to the Infinity Cache instead of two)
+  double Gd[TB][2][3];
+  load_G_image(Gd, Gg, R.l);                                // (Gg: the per-lane image)
   double px[3];
   {
     double p6[6];
@@ -913,8 +916,6 @@ __device__ __noinline__ int terminate_test(SolveState *st, const LaneConst *lcp,
   double qu[3], cD[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) { qu[c] = R.act ? qv[kx + c] : 0.0; cD[c] = C.cs * (R.act ? Dv[kx + c] : 1.0); }
-  double Gd[TB][2][3];
-  load_G_image(Gd, Gg, R.l);                                // (Gg: the per-lane image)
   TSTAMP(1)
   double ax3[3], aty3[3], axB[3];
   stage3_partials(Gd, J);
