@@ -601,10 +601,24 @@ __device__ __forceinline__ void sweep_tile_row(d4_t (&acc)[NTILES], double *c0, 
   if (Kt + 1 < NT) publish_panel<(Kt + 1 < NT ? Kt + 1 : 0), 0>(acc, c0, lc, lq, l);
 }
 
+#ifdef F16_EXP_STAMPW
+__device__ unsigned long long g_wstamp[16];      // diagnostic build: cycles per phase of the iterations of workgroup 0, + counts
+__device__ unsigned long long g_tstamp[8];       // phases of the termination test
+#define TSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && threadIdx.x == 0) g_tstamp[i] += t1_ - tt0_; tt0_ = t1_; }
+#define WSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); tS[i] += t1_ - t0_; t0_ = t1_; }
+#else
+#define WSTAMP(i)
+#define TSTAMP(i)
+#endif
 // One KKT factorisation: K = c P + sigma D^-2 + rho A'WA as lower-triangular tiles (identity on the padding), the sweep, and
 // the scatter of the inverse into the symmetric block image in LDS (table KSCAT).  sg2v: sigma D^-2 per variable (LDS).
-__device__ __noinline__ bool factorise(const double *Pg, const double *gw, const double *sg2v, double *kimg, int N, double cs, double rho) {
+// (okp: an out-parameter in the caller's frame on purpose -- a call that passes no pointer into the caller's frame is marked as a
+// tail call, which switches the "no callee-saved registers" treatment of internal functions off: 248 scratch stores + loads per call.)
+__device__ __noinline__ void factorise(const double *Pg, const double *gw, const double *sg2v, double *kimg, int N, double cs, double rho, int *okp) {
   const int n = 3 * N, l = threadIdx.x, lc = l & 15, lq = l >> 4;
+#ifdef F16_EXP_STAMPW
+  unsigned long long tt0_ = __builtin_amdgcn_s_memtime();
+#endif
   d4_t acc[NTILES];
   {
     // one tile row at a time: all its loads (unconditional, clamped addresses) as one batch, then the arithmetic -- a load
@@ -641,6 +655,7 @@ __device__ __noinline__ bool factorise(const double *Pg, const double *gw, const
   bool ok = true;
   const double ndel = (lq == (lc & 3)) ? -1.0 : 0.0;
   wave_lds_sync();
+  TSTAMP(5)
   publish_panel<0, 0>(acc, c0, lc, lq, l);
   sweep_tile_row<0>(acc, c0, c1, lc, lq, l, ndel, ok);
   sweep_tile_row<1>(acc, c0, c1, lc, lq, l, ndel, ok);
@@ -649,6 +664,7 @@ __device__ __noinline__ bool factorise(const double *Pg, const double *gw, const
   sweep_tile_row<4>(acc, c0, c1, lc, lq, l, ndel, ok);
   sweep_tile_row<5>(acc, c0, c1, lc, lq, l, ndel, ok);
   wave_lds_sync();
+  TSTAMP(6)
   // acc = MINUS the inverse: scatter into the block image (the panels are dead); the table entries of a tile row as one batch
 #pragma unroll
   for (int w = 0; w < NT; ++w) {
@@ -671,7 +687,8 @@ __device__ __noinline__ bool factorise(const double *Pg, const double *gw, const
   wave_lds_sync();
   store_KA_image(kimg, l);                                  // the A blocks: to the workspace (registers of the hot loop); their half
   wave_lds_sync();                                          // of the LDS image is the iterations' partial-sum space from here on
-  return __ballot(!ok) == 0;
+  TSTAMP(7)
+  *okp = __ballot(!ok) == 0 ? 1 : 0;
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -684,15 +701,6 @@ __device__ __noinline__ bool factorise(const double *Pg, const double *gw, const
 __device__ __forceinline__ double uniform_f64(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
-#ifdef F16_EXP_STAMPW
-__device__ unsigned long long g_wstamp[16];      // diagnostic build: cycles per phase of the iterations of workgroup 0, + counts
-__device__ unsigned long long g_tstamp[8];       // phases of the termination test
-#define TSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && threadIdx.x == 0) g_tstamp[i] += t1_ - tt0_; tt0_ = t1_; }
-#define WSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); tS[i] += t1_ - t0_; t0_ = t1_; }
-#else
-#define WSTAMP(i)
-#define TSTAMP(i)
-#endif
 
 template <bool ANYEQ>
 struct RowOps {                                  // per-row rho and 1 / rho of a lane's six rows
@@ -726,10 +734,22 @@ struct RowSlots {                                // where a lane's rows live in 
 // the lane's variable step (and the one before it) of the x vector in LDS: four doubles per step behind XPADS zero steps
 __device__ __forceinline__ double *x4_step(int step) { return s_w + XT_OFF + 4 * (step + XPADS); }
 
-// nrun >= 1 iterations from the state in *st (w of that point is in LDS); leaves the state, the dual step of the last
-// iteration and w of the new point.
+// Iterations from the state in *st (w of that point is in LDS) up to the next termination test that needs MORE than the
+// primal side, block of check_every iterations after block.  After every block the primal half of OSQP's test runs here,
+// on the operands this function holds anyway (A x of the new point by one more stage 3, the primal residual and its scale,
+// the two scalars of the primal-infeasibility certificate): the test cannot pass while the primal residual is above its
+// bound, so on a block end that is no rho-update iteration, not the last iteration and no certificate candidate the
+// decision is "go on" whatever P x and A' y are -- same decisions as evaluating everything, and the P image (37 KB from the
+// Infinity Cache), the second Toeplitz pass and the reload of this function's operands are paid on a third of the block ends
+// (config-4 batch: 5.6 of 18.3).  Leaves the state, the dual step of the last iteration, w of the new point, st->it / to_check.
 template <bool ANYEQ>
-__device__ __noinline__ void run_iterations(SolveState *st, const LaneConst *lcp, const double *Gg, const double *kimg, int N, double alpha, int nrun) {
+__device__ __noinline__ void run_iterations(SolveState *st, const LaneConst *lcp, const double *Gg, const double *kimg, int N, IterSettings oa) {
+  IterSettings o;                                           // (arguments of a device function arrive in vector registers)
+  o.alpha = uniform_f64(oa.alpha); o.eps_abs = uniform_f64(oa.eps_abs); o.eps_rel = uniform_f64(oa.eps_rel);
+  o.eps_prim_inf = uniform_f64(oa.eps_prim_inf);
+  o.max_iter = __builtin_amdgcn_readfirstlane(oa.max_iter); o.check_every = __builtin_amdgcn_readfirstlane(oa.check_every);
+  o.rho_every = __builtin_amdgcn_readfirstlane(oa.rho_every); o.adaptive_rho = __builtin_amdgcn_readfirstlane(oa.adaptive_rho);
+  const double alpha = o.alpha;
   const Role R = role(N);
   const TJob J = tjob();
   const Consume Q = consume_addresses(R);
@@ -827,8 +847,48 @@ __device__ __noinline__ void run_iterations(SolveState *st, const LaneConst *lcp
     wave_lds_sync();
     WSTAMP(6)
   };
-  for (; nrun > 1; --nrun) iteration(std::false_type{});
-  iteration(std::true_type{});
+  int it = __builtin_amdgcn_readfirstlane(st->it), to_check = __builtin_amdgcn_readfirstlane(st->to_check);     // (scalar loop counters)
+  double rp = INFINITY;
+  for (;;) {
+    const int left = o.max_iter - it;
+    const int nrun = left < to_check ? left : to_check;       // iterations up to the next test (>= 1)
+    for (int k = nrun; k > 1; --k) iteration(std::false_type{});     // (a single loop body that always keeps the dual step: 1 % slower)
+    iteration(std::true_type{});
+    it += nrun; to_check -= nrun;
+    if (to_check == 0) to_check = o.check_every;
+    // primal half of the test (terminate_test: same expressions on the same operands)
+    if (wrx) {
+      double *const xw = x4_step(R.istep);
+      *reinterpret_cast<double2 *>(xw) = make_double2(x[0], x[1]); xw[2] = x[2];
+    }
+    wave_lds_sync();
+    stage3_partials(Gd, J);
+    wave_lds_sync();
+    double ax3[3], v0 = 0.0, v12 = 0.0, v7 = 0.0, v8 = 0.0;
+    stage3_totals(Q.a3, ax3);
+    if (R.act) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double xkk = xk4[c], xkm = xk4[c - 4];
+        const double axB = R.par ? xkk - xkm : xkk;
+        v0 = fmax(v0, fmax(fabs(ax3[c] - zA[c]), fabs(axB - zB[c])));
+        v12 = fmax(v12, fmax(fmax(fabs(ax3[c]), fabs(axB)), fmax(fabs(zA[c]), fabs(zB[c]))));
+        v7 = fmax(v7, fmax(C.WA[c] * fabs(dyA[c]), C.WB[c] * fabs(dyB[c])));
+        v8 += C.WA[c] * (C.hiA[c] * fmax(dyA[c], 0.0) + C.loA[c] * fmin(dyA[c], 0.0)) +
+              C.WB[c] * (C.hiB[c] * fmax(dyB[c], 0.0) + C.loB[c] * fmin(dyB[c], 0.0));
+      }
+    }
+    v0 = wave_reduce_dpp<false>(v0); v12 = wave_reduce_dpp<false>(v12);
+    v7 = wave_reduce_dpp<false>(v7); v8 = wave_reduce_dpp<true>(v8);
+    rp = v0;
+    const bool prim_ok = rp < o.eps_abs + o.eps_rel * v12;
+    const bool cert = v7 > o.eps_prim_inf && v8 < -o.eps_prim_inf * v7;
+    const bool full = prim_ok || cert || it >= o.max_iter || (o.adaptive_rho && it % o.rho_every == 0);
+    WSTAMP(7)
+    if (__builtin_amdgcn_readfirstlane((int)full)) break;   // (wave-uniform: the reductions leave the same value on every lane)
+    wave_lds_sync();                                          // (the x~ buffer and the stage-3 records are rewritten by the next iteration)
+  }
+  st->it = it; st->to_check = to_check; st->rp = rp;
 #pragma unroll
   for (int c = 0; c < 3; ++c) { st->x[c] = x[c]; st->zA[c] = zA[c]; st->yA[c] = yA[c]; st->zB[c] = zB[c]; st->yB[c] = yB[c];
                                 st->dyA[c] = dyA[c]; st->dyB[c] = dyB[c]; }
@@ -1034,19 +1094,17 @@ __device__ __forceinline__ bool solve_loop(SolveState *st, const LaneConst *lcp,
 #else
 #define WSTAMPK(i, j)
 #endif
-    ok = factorise(Pg, gw, xt + XT_PAD, const_cast<double *>(Gg) + GIMG_DOUBLES, N, cs, st->rho) && ok;
+    int fok = 0;
+    factorise(Pg, gw, xt + XT_PAD, const_cast<double *>(Gg) + GIMG_DOUBLES, N, cs, st->rho, &fok);
+    ok = fok != 0 && ok;
     WSTAMPK(10, 12)
     if (!ok) break;
     start_point<ANYEQ>(st, lcp, N);
     bool refactor = false;
     while (!st->done && !refactor) {
-      const int left = o.max_iter - st->it;
-      const int nrun = left < st->to_check ? left : st->to_check;       // iterations up to the next test (>= 1)
       WSTAMPK(14, 15)
-      run_iterations<ANYEQ>(st, lcp, Gg, Gg + GIMG_DOUBLES, N, o.alpha, nrun);
+      run_iterations<ANYEQ>(st, lcp, Gg, Gg + GIMG_DOUBLES, N, o);      // (to the next block end whose test needs the dual side too)
       WSTAMPK(13, 15)
-      st->it += nrun; st->to_check -= nrun;
-      if (st->to_check == 0) st->to_check = o.check_every;
       refactor = terminate_test<ANYEQ>(st, lcp, pb, Gg, qv, Dv, N, o) != 0;
       WSTAMPK(9, 11)
     }
@@ -1418,7 +1476,7 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
     for (int i = 0; i < 8; ++i) a.useq[(60 + i) * a.ld + b] = (double)g_wstamp[i];
     a.useq[68 * a.ld + b] = (double)st.it;
     for (int i = 9; i < 16; ++i) a.useq[(60 + 12 + i - 9) * a.ld + b] = (double)g_wstamp[i];
-    for (int i = 0; i < 5; ++i) a.useq[(80 + i) * a.ld + b] = (double)g_tstamp[i];
+    for (int i = 0; i < 8; ++i) a.useq[(80 + i) * a.ld + b] = (double)g_tstamp[i];
     a.useq[71 * a.ld + b] = (double)(__builtin_amdgcn_s_memtime() - tK0);
   }
 #endif

@@ -17,7 +17,7 @@ for _ in range(2):
 s = info["u_seq"][0, 60:72].cpu().numpy()
 e = info["u_seq"][0, 72:79].cpu().numpy()      # 9..15: test cycles, factorise cycles, #tests, #factorisations, run_iterations cycles, other, -
 it = s[8]
-names = ["A stage1+rhs", "sync", "B matvec", "sync+xt+sync", "C stage3", "projection", "w+sync", "loop"]
+names = ["A stage1+rhs", "sync", "B matvec", "sync+xt+sync", "C stage3", "projection", "w+sync", "loop+primal test"]
 print(f"aircraft 0: {it:.0f} iterations (info: {float(info['iters'][0]):.0f}); cycles per iteration:")
 for n, v in zip(names, s[:8]):
     print(f"   {n:14s} {v / it:8.0f}")
@@ -25,3 +25,5 @@ print(f"   total          {s[:8].sum() / it:8.0f}")
 print(f"tests: {e[2]:.0f} x {e[0] / max(e[2], 1):.0f} cycles; factorisations: {e[3]:.0f} x {e[1] / max(e[3], 1):.0f} cycles; run_iterations calls total {e[4]:.0f} cycles; other {e[5]:.0f}; whole kernel (workgroup 0) {s[11]:.0f} cycles")
 t = info["u_seq"][0, 80:85].cpu().numpy()
 print("termination test, cycles per test: P x %.0f | W y + G load %.0f | A x, A'y %.0f | norms + reductions %.0f | decision + w %.0f" % tuple(t / max(e[2], 1)))
+f = info["u_seq"][0, 85:88].cpu().numpy()
+print("factorisation, cycles per call: K from P and A'WA %.0f | sweep (24 pivot blocks) %.0f | scatter + A-block image %.0f" % tuple(f / max(e[3], 1)))
