@@ -601,6 +601,12 @@ __device__ __forceinline__ void sweep_tile_row(d4_t (&acc)[NTILES], double *c0, 
   if (Kt + 1 < NT) publish_panel<(Kt + 1 < NT ? Kt + 1 : 0), 0>(acc, c0, lc, lq, l);
 }
 
+// (Round 4, measured and not kept: the six products that feed the next pivot's rows first, the other fifteen pinned one at a time
+// between the pieces of the 4 x 4 inverse -- 90.6 k against 92.2 k cycles per sweep, because there is no shadow to work in:
+// v_mfma_f64_16x16x4_f64 holds the wave for 64 cycles and every fp64 vector FMA issued between two products ADDS its ~7 cycles
+// (tools/micro/mfma_f64_rate.hip: 64.0 / 92.5 / 112.5 / 132.5 cycles per product with 0 / 4 / 8 / 12 FMAs behind it) -- the fp64
+// matrix instruction runs on the same fp64 lanes as the vector FMA.  A variant that computes the next pivot block ahead of the
+// products, D' - C' D^-1 C'^T, to save the second sync of a step was slower for the same reason: 109 k.)
 #ifdef F16_EXP_STAMPW
 __device__ unsigned long long g_wstamp[16];      // diagnostic build: cycles per phase of the iterations of workgroup 0, + counts
 __device__ unsigned long long g_tstamp[8];       // phases of the termination test
@@ -621,12 +627,25 @@ __device__ __noinline__ void factorise(const double *Pg, const double *gw, const
 #endif
   d4_t acc[NTILES];
   {
-    // one tile row at a time: all its loads (unconditional, clamped addresses) as one batch, then the arithmetic -- a load
-    // under a lane condition becomes a branch around it and every element then waits out its own memory round trip
+    // TWO batches of loads (unconditional, clamped addresses) for the whole matrix, then the arithmetic: a load under a lane
+    // condition becomes a branch around it and every element then waits out its own memory round trip; a batch per tile row
+    // (round 3) was six round trips to the Infinity Cache in sequence
     const gptr_t Pgg = as_global(Pg), gwg = as_global(gw);
+    double dg[NT][4];
 #pragma unroll
-    for (int w = 0; w < NT; ++w) {
-      double pv[NT][4], gv[NT][4], dg[4];
+    for (int w = 0; w < NT; ++w)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) { const int i = 16 * w + 4 * qq + lq; dg[w][qq] = sg2v[i < n ? i : 0]; }
+#pragma unroll
+    for (int w = 0; w < NT; ++w)
+#pragma unroll
+      for (int J = 0; J <= w; ++J)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) acc[tile_idx(w, J)][qq] = gwg[(tile_idx(w, J) * 4 + qq) * 64 + l];
+    __builtin_amdgcn_sched_barrier(0);
+    double pv[NTILES][4];
+#pragma unroll
+    for (int w = 0; w < NT; ++w)
 #pragma unroll
       for (int J = 0; J <= w; ++J)
 #pragma unroll
@@ -634,22 +653,20 @@ __device__ __noinline__ void factorise(const double *Pg, const double *gw, const
           const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
           const bool in = i < n && j < n;
           const int hi_ = i >= j ? i : j, lo_ = i >= j ? j : i;
-          pv[J][qq] = Pgg[in ? hi_ * (hi_ + 1) / 2 + lo_ : 0];
-          gv[J][qq] = gwg[(tile_idx(w, J) * 4 + qq) * 64 + l];
+          pv[tile_idx(w, J)][qq] = Pgg[in ? hi_ * (hi_ + 1) / 2 + lo_ : 0];
         }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) { const int i = 16 * w + 4 * qq + lq; dg[qq] = sg2v[i < n ? i : 0]; }
-      __builtin_amdgcn_sched_barrier(0);
+    for (int w = 0; w < NT; ++w)
 #pragma unroll
       for (int J = 0; J <= w; ++J)
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
           const int i = 16 * w + 4 * qq + lq, j = 16 * J + lc;
           const bool in = i < n && j < n;
-          const double kin = cs * pv[J][qq] + rho * gv[J][qq] + (i == j ? dg[qq] : 0.0);
+          const double kin = cs * pv[tile_idx(w, J)][qq] + rho * acc[tile_idx(w, J)][qq] + (i == j ? dg[w][qq] : 0.0);
           acc[tile_idx(w, J)][qq] = in ? kin : (i == j ? 1.0 : 0.0);
         }
-    }
   }
   double *c0 = s_w + PAN_OFF, *c1 = s_w + PAN_OFF + PAN_SIZE;
   bool ok = true;
@@ -665,21 +682,20 @@ __device__ __noinline__ void factorise(const double *Pg, const double *gw, const
   sweep_tile_row<5>(acc, c0, c1, lc, lq, l, ndel, ok);
   wave_lds_sync();
   TSTAMP(6)
-  // acc = MINUS the inverse: scatter into the block image (the panels are dead); the table entries of a tile row as one batch
+  // acc = MINUS the inverse: scatter into the block image (the panels are dead); the table entries of all tiles as one batch
+  {
+    unsigned dd[NTILES][4];
 #pragma unroll
-  for (int w = 0; w < NT; ++w) {
-    unsigned dd[NT][4];
+    for (int t = 0; t < NTILES; ++t)
 #pragma unroll
-    for (int J = 0; J <= w; ++J)
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) dd[J][qq] = F16_WAVE_KSCAT[(tile_idx(w, J) * 4 + qq) * 64 + l];
+      for (int qq = 0; qq < 4; ++qq) dd[t][qq] = F16_WAVE_KSCAT[(t * 4 + qq) * 64 + l];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int J = 0; J <= w; ++J)
+    for (int t = 0; t < NTILES; ++t)
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
-        const unsigned d0 = dd[J][qq] & 0xFFFFu, d1 = dd[J][qq] >> 16;
-        const double v = -acc[tile_idx(w, J)][qq];
+        const unsigned d0 = dd[t][qq] & 0xFFFFu, d1 = dd[t][qq] >> 16;
+        const double v = -acc[t][qq];
         if (d0 != 0xFFFFu) s_w[d0] = v;
         if (d1 != 0xFFFFu) s_w[d1] = v;
       }
