@@ -64,6 +64,9 @@ struct MpcArgs {
   int wave_ruiz;              // wavefront solver: equilibrate in the solver itself (else: k_mpc_fast mode 3 went before it)
   unsigned wave_stride;       // wavefront solver without a dispatch order: workgroup w solves aircraft (w * wave_stride) % B, a
                               // stride coprime to B (0: the identity)
+  unsigned *wave_queue;       // wavefront solver: work-queue counter (zeroed on the stream before the launch): the grid is one
+                              // workgroup per SIMD and every workgroup takes the next aircraft of the dispatch order when it is free;
+                              // null: one workgroup per aircraft (the hardware's own distribution)
   int mode;                   // 0 one-shot; 1 prepare (build + factor, keep everything, no iterations); 2 solve from a plan;
                               // 3 equilibration only: D | E | c -> gramws + WAVE_SCAL_OFF (for the wavefront solver)
   double *warm;               // plans with warm start: [B][MPC_WARM_DOUBLES] x, z, y of the previous solve (per lane)

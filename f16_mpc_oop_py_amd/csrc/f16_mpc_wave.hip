@@ -71,6 +71,7 @@ static_assert((PAN_OFF & 1) == 0 && (PAN_SIZE & 1) == 0 && (XT_OFF & 1) == 0 && 
 // ---- per-aircraft workspace in HBM (the `gramws` block of MpcArgs, MPC_TILE_DOUBLES = 9216 doubles)
 constexpr int GW_TILES = 0;                            // [21][4][64] A'WA as lower-triangular tiles
 constexpr int GW_SCAL = WAVE_SCAL_OFF;                 // D[96] | E state [192] | E command [96] | E rate [96] | c   (k_mpc_fast mode 3)
+constexpr int GW_QUEUE = 484;                          // (behind D | E | c of the scaling block: the work-queue counter of a launch, in aircraft 0's block)
 static_assert(NTILES * 256 <= WAVE_SCAL_OFF && WAVE_SCAL_OFF + 488 <= MPC_TILE_DOUBLES, "workspace map");
 
 __shared__ __attribute__((aligned(16))) double s_w[LDS_DOUBLES];
@@ -608,9 +609,11 @@ __device__ __forceinline__ void sweep_tile_row(d4_t (&acc)[NTILES], double *c0, 
 // matrix instruction runs on the same fp64 lanes as the vector FMA.  A variant that computes the next pivot block ahead of the
 // products, D' - C' D^-1 C'^T, to save the second sync of a step was slower for the same reason: 109 k.)
 #ifdef F16_EXP_STAMPW
+__device__ int g_stamp_wg = -1;                  // the workgroup that solves job 0 of the launch (while it does)
+#define STAMP_WG() (blockIdx.x == g_stamp_wg)
 __device__ unsigned long long g_wstamp[16];      // diagnostic build: cycles per phase of the iterations of workgroup 0, + counts
 __device__ unsigned long long g_tstamp[8];       // phases of the termination test
-#define TSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && threadIdx.x == 0) g_tstamp[i] += t1_ - tt0_; tt0_ = t1_; }
+#define TSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); if (STAMP_WG() && threadIdx.x == 0) g_tstamp[i] += t1_ - tt0_; tt0_ = t1_; }
 #define WSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); tS[i] += t1_ - t0_; t0_ = t1_; }
 #else
 #define WSTAMP(i)
@@ -909,7 +912,7 @@ __device__ __noinline__ void run_iterations(SolveState *st, const LaneConst *lcp
   for (int c = 0; c < 3; ++c) { st->x[c] = x[c]; st->zA[c] = zA[c]; st->yA[c] = yA[c]; st->zB[c] = zB[c]; st->yB[c] = yB[c];
                                 st->dyA[c] = dyA[c]; st->dyB[c] = dyB[c]; }
 #ifdef F16_EXP_STAMPW
-  if (blockIdx.x == 0 && R.l == 0)
+  if (STAMP_WG() && R.l == 0)
     for (int i = 0; i < 8; ++i) g_wstamp[i] += tS[i];
 #endif
 }
@@ -1106,7 +1109,7 @@ __device__ __forceinline__ bool solve_loop(SolveState *st, const LaneConst *lcp,
     wave_lds_sync();
 #ifdef F16_EXP_STAMPW
     unsigned long long tq0 = __builtin_amdgcn_s_memtime();
-#define WSTAMPK(i, j) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long tq1 = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && R.l == 0) { g_wstamp[i] += tq1 - tq0; g_wstamp[j] += 1; } tq0 = tq1; }
+#define WSTAMPK(i, j) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long tq1 = __builtin_amdgcn_s_memtime(); if (STAMP_WG() && R.l == 0) { g_wstamp[i] += tq1 - tq0; g_wstamp[j] += 1; } tq0 = tq1; }
 #else
 #define WSTAMPK(i, j)
 #endif
@@ -1353,19 +1356,35 @@ __device__ __noinline__ void p_block_image(const double *Pg, double *pb, int n) 
 // ----------------------------------------------------------------------------------------------------------------
 // The solve of one aircraft per wavefront-workgroup (grid = B).  D, E, c of the equilibration come from the workspace
 // (k_mpc_fast, scale-only mode), P / q / G_k / pred from the build kernel (k_mpc<true>).
+// Dispatch (round 4): the hardware hands workgroups to the XCDs, and inside an XCD to its four shader engines, ROUND-ROBIN -- 32
+// static partitions of 32 SIMDs that each work through their own 128 aircraft (tools/gpu_wave_timeline.py: every shader engine
+// solves exactly B / 32 aircraft, 996 of 1024 SIMDs exactly four), so the longest-first order is greedy only inside a partition and
+// the launch ends when the unluckiest partition does: 7.96 ms where one greedy queue over all 1024 SIMDs needs 7.53 (simulated from
+// the measured durations of the same launch).  With `wave_queue` the grid is one workgroup per SIMD and the queue is ours: a
+// workgroup takes the next aircraft of the dispatch order from an atomic counter whenever it is free, until the counter passes B
+// (an exit every workgroup reaches, whatever the number of resident ones).
 __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
-#ifdef F16_EXP_STAMPW
-  const unsigned long long wc0_ = wall_clock64();
-#endif
   const int N = a.N, n = 3 * N;
   const Role R = role(N);
   const int l = R.l;
+  for (long job = blockIdx.x;; ) {
+  if (a.wave_queue) {
+    unsigned q = 0;
+    if (l == 0) q = atomicAdd(a.wave_queue, 1u);
+    job = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)q);
+    if (job >= a.B) break;
+    wave_lds_sync();                                         // (the previous aircraft's LDS traffic is over on every lane)
+  }
+#ifdef F16_EXP_STAMPW
+  const unsigned long long wc0_ = wall_clock64();
+  if (job == 0 && l == 0) g_stamp_wg = (int)blockIdx.x;
+#endif
   // No order from a previous call (first call on this stream / batch size): NOT the caller's order either -- workgroup ids go to
   // the XCDs round-robin, and how hard an aircraft is tends to follow its index (the config-4 workload: every aircraft = 0, 3, 6
   // mod 8 needs twice the iterations), so the identity gives three XCDs twice the work of the others.  A fixed stride coprime to
   // B spreads any such pattern; the results do not depend on the map.
-  const long b = a.order ? (long)__builtin_amdgcn_readfirstlane(a.order[blockIdx.x])
-                         : (a.wave_stride ? (long)(((unsigned long long)blockIdx.x * a.wave_stride) % (unsigned long long)a.B) : (long)blockIdx.x);
+  const long b = a.order ? (long)__builtin_amdgcn_readfirstlane(a.order[job])
+                         : (a.wave_stride ? (long)(((unsigned long long)job * a.wave_stride) % (unsigned long long)a.B) : job);
   double *const exw = a.ext + (size_t)b * mpc_ext_doubles(N);
   const double *Pg = a.Ppk + (size_t)b * (n * (n + 1) / 2);
   const double *Gg = exw + n, *pred = exw + n + 27 * N;
@@ -1460,8 +1479,8 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
     }
   }
 #ifdef F16_EXP_STAMPW
-  if (blockIdx.x == 0 && l < 16) g_wstamp[l] = 0;
-  if (blockIdx.x == 0 && l < 8) g_tstamp[l] = 0;
+  if (job == 0 && l < 16) g_wstamp[l] = 0;
+  if (job == 0 && l < 8) g_tstamp[l] = 0;
   const unsigned long long tK0 = __builtin_amdgcn_s_memtime();
 #endif
   IterSettings o;
@@ -1488,7 +1507,7 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
     }
   }
 #ifdef F16_EXP_STAMPW
-  if (blockIdx.x == 0 && l == 0 && a.useq) {      // diagnostic build: the stamps replace rows 60.. of this aircraft's u_seq column
+  if (job == 0 && l == 0 && a.useq) {      // diagnostic build: the stamps replace rows 60.. of this aircraft's u_seq column
     for (int i = 0; i < 8; ++i) a.useq[(60 + i) * a.ld + b] = (double)g_wstamp[i];
     a.useq[68 * a.ld + b] = (double)st.it;
     for (int i = 9; i < 16; ++i) a.useq[(60 + 12 + i - 9) * a.ld + b] = (double)g_wstamp[i];
@@ -1506,10 +1525,16 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
 #ifdef F16_EXP_STAMPW
       a.info[1 * a.ld + b] = (double)wc0_;                 // diagnostic build: start / end of this solve on the 100 MHz clock
       a.info[2 * a.ld + b] = (double)wall_clock64();
+      a.info[3 * a.ld + b] = (double)((__builtin_amdgcn_s_getreg(63508) & 15) * 65536 + (__builtin_amdgcn_s_getreg(63492) & 0xFFFF));    // XCC_ID | HW_ID: which SIMD
 #endif
     }
     if (a.status && infeasible) a.status[b] |= F16_ST_QP_INFEASIBLE;
     else if (a.status && (!converged || !ok)) a.status[b] |= F16_ST_QP_MAXITER;
+  }
+#ifdef F16_EXP_STAMPW
+  if (job == 0 && l == 0) g_stamp_wg = -1;
+#endif
+  if (!a.wave_queue) break;
   }
 }
 
@@ -1532,7 +1557,24 @@ int mpc_wave_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
     for (unsigned p : primes)
       if (a.B % p != 0) { w.wave_stride = p; break; }
   }
-  hipLaunchKernelGGL(wave::k_mpc_wave, dim3((unsigned)a.B), dim3(64), 0, (hipStream_t)stream, w);
+  // one workgroup per SIMD and a work queue of our own (see k_mpc_wave); the counter is the spare slot behind the scaling block of
+  // aircraft 0's workspace.  F16_MPC_WAVE_QUEUE=0: one workgroup per aircraft, distributed by the hardware.
+  static const bool queue = [] { const char *e = getenv("F16_MPC_WAVE_QUEUE"); return !(e && e[0] == '0'); }();
+  unsigned grid = (unsigned)a.B;
+  w.wave_queue = nullptr;
+  if (queue) {
+    static const int cus = [] {                              // (one GPU model per process: asked once)
+      int dev = 0, n = 0;
+      return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? n : 0;
+    }();
+    if (cus > 0 && a.B > 4L * cus) {
+      w.wave_queue = reinterpret_cast<unsigned *>(a.gramws + wave::GW_SCAL + wave::GW_QUEUE);
+      int rc = hip_check(hipMemsetAsync(w.wave_queue, 0, sizeof(unsigned), (hipStream_t)stream), "f16_mpc_batch work-queue counter");
+      if (rc) return rc;
+      grid = 4u * (unsigned)cus;
+    }
+  }
+  hipLaunchKernelGGL(wave::k_mpc_wave, dim3(grid), dim3(64), 0, (hipStream_t)stream, w);
   return hip_check(hipGetLastError(), "f16_mpc_batch wavefront solve launch");
 }
 
