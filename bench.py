@@ -502,6 +502,9 @@ def bench_mpc(args, dev, rank, world, fdist, barrier):
     del os.environ["F16_MPC_DISPATCH_ORDER"]
     res["dispatch"] = {"order": "longest-first by the previous call's iteration counts (any order gives the same results); a first call: "
                                 "longest-first by ||q||_inf of the QPs just built",
+                       "queue": ("one workgroup per SIMD takes the next aircraft of that order from an atomic counter"
+                                 if os.environ.get("F16_MPC_WAVE_QUEUE", "1")[:1] != "0" else
+                                 "F16_MPC_WAVE_QUEUE=0: one workgroup per aircraft, dealt round-robin to 32 (XCD, shader engine) partitions by the hardware"),
                        "value_in_caller_order": world * B / dco, "ms_per_batch_in_caller_order": dco * 1e3,
                        "value_first_call": world * B / dfirst, "ms_per_batch_first_call": dfirst * 1e3}
     res["first_call_value"] = world * B / dfirst
