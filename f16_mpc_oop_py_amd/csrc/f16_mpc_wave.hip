@@ -527,8 +527,9 @@ __device__ __forceinline__ double sel4(double v0, double v1, double v2, double v
   return (k & 2) ? hi : lo;
 }
 // pan: C[col][0..3] = M[pivot row][col] (FN x 4) | D^-1 (4 x 4) | ok flag.  Publish pivots 16 Kt + 4 KQ .. + 3 from the tiles.
+struct PivInv { double2 a0, a1; double dpiv; };      // row l / 16 of the pivot block's inverse, and its element (l / 16, l % 4)
 template <int Kt, int KQ>
-__device__ __forceinline__ void publish_panel(const d4_t (&acc)[NTILES], double *pan, int lc, int lq, int l) {
+__device__ __forceinline__ void publish_panel(const d4_t (&acc)[NTILES], double *pan, int lc, int lq, PivInv &P, bool &ok) {
   // the part of the pivot rows left of and inside the diagonal tile: tile row Kt, register KQ
 #pragma unroll
   for (int J = 0; J <= Kt; ++J) pan[(16 * J + lc) * 4 + lq] = acc[tile_idx(Kt, J)][KQ];
@@ -547,25 +548,21 @@ __device__ __forceinline__ void publish_panel(const d4_t (&acc)[NTILES], double 
     const double2 u = src[2 * i], v = src[2 * i + 1];
     D[i][0] = u.x; D[i][1] = u.y; D[i][2] = v.x; D[i][3] = v.y;
   }
+  // every lane holds the inverse: what it needs of it (row l / 16, one element of that row) comes by selects -- round 3 wrote it to the
+  // panel and read it back behind a second sync (~250 cycles of a pivot step)
   const bool good = inv4_spd(D, Di);
-  if (l < 4) {
-    double2 *dst = reinterpret_cast<double2 *>(pan + PAN_DI + 4 * l);
-    dst[0] = make_double2(sel4(Di[0][0], Di[1][0], Di[2][0], Di[3][0], l), sel4(Di[0][1], Di[1][1], Di[2][1], Di[3][1], l));
-    dst[1] = make_double2(sel4(Di[0][2], Di[1][2], Di[2][2], Di[3][2], l), sel4(Di[0][3], Di[1][3], Di[2][3], Di[3][3], l));
-    if (l == 0) pan[PAN_OK] = good ? 1.0 : 0.0;
-  }
-  wave_lds_sync();
+  ok = ok && good;
+  P.a0 = make_double2(sel4(Di[0][0], Di[1][0], Di[2][0], Di[3][0], lq), sel4(Di[0][1], Di[1][1], Di[2][1], Di[3][1], lq));
+  P.a1 = make_double2(sel4(Di[0][2], Di[1][2], Di[2][2], Di[3][2], lq), sel4(Di[0][3], Di[1][3], Di[2][3], Di[3][3], lq));
+  P.dpiv = sel4(P.a0.x, P.a0.y, P.a1.x, P.a1.y, lc & 3);
 }
 template <int Kt, int KQ>
-__device__ __forceinline__ void sweep_step(d4_t (&acc)[NTILES], const double *cb, int lc, int lq, double ndel, bool &ok) {
+__device__ __forceinline__ void sweep_step(d4_t (&acc)[NTILES], const double *cb, int lc, int lq, double ndel, const PivInv &P) {
   const bool pl = (lc >> 2) == KQ;                       // this lane's column (within a tile) is a pivot column
-  double2 a0, a1;
   double a_op[NT], b_op[NT];
   {
-    const double2 *ra = reinterpret_cast<const double2 *>(cb + PAN_DI + 4 * lq);       // row l/16 of D^-1
-    a0 = ra[0]; a1 = ra[1];
-    const double okf = cb[PAN_OK];
-    const double dpiv = cb[PAN_DI + 4 * lq + (lc & 3)];
+    const double2 a0 = P.a0, a1 = P.a1;                  // row l/16 of D^-1
+    const double dpiv = P.dpiv;
 #pragma unroll
     for (int w = 0; w < NT; ++w) {
       const double2 *src = reinterpret_cast<const double2 *>(cb + (16 * w + lc) * 4);
@@ -573,7 +570,6 @@ __device__ __forceinline__ void sweep_step(d4_t (&acc)[NTILES], const double *cb
       a_op[w] = -(c0.x * a0.x + c0.y * a0.y + c1.x * a1.x + c1.y * a1.y);
       b_op[w] = cb[(16 * w + lc) * 4 + lq];
     }
-    ok = ok && okf > 0.5;
     if (pl) { a_op[Kt] = dpiv; b_op[Kt] = ndel; }
   }
   // pivot columns (tile column Kt, tile rows Kt..) and pivot rows (tile row Kt, register KQ) start from zero
@@ -590,16 +586,16 @@ __device__ __forceinline__ void sweep_step(d4_t (&acc)[NTILES], const double *cb
       acc[tile_idx(w, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op[w], b_op[J], acc[tile_idx(w, J)], 0, 0, 0);
 }
 template <int Kt>
-__device__ __forceinline__ void sweep_tile_row(d4_t (&acc)[NTILES], double *c0, double *c1, int lc, int lq, int l, double ndel, bool &ok) {
-  // entry: the panel of pivots (Kt, 0) is in c0
-  sweep_step<Kt, 0>(acc, c0, lc, lq, ndel, ok);
-  publish_panel<Kt, 1>(acc, c1, lc, lq, l);
-  sweep_step<Kt, 1>(acc, c1, lc, lq, ndel, ok);
-  publish_panel<Kt, 2>(acc, c0, lc, lq, l);
-  sweep_step<Kt, 2>(acc, c0, lc, lq, ndel, ok);
-  publish_panel<Kt, 3>(acc, c1, lc, lq, l);
-  sweep_step<Kt, 3>(acc, c1, lc, lq, ndel, ok);
-  if (Kt + 1 < NT) publish_panel<(Kt + 1 < NT ? Kt + 1 : 0), 0>(acc, c0, lc, lq, l);
+__device__ __forceinline__ void sweep_tile_row(d4_t (&acc)[NTILES], double *c0, double *c1, int lc, int lq, double ndel, PivInv &P, bool &ok) {
+  // entry: the panel of pivots (Kt, 0) is in c0, the pivot block's inverse in P
+  sweep_step<Kt, 0>(acc, c0, lc, lq, ndel, P);
+  publish_panel<Kt, 1>(acc, c1, lc, lq, P, ok);
+  sweep_step<Kt, 1>(acc, c1, lc, lq, ndel, P);
+  publish_panel<Kt, 2>(acc, c0, lc, lq, P, ok);
+  sweep_step<Kt, 2>(acc, c0, lc, lq, ndel, P);
+  publish_panel<Kt, 3>(acc, c1, lc, lq, P, ok);
+  sweep_step<Kt, 3>(acc, c1, lc, lq, ndel, P);
+  if (Kt + 1 < NT) publish_panel<(Kt + 1 < NT ? Kt + 1 : 0), 0>(acc, c0, lc, lq, P, ok);
 }
 
 // (Round 4, measured and not kept: the six products that feed the next pivot's rows first, the other fifteen pinned one at a time
@@ -676,13 +672,14 @@ __device__ __noinline__ void factorise(const double *Pg, const double *gw, const
   const double ndel = (lq == (lc & 3)) ? -1.0 : 0.0;
   wave_lds_sync();
   TSTAMP(5)
-  publish_panel<0, 0>(acc, c0, lc, lq, l);
-  sweep_tile_row<0>(acc, c0, c1, lc, lq, l, ndel, ok);
-  sweep_tile_row<1>(acc, c0, c1, lc, lq, l, ndel, ok);
-  sweep_tile_row<2>(acc, c0, c1, lc, lq, l, ndel, ok);
-  sweep_tile_row<3>(acc, c0, c1, lc, lq, l, ndel, ok);
-  sweep_tile_row<4>(acc, c0, c1, lc, lq, l, ndel, ok);
-  sweep_tile_row<5>(acc, c0, c1, lc, lq, l, ndel, ok);
+  PivInv P;
+  publish_panel<0, 0>(acc, c0, lc, lq, P, ok);
+  sweep_tile_row<0>(acc, c0, c1, lc, lq, ndel, P, ok);
+  sweep_tile_row<1>(acc, c0, c1, lc, lq, ndel, P, ok);
+  sweep_tile_row<2>(acc, c0, c1, lc, lq, ndel, P, ok);
+  sweep_tile_row<3>(acc, c0, c1, lc, lq, ndel, P, ok);
+  sweep_tile_row<4>(acc, c0, c1, lc, lq, ndel, P, ok);
+  sweep_tile_row<5>(acc, c0, c1, lc, lq, ndel, P, ok);
   wave_lds_sync();
   TSTAMP(6)
   // acc = MINUS the inverse: scatter into the block image (the panels are dead); the table entries of all tiles as one batch
