@@ -648,7 +648,7 @@ def bench_closed_loop(args, dev, rank, world, fdist, barrier):
         dt = fdist.max_over_ranks(time.perf_counter() - t0, dev)
         assert bool(torch.isfinite(traj).all()) and fdist.or_status(env.status) & ~(64 | 128) == 0
         r = {"aircraft_steps_per_s": world * B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps,
-             "iters_mean": stats["iters_mean"]}
+             "iters_mean": stats["iters_mean"], "longest_solve_iters_mean_over_steps": stats["iters_max_mean"]}
         return (r, traj, dt) if keep_traj else (r, None, dt)
 
     # every variant over the SAME number of steps (the first steps of a closed loop need the most iterations: legs of different

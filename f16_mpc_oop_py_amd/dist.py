@@ -155,7 +155,8 @@ def closed_loop_mpc_rollout(env, steps, hzn, p_dem=0.0, q_dem=0.0, r_dem=0.0, tr
     per solve (bench.py reports both legs at equal length); with the opt-in rule the factorisation is cached as well.
     (A HIP-graph replay of the step was measured and is SLOWER than the six eager launches on ROCm 7.2: 0.50 vs
     0.19 ms per step at B = 256, 3.36 vs 3.15 ms at B = 8192 -- the step is kept capture-safe but launched eagerly.)
-    stats (dict, optional): receives "iters_mean" = mean ADMM iterations per solve over the whole loop (one device-side sum per step).
+    stats (dict, optional): receives "iters_mean" = mean ADMM iterations per solve over the whole loop and "iters_max_mean" = the mean over
+    the steps of the LONGEST solve of the step (device-side reductions, read once at the end): a step cannot end before its longest solve.
     Returns the collated trajectory [steps//traj_every, 18, B_total] (or the local shard if gather=False)."""
     T = steps // traj_every
     traj = torch.empty((T, 18, env.B), dtype=torch.float64, device=env.device)
@@ -163,14 +164,17 @@ def closed_loop_mpc_rollout(env, steps, hzn, p_dem=0.0, q_dem=0.0, r_dem=0.0, tr
     for k, v in enumerate((p_dem, q_dem, r_dem)):
         dem[k] = torch.as_tensor(v, dtype=torch.float64, device=env.device)
     it_sum = torch.zeros((), dtype=torch.float64, device=env.device) if stats is not None else None
+    it_max = torch.zeros((), dtype=torch.float64, device=env.device) if stats is not None else None
     for k in range(steps):
         cmd = env._calc_MPC_action(dem, None, None, hzn, use_plan=use_plan)
         if it_sum is not None:
             it_sum += env.last_iters.sum()
+            it_max += env.last_iters.max()
         env._u[1:4] = cmd.t()
         env.rollout(1)
         if (k + 1) % traj_every == 0:
             traj[(k + 1) // traj_every - 1] = env._x
     if stats is not None:
         stats["iters_mean"] = float(it_sum) / max(1, steps * env.B)
+        stats["iters_max_mean"] = float(it_max) / max(1, steps)
     return all_gather_trajectories(traj) if gather else traj

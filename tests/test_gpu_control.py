@@ -788,8 +788,9 @@ def test_weights_argument_validation_and_defaults():
 
 
 def test_dispatch_orders_do_not_change_results():
-    """Scheduling only: the same batch with no ordering, with the first-call order (by ||q||_inf) and with the order of a previous
-    call returns the same commands, iteration counts and status words, bit for bit.  Fresh processes (the switch is read per call,
+    """Scheduling only: the same batch with no ordering, with the first-call order (by ||q||_inf), with the order of a previous
+    call, and with the hardware's distribution of workgroups instead of the kernel's own work queue returns the same commands,
+    iteration counts and status words, bit for bit.  Fresh processes (the switch is read per call,
     the history lives in the context)."""
     import subprocess
     import sys
@@ -811,14 +812,16 @@ def test_dispatch_orders_do_not_change_results():
     import tempfile
     res = []
     with tempfile.TemporaryDirectory() as d:
-        for mode in ("0", "first", "1"):
-            f = os.path.join(d, f"o_{mode}.npz")
-            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, PYTHONPATH=REPO, F16_MPC_DISPATCH_ORDER=mode),
+        for mode, queue in (("0", "1"), ("first", "1"), ("1", "1"), ("1", "0")):      # queue = 0: one workgroup per aircraft, dealt by the hardware
+            f = os.path.join(d, f"o_{mode}_{queue}.npz")
+            r = subprocess.run([sys.executable, "-c", code, f],
+                               env=dict(os.environ, PYTHONPATH=REPO, F16_MPC_DISPATCH_ORDER=mode, F16_MPC_WAVE_QUEUE=queue),
                                capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             res.append(np.load(f))
     for k in ("u", "it", "st"):
-        assert np.array_equal(res[0][k], res[1][k], equal_nan=True) and np.array_equal(res[0][k], res[2][k], equal_nan=True)
+        for other in res[1:]:
+            assert np.array_equal(res[0][k], other[k], equal_nan=True), k
     assert res[0]["it"].min() >= 25 and res[0]["it"].max() > res[0]["it"].min()
 
 
