@@ -638,7 +638,7 @@ def bench_closed_loop(args, dev, rank, world, fdist, barrier):
             if "builder_rule" in name:
                 st.update(F16Batch.solver_modes()["builder_rule"])
             env.prepare_MPC(args.mpc_hzn, settings=st or None, warm_start="warm_start" in name)
-        fdist.closed_loop_mpc_rollout(env, steps=2, hzn=args.mpc_hzn, gather=False, use_plan=use_plan)
+        fdist.closed_loop_mpc_rollout(env, steps=2, hzn=args.mpc_hzn, gather=False, use_plan=use_plan, stats={})    # (stats: the reductions' first launch too)
         env.reset()
         stats = {}
         barrier()
