@@ -676,7 +676,9 @@ def bench_closed_loop(args, dev, rank, world, fdist, barrier):
     res["steps"] = T
     res["hzn"] = args.mpc_hzn
     res["short_leg_steps"] = short
-    res["note"] = ("every variant runs the same `short_leg_steps`; `headline` = the faster reference-settings leg over all `steps`.  "
+    res["note"] = ("every variant runs the same `short_leg_steps`; `headline` = the faster reference-settings leg over all `steps` "
+                   "(from step ~40 on a few aircraft of this synthetic batch have infeasible QPs that OSQP's rules certify after 5,000+ "
+                   "iterations: those steps end with their longest solve -- `longest_solve_iters_mean_over_steps` -- not with the batch's throughput).  "
                    "prepared_plan / one_shot start every solve cold, as the reference does (a new OSQP object per call; with OSQP's "
                    "defaults a plan saves the QP build only -- the equilibration depends on q); "
                    "warm_start is the opt-in extension (OSQP's in-object default); check5 = the same with the termination test "
