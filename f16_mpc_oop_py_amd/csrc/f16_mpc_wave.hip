@@ -63,7 +63,7 @@ static_assert(ZP_OFF + 8 <= KB_OFF && (P1_OFF & 1) == 0 && (ZP_OFF & 1) == 0 && 
 constexpr int GL_OFF = 0, GL_SIZE = 27 * (WN + 1) + 1;                 // all nine rows of every G_k + a zero block
 constexpr int WG_OFF = GL_OFF + GL_SIZE, WG_SIZE = 6 * WN + 8;         // Gram weights of the kept state rows (zero padded)
 constexpr int WCV_OFF = WG_OFF + WG_SIZE, WRV_OFF = WCV_OFF + 96;      // Gram weights of command / rate rows (rate: + 4)
-constexpr int PAN_DI = FN * 4, PAN_OK = FN * 4 + 16, PAN_SIZE = FN * 4 + 18;
+constexpr int PAN_SIZE = FN * 4 + 2;                    // a panel: C[col][0..3] = M[pivot row][col] (FN x 4)
 constexpr int PAN_OFF = WRV_OFF + 100;
 static_assert(PAN_OFF + 2 * PAN_SIZE <= KI_SIZE, "factorisation scratch");
 static_assert((PAN_OFF & 1) == 0 && (PAN_SIZE & 1) == 0 && (XT_OFF & 1) == 0 && (WS_OFF & 1) == 0 && (WC_OFF & 1) == 0, "16-byte alignment");
@@ -526,7 +526,7 @@ __device__ __forceinline__ double sel4(double v0, double v1, double v2, double v
   const double lo = (k & 1) ? v1 : v0, hi = (k & 1) ? v3 : v2;
   return (k & 2) ? hi : lo;
 }
-// pan: C[col][0..3] = M[pivot row][col] (FN x 4) | D^-1 (4 x 4) | ok flag.  Publish pivots 16 Kt + 4 KQ .. + 3 from the tiles.
+// pan: C[col][0..3] = M[pivot row][col] (FN x 4).  Publish pivots 16 Kt + 4 KQ .. + 3 from the tiles; the pivot block's inverse: P.
 struct PivInv { double2 a0, a1; double dpiv; };      // row l / 16 of the pivot block's inverse, and its element (l / 16, l % 4)
 template <int Kt, int KQ>
 __device__ __forceinline__ void publish_panel(const d4_t (&acc)[NTILES], double *pan, int lc, int lq, PivInv &P, bool &ok) {
@@ -1424,7 +1424,6 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
   const double cs = rz.cs;
   C.cs = cs; C.cinv = 1.0 / cs;
   C.eqA = 0; C.eqB = 0;
-  double *const xt = s_w + XT_OFF;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const int k = R.act ? kx + c : 0;
