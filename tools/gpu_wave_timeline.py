@@ -31,6 +31,12 @@ for rep in range(4):
     gaps = np.array(gaps)
     print(f"   {len(np.unique(slot))} SIMDs used; first start {1e6 * np.median(firsts):.1f} us (median) after the earliest; gap between a solve's end and the next "
           f"solve's start on the same SIMD: median {1e6 * np.median(gaps):.1f} us, mean {1e6 * gaps.mean():.1f} us, 95 % {1e6 * np.percentile(gaps, 95):.1f} us, sum {1e3 * gaps.sum():.0f} slot-ms")
+    xcc, se = slot // 4096, (slot % 4096) // 512
+    per_part = np.bincount(xcc * 8 + se)
+    per_part = per_part[per_part > 0]
+    per_simd = np.bincount(np.unique(slot, return_inverse=True)[1])
+    print(f"   solves per XCD: {np.bincount(xcc).min()}..{np.bincount(xcc).max()}; per (XCD, shader engine): {per_part.min()}..{per_part.max()} over {len(per_part)} partitions; "
+          f"per SIMD: " + ", ".join(f"{k} x {v}" for k, v in enumerate(np.bincount(per_simd)) if v))
     last = np.argsort(-en)[:12]
     rank = np.empty(B, dtype=np.int64); rank[np.argsort(st, kind="stable")] = np.arange(B)
     print("   last finishers (aircraft: iterations, start rank, start ms, duration ms, us per iteration): " +
