@@ -353,9 +353,9 @@ def test_mpc_full_size_properties():
     assert np.abs(u3 - u[idx]).max() < 2e-3
 
 
-def test_config4_full_size_every_64th_aircraft_vs_oracle_chain(oracle):
+def test_config4_full_size_every_8th_aircraft_vs_oracle_chain(oracle):
     """BASELINE config 4 at FULL size (B = 4096, N = 30, xcg 0.35, the reference's solver settings) against the checker:
-    every 64th aircraft's first move, iteration count and status word vs the C restatement of the whole chain on the CPU
+    every 8th aircraft's first move, iteration count and status word vs the C restatement of the whole chain on the CPU
     (its own linearisation + ZOH + DARE + dense setup_OSQP + the OSQP twin, env.py:373-424).  The two chains differ at
     the 1e-9 level in (Ad, Bd) (device libm), so iterates agree to ~1e-7 until a termination test falls the other way;
     then the answers are one test interval apart, i.e. inside the solver's own tolerance."""
@@ -365,8 +365,8 @@ def test_config4_full_size_every_64th_aircraft_vs_oracle_chain(oracle):
     env = make_env(x0, u0, xcg=0.35)
     env.build_ssr()
     u, info = env._calc_MPC_action(0.0, 0.0, 0.0, N, return_info=True)
-    idx = np.arange(0, B, 64)
-    ref = oracle.mpc_batch(x0[idx], N, xcg=0.35, nthreads=8)
+    idx = np.arange(0, B, 8)                                   # (512 solves of the CPU twin: ~5 s on the GPU box's 16 cores)
+    ref = oracle.mpc_batch(x0[idx], N, xcg=0.35, nthreads=16)
     ug, itg, stg = u.cpu().numpy()[idx], info["iters"].cpu().numpy()[idx].astype(int), info["status"].cpu().numpy()[idx]
     assert np.array_equal(stg, ref["status"]), (stg, ref["status"])
     same = itg == ref["iters"]
