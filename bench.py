@@ -507,6 +507,23 @@ def bench_mpc(args, dev, rank, world, fdist, barrier):
                                  "F16_MPC_WAVE_QUEUE=0: one workgroup per aircraft, dealt round-robin to 32 (XCD, shader engine) partitions by the hardware"),
                        "value_in_caller_order": world * B / dco, "ms_per_batch_in_caller_order": dco * 1e3,
                        "value_first_call": world * B / dfirst, "ms_per_batch_first_call": dfirst * 1e3}
+    if world == 1 and os.environ.get("F16_MPC_WAVE_QUEUE", "1")[:1] != "0":
+        # the same repeated call with one workgroup per aircraft dealt by the hardware (the switch is read once per process: a child)
+        code = ("import sys, time, torch; sys.path.insert(0, %r)\n"
+                "from f16_mpc_oop_py_amd import F16Batch\nfrom f16_mpc_oop_py_amd.workload import config4_states\n"
+                "x0, u0 = config4_states(%d); env = F16Batch(x0, u0, xcg=0.35); env.build_ssr()\n"
+                "for _ in range(2): env._calc_MPC_action(0.0, 0.0, 0.0, %d)\n"
+                "torch.cuda.synchronize(); t0 = time.perf_counter()\n"
+                "for _ in range(%d): env._calc_MPC_action(0.0, 0.0, 0.0, %d)\n"
+                "torch.cuda.synchronize(); print((time.perf_counter() - t0) / %d)\n" % (REPO, B, args.mpc_hzn, n, args.mpc_hzn, n))
+        try:
+            r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, F16_MPC_WAVE_QUEUE="0"), capture_output=True, text=True, timeout=300)
+            dhw = float(r.stdout.strip().splitlines()[-1])
+            res["dispatch"]["value_workgroup_per_aircraft_dealt_by_the_hardware"] = B / dhw
+            res["dispatch"]["ms_per_batch_workgroup_per_aircraft"] = dhw * 1e3
+        except Exception as e:      # (a diagnostic leg: never fails the bench)
+            res["dispatch"]["value_workgroup_per_aircraft_dealt_by_the_hardware"] = None
+            res["dispatch"]["hardware_dispatch_leg_error"] = repr(e)[:200]
     res["first_call_value"] = world * B / dfirst
     res["call_pattern_note"] = ("`value` is a REPEATED call of the same batch (workgroups ordered longest-first by the previous call's "
                                 "iteration counts: the closed loops' pattern); BASELINE config 4 as written is ONE call per aircraft on "
