@@ -825,6 +825,29 @@ def test_dispatch_orders_do_not_change_results():
     assert res[0]["it"].min() >= 25 and res[0]["it"].max() > res[0]["it"].min()
 
 
+def test_work_queue_batches_equal_small_batches_bit_for_bit():
+    """Batches above 4 x the CU count run the wavefront solver as one workgroup per SIMD with a work queue, smaller ones as one
+    workgroup per aircraft: an aircraft's answer does not depend on which -- 1100 aircraft (a last, partial round of the queue), their
+    first 64 and their last 36 on their own, commands, iteration counts, residuals and status words bit for bit; twice (the second
+    call is ordered by the first one's history)."""
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(1100, seed=23)
+    env = make_env(x0, u0, xcg=0.35)
+    env.build_ssr()
+    outs = []
+    for _ in range(2):
+        u, info = env._calc_MPC_action(0.01, -0.02, 0.0, 30, return_info=True)
+        outs.append((u.clone(), info["iters"].clone(), info["r_prim"].clone(), info["r_dual"].clone(), info["status"].clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    for sl in (slice(0, 64), slice(1064, 1100)):
+        es = make_env(x0[sl], u0[sl], xcg=0.35)
+        es.build_ssr()
+        u, info = es._calc_MPC_action(0.01, -0.02, 0.0, 30, return_info=True)
+        assert torch.equal(u, outs[0][0][sl]) and torch.equal(info["iters"], outs[0][1][sl])
+        assert torch.equal(info["r_prim"], outs[0][2][sl]) and torch.equal(info["r_dual"], outs[0][3][sl]) and torch.equal(info["status"], outs[0][4][sl])
+
+
 def test_more_batch_sizes_than_history_slots_on_one_context():
     """The dispatch-order history has F16_MAX_SCHED = 16 slots per context ((stream, batch size) pairs): a 17th pair recycles the oldest
     slot instead of running unordered for ever; results never depend on it."""
