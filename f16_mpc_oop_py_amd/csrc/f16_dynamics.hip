@@ -113,7 +113,7 @@ __device__ __forceinline__ void rollout_lanes(const DynArgs &a, TP T, double (*u
     for (int k = 0; k < 18; ++k) x[k] = a.out[k * a.ld + b];
 #pragma unroll
     for (int k = 0; k < 4; ++k) us[k][threadIdx.x] = a.u[k * a.ld + b];
-    double ul[3] = {0.0, 0.0, 0.0};
+    double ul[3] = {us[1][threadIdx.x], us[2][threadIdx.x], us[3][threadIdx.x]};   // (u_out of an aircraft that never steps: u0)
     if (LQR) {   // K[i][4..6] and the demands: lane-indexed LDS slots like the inputs (constant over the rollout, used once per step)
 #pragma unroll
       for (int i = 0; i < 3; ++i)
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void k_rollout_4w(DynArgs a) {
     for (int k = 0; k < 18; ++k) x[k] = a.out[k * a.ld + b];
 #pragma unroll
     for (int k = 0; k < 4; ++k) u[k] = a.u[k * a.ld + b];
-    double kq[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ul[3] = {0.0, 0.0, 0.0};   // LQR (wave 3): K[i][4..6], demands; last action
+    double kq[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ul[3] = {u[1], u[2], u[3]};   // LQR (wave 3): K[i][4..6], demands; last action (u0 if it never steps)
     if (LQR && wave == 3) {
 #pragma unroll
       for (int i = 0; i < 3; ++i)
@@ -582,8 +582,8 @@ __global__ __launch_bounds__(256 * GROUPS) void k_rollout_q(DynArgs a) {
             uc = s > 0 ? ua : ucmd;
             ulast = uc;
           }
-          const double dth = clipd(clipd(ucmd, 1000, 19000) - xact, -10000, 10000);
-          const double dsf = clipd(20.2 * (clipd(uc, -lim, lim) - xact), -rate, rate);
+          const double dth = actuator_rate(ucmd, 1000, 19000, 1.0, xact, 10000);
+          const double dsf = actuator_rate(uc, -lim, lim, 20.2, xact, rate);
           double lf1_dot, lf2_dot;
           upd_lef_dev(xa[2], xa[6], xa[7], x[17], x[16], qbar, ps, lf1_dot, lf2_dot);
           xact += (s == 0 ? dth : dsf) * a.dt;             // env.py:126 on the actuator / flap states
@@ -667,6 +667,74 @@ __global__ __launch_bounds__(256 * GROUPS) void k_rollout_q(DynArgs a) {
     }
     __syncthreads();
   }
+}
+
+// The reference's LINEAR-model closed loops (test_env_mk2.py:46-62 `LQR(linear=True)` -- what main.py:35 runs -- and
+// test_env.py:501-576 `test_LQR_lin`): per step  u = -K (x_ref - x) + u0,  x = Ad x + Bd u  on the reduced model (9 states, 3 inputs).
+// One lane = one aircraft; its three matrices (135 doubles) are loaded ONCE and stay in registers (one wave per SIMD, 512 registers
+// per lane), so a step is 135 fused multiply-adds and, with every sample stored, 96 bytes of HBM writes: 2.8 FLOP per byte, under the
+// fp64 ridge -- the stored rollout is HBM-write-bound.  track: bit j set = entry j of the reference is given (x_ref[j]); clear =
+// the reference follows the current state (env.py:362-367: x_ref = copy(x); x_ref[4:7] = demands).
+struct LinArgsL {
+  double *x;            // [9][ld] in place
+  const double *Ad, *Bd, *K, *xref, *u0;
+  double *trx, *tru;    // [T / every][9][ld], [T / every][3][ld]; may be null
+  long B, ld;
+  int nsteps, every;
+  unsigned track;
+};
+__global__ __launch_bounds__(64, 1) void k_rollout_lqr_linear(LinArgsL a) {
+  const long b = (long)blockIdx.x * 64 + threadIdx.x;
+  if (b >= a.B) return;
+  double A[81], Bm[27], K[27], x[9], xr[9], u0[3];
+#pragma unroll
+  for (int e = 0; e < 81; ++e) A[e] = a.Ad[e * a.ld + b];
+#pragma unroll
+  for (int e = 0; e < 27; ++e) { Bm[e] = a.Bd[e * a.ld + b]; K[e] = a.K[e * a.ld + b]; }
+#pragma unroll
+  for (int j = 0; j < 9; ++j) { x[j] = a.x[j * a.ld + b]; xr[j] = a.xref[j * a.ld + b]; }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) u0[c] = a.u0 ? a.u0[c * a.ld + b] : 0.0;
+  double *px = a.trx ? a.trx + b : nullptr, *pu = a.tru ? a.tru + b : nullptr;
+  int until = a.every;
+  for (int t = 0; t < a.nsteps; ++t) {
+    double e[9], u[3], xn[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) e[j] = (((a.track >> j) & 1u) ? xr[j] : x[j]) - x[j];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) s += K[9 * c + j] * e[j];
+      u[c] = -s + u0[c];                                     // env.py:371 / test_env.py:555
+    }
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      double s = 0.0, v = 0.0;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) s += A[9 * r + j] * x[j];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v += Bm[3 * r + c] * u[c];
+      xn[r] = s + v;                                         // test_env_mk2.py:58 / test_env.py:556
+    }
+#pragma unroll
+    for (int r = 0; r < 9; ++r) x[r] = xn[r];
+    if (--until == 0) {
+      until = a.every;
+      if (px) {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) __builtin_nontemporal_store(x[r], px + r * a.ld);
+        px += 9 * a.ld;
+      }
+      if (pu) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) __builtin_nontemporal_store(u[c], pu + c * a.ld);
+        pu += 3 * a.ld;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 9; ++r) a.x[r * a.ld + b] = x[r];
 }
 
 template <int BLOCK>
@@ -860,6 +928,21 @@ extern "C" int f16_rollout_lqr(f16_ctx *ctx, double *x, const double *u0, const 
   a.dt = dt; a.xcg = xcg; a.fi = fi_flag; a.flags = flags;
   a.K = K; a.dem = dem; a.u_out = u_out;
   return rollout_dispatch<true>(ctx, a, stream);
+}
+
+extern "C" int f16_rollout_lqr_linear(f16_ctx *ctx, double *x9, const double *Ad, const double *Bd, const double *K, const double *x_ref,
+                                      const double *u0, double *traj_x, double *traj_u, long B, long ld, int nsteps, int traj_every,
+                                      unsigned track_mask, void *stream) {
+  if (int rc = check_common(ctx, x9, Ad, B, ld)) return rc;
+  if (!Bd || !K || !x_ref) return set_error(F16_EINVAL, "Bd / K / x_ref is NULL");
+  if (nsteps < 0 || ((traj_x || traj_u) && (traj_every < 1 || nsteps % traj_every != 0)))
+    return set_error(F16_EINVAL, "nsteps must be >= 0 and a multiple of traj_every >= 1 when a trajectory is given");
+  if (B == 0 || nsteps == 0) return F16_OK;
+  LinArgsL a{};
+  a.x = x9; a.Ad = Ad; a.Bd = Bd; a.K = K; a.xref = x_ref; a.u0 = u0; a.trx = traj_x; a.tru = traj_u;
+  a.B = B; a.ld = ld; a.nsteps = nsteps; a.every = (traj_x || traj_u) ? traj_every : nsteps + 1; a.track = track_mask & 0x1FFu;
+  hipLaunchKernelGGL(k_rollout_lqr_linear, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, (hipStream_t)stream, a);
+  return hip_check(hipGetLastError(), "f16_rollout_lqr_linear launch");
 }
 
 extern "C" int f16_xdot_na_batch(f16_ctx *ctx, const double *x_full, const double *x9, const double *u3, double *xdot9,

@@ -816,7 +816,19 @@ F16_DEV void plant(TP T, const double *__restrict__ LT, const double *xu, double
   plant_post<OUTPUTS>(xu, p, t, xdot);
 }
 
+// IEEE minNum / maxNum clamp: DROPS a NaN (returns the bound).  For callers whose operand is finite by construction (trim).
 F16_DEV double clipd(double a, double lo, double hi) { return fmin(fmax(a, lo), hi); }
+
+// The reference's actuators saturate with np.clip (utils.py:303-330), and np.clip PROPAGATES NaN: a NaN command (what OSQP hands
+// back for a QP it certifies infeasible, env.py:420-424) or a NaN state gives a NaN derivative -- fmin / fmax alone would turn it
+// into a hard-over at full rate.  One command-saturated, rate-saturated first-order lag
+//     clip(k * (clip(cmd, lo, hi) - state), -rate, rate)
+// with that rule: the fast clamps, then ONE unordered compare of the command with the unclamped rate (NaN if either is) + a select.
+F16_DEV double actuator_rate(double cmd, double lo, double hi, double k, double state, double rate) {
+  const double t = k * (clipd(cmd, lo, hi) - state);
+  const double r = clipd(t, -rate, rate);
+  return __builtin_isunordered(cmd, t) ? __builtin_nan("") : r;
+}
 
 // utils.py:289-306 -> lf1_dot (7.25*LF_err), lf2_dot (lef_err).  qbar/ps are those of atmos(h, V) with the
 // RAW V (utils.py:291); plant() evaluates atmos with vt clamped to >= 0.01, identical whenever V > 0.01.
@@ -831,18 +843,17 @@ F16_DEV void upd_lef_dev(double h, double V, double alpha, double lf1, double lf
   const double alpha_deg = F16_DIVC(alpha * 180, 3.141592653589793);
   const double LF_err = alpha_deg - (lf1 + (2 * alpha_deg));
   const double LF_out = (lf1 + (2 * alpha_deg)) * 1.38;
-  double lef_cmd = LF_out + 1.45 - atmos_out;
-  lef_cmd = clipd(lef_cmd, 0., 25);
-  lf2_dot = clipd((1 / 0.136) * (lef_cmd - lf2), -25, 25);
+  const double lef_cmd = LF_out + 1.45 - atmos_out;
+  lf2_dot = actuator_rate(lef_cmd, 0., 25, 1 / 0.136, lf2, 25);     // utils.py:303-305 (np.clip: NaN in -> NaN out)
   lf1_dot = LF_err * 7.25;
 }
 
 // utils.py:308-330 + env.py:90-102: actuator and leading-edge-flap state derivatives xdot[12..17].
 F16_DEV void actuators_dev(const double *x, const double *u, double qbar, double ps, double *xdot) {
-  xdot[12] = clipd(clipd(u[0], 1000, 19000) - x[12], -10000, 10000);      // utils.py:308-312
-  xdot[13] = clipd(20.2 * (clipd(u[1], -25, 25) - x[13]), -60, 60);       // :314-318
-  xdot[14] = clipd(20.2 * (clipd(u[2], -21.5, 21.5) - x[14]), -80, 80);   // :320-324
-  xdot[15] = clipd(20.2 * (clipd(u[3], -30., 30) - x[15]), -120, 120);    // :326-330
+  xdot[12] = actuator_rate(u[0], 1000, 19000, 1.0, x[12], 10000);      // utils.py:308-312
+  xdot[13] = actuator_rate(u[1], -25, 25, 20.2, x[13], 60);            // :314-318
+  xdot[14] = actuator_rate(u[2], -21.5, 21.5, 20.2, x[14], 80);        // :320-324
+  xdot[15] = actuator_rate(u[3], -30., 30, 20.2, x[15], 120);          // :326-330
   double lf1_dot, lf2_dot;
   upd_lef_dev(x[2], x[6], x[7], x[17], x[16], qbar, ps, lf1_dot, lf2_dot);
   xdot[16] = lf2_dot;   // env.py:98,102: temp[4] -> xdot[16]

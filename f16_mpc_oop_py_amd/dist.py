@@ -132,18 +132,16 @@ def sum_over_ranks(value, device=None):
 
 
 def or_status(status):
-    """Bitwise OR over every aircraft of every rank (int)."""
-    v = 0
-    s = status.detach().to("cpu").numpy()
-    for bit in (1, 2, 4, 8, 16, 32, 64, 128):
-        if (s & bit).any():
-            v |= bit
-    if not group_active():
-        return v
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([(v >> k) & 1 for k in range(8)], dtype=torch.int32, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return int(sum(int(b) << k for k, b in enumerate(t.tolist())))
+    """Bitwise OR of the status words of every aircraft of every rank (int): all 26 bits -- the eight condition bits and the
+    F16_ST_ENV_STATE(k) which-state bits 8..25.  The OR over the shard runs where the tensor lives; across ranks the word goes as 32
+    0 / 1 flags through an all-reduce(MAX) (RCCL has no bitwise-or reduction)."""
+    s = status.detach().reshape(-1).to(torch.int32)
+    bits = torch.arange(32, dtype=torch.int32, device=s.device)
+    flags = ((s.unsqueeze(1) >> bits) & 1).amax(0).to(torch.int32) if s.numel() else torch.zeros(32, dtype=torch.int32, device=s.device)
+    if group_active():
+        flags = flags.to("cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+    return int(sum(int(b) << k for k, b in enumerate(flags.tolist())))
 
 
 def closed_loop_mpc_rollout(env, steps, hzn, p_dem=0.0, q_dem=0.0, r_dem=0.0, traj_every=1, gather=True, use_plan=True, stats=None):

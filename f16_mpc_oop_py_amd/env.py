@@ -326,22 +326,43 @@ class F16Batch:
         x_ref[:, 4], x_ref[:, 5], x_ref[:, 6] = p_dem, q_dem, r_dem
         return -(K @ (x_ref - x).unsqueeze(-1)).squeeze(-1) + u0
 
-    def rollout_LQR(self, nsteps, p_dem, q_dem, r_dem, K=None, u0=None, traj_every=None):
-        """The reference's nonlinear LQR loop (test_env_mk2.py:70-85; flight_sim.py:139,181) as ONE launch: per step
-        `u = _calc_LQR_action(p_dem, q_dem, r_dem, K, x._get_mpc_x(), u.initial_condition[1:])`, `u.values[1:] = u`,
-        `step(u.values)`, the state in registers for all nsteps.  K [B,3,9] defaults to `_calc_LQR_gain()` at the current
-        point, u0 [B,4] to u.initial_condition; demands scalars or [B].  u.values ends up holding the last action, as in
-        the reference.  traj_every=k returns the states after every k-th step, [nsteps//k, 18, B]."""
-        if K is None:
-            K = self._calc_LQR_gain()
-        Ks = torch.as_tensor(K, device=self.device, dtype=torch.float64).reshape(self.B, 27).t().contiguous()
-        u0s = self._u_init if u0 is None else self._soa(u0, 4)
+    def _demands(self, p_dem, q_dem, r_dem):
+        """(p, q, r) demands, scalars or [B], as a state-major [3,B] device tensor."""
         dem = torch.empty((3, self.B), dtype=torch.float64, device=self.device)
         for k, v in enumerate((p_dem, q_dem, r_dem)):
             if isinstance(v, (int, float)):
-                dem[k].fill_(float(v))
+                dem[k].fill_(float(v))                # scalar demand: a fill kernel, no host-to-device copy
             else:
                 dem[k] = torch.as_tensor(v, dtype=torch.float64, device=self.device)
+        return dem
+
+    def rollout_LQR(self, nsteps, p_dem, q_dem, r_dem, K=None, u0=None, traj_every=None, linear=False):
+        """The reference's LQR loops (test_env_mk2.py:25-88 `LQR(linear=...)`; flight_sim.py:139,181) as ONE launch.
+        linear=False (test_env_mk2.py:70-85): per step `u = _calc_LQR_action(p_dem, q_dem, r_dem, K, x._get_mpc_x(),
+        u.initial_condition[1:])`, `u.values[1:] = u`, `step(u.values)`, the state in registers for all nsteps.  K [B,3,9] defaults
+        to `_calc_LQR_gain()` at the current point; u0 [B,4] defaults to the CURRENT thrust command u.values[0] (the loop never
+        writes it) with u.initial_condition[1:] as the LQR offset; demands scalars or [B].  u.values ends up holding the last
+        action, as in the reference.  traj_every=k returns the states after every k-th step, [nsteps//k, 18, B].
+        linear=True (test_env_mk2.py:46-62, what main.py:35 runs): the same law on the frozen reduced model,
+        `x = ssr.Ad @ x + ssr.Bd @ u` from x = x._get_mpc_x(); x.values / u.values are not touched (the reference's loop works on
+        locals).  Returns (x_storage [nsteps//k, 9, B], u_storage [nsteps//k, 3, B]) with k = traj_every or 1."""
+        if K is None:
+            K = self._calc_LQR_gain()
+        Ks = torch.as_tensor(K, device=self.device, dtype=torch.float64).reshape(self.B, 27).t().contiguous()
+        dem = self._demands(p_dem, q_dem, r_dem)
+        if linear:
+            if self.ssr is None:
+                self.build_ssr()
+            Ad, Bd, _ = self.ssr
+            xref = torch.zeros((9, self.B), dtype=torch.float64, device=self.device)
+            xref[4:7] = dem                                                  # env.py:365-367
+            u03 = self._u_init[1:4].contiguous() if u0 is None else self._soa(u0, 4)[1:4].contiguous()
+            return self.rollout_linear(self._x[P.mpc_x_idx], Ad, Bd, Ks, xref, u03, nsteps, track=(4, 5, 6), traj_every=traj_every,
+                                       state_major=True)
+        if u0 is None:       # test_env_mk2.py:76-82: the offset is u.initial_condition[1:], the thrust the CURRENT u.values[0]
+            u0s = torch.cat((self._u[0:1], self._u_init[1:4]), 0).contiguous()
+        else:
+            u0s = self._soa(u0, 4)
         traj = None
         if traj_every:
             assert nsteps % traj_every == 0
@@ -350,6 +371,34 @@ class F16Batch:
                                              _vp(self.status), self.B, self.B, int(nsteps), int(traj_every or 1), self.dt,
                                              self.xcg, self.fi_flag, self.flags, self._stream))
         return traj
+
+    def rollout_linear(self, x9, Ad, Bd, K, x_ref, u0, nsteps, track=None, traj_every=None, state_major=False):
+        """`u = -K (x_ref - x) + u0; x = Ad x + Bd u` for nsteps on per-aircraft 9-state / 3-input linear models (C-ABI
+        f16_rollout_lqr_linear): the loop of test_env_mk2.py:54-62 (track = (4, 5, 6): the reference follows the current state
+        except the three rate demands, env.py:360-371; K = -dlqr as `_calc_LQR_gain` returns it) and of test_env.py:553-559
+        (track=None: a fixed full reference; pass K = -dlqr(A, B, Q, R)).  x9 [B,9], Ad [B,9,9], Bd [B,9,3], K [B,3,9], x_ref [B,9],
+        u0 [B,3] or None -- or, with state_major=True, the device layout itself ([9,B], [81,B], [27,B], [27,B], [9,B], [3,B]: what
+        build_ssr and the gain kernel hold).  Returns (x_storage [nsteps//k, 9, B], u_storage [nsteps//k, 3, B]), k = traj_every or 1;
+        the final state is kept in `last_linear_state` [B,9]."""
+        def sm(a, rows):                      # -> contiguous state-major [rows, B]
+            t = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float64))
+            t = t.to(device=self.device, dtype=torch.float64)
+            if state_major:
+                assert tuple(t.shape) == (rows, self.B), (tuple(t.shape), rows)
+                return t.contiguous()
+            return t.reshape(self.B, rows).t().contiguous()
+        xs = sm(x9, 9).clone()
+        Ads, Bds, Ks, xr = sm(Ad, 81), sm(Bd, 27), sm(K, 27), sm(x_ref, 9)
+        u0s = sm(u0, 3) if u0 is not None else None
+        k = int(traj_every or 1)
+        assert nsteps % k == 0
+        trx = torch.empty((nsteps // k, 9, self.B), dtype=torch.float64, device=self.device)
+        tru = torch.empty((nsteps // k, 3, self.B), dtype=torch.float64, device=self.device)
+        mask = 0x1FF if track is None else sum(1 << int(j) for j in track)
+        self._check(self.lib.f16_rollout_lqr_linear(self.ctx.handle, _vp(xs), _vp(Ads), _vp(Bds), _vp(Ks), _vp(xr), _vp(u0s), _vp(trx),
+                                                    _vp(tru), self.B, self.B, int(nsteps), k, mask, self._stream))
+        self.last_linear_state = xs.t()
+        return trx, tru
 
     # ------------------------------------------------------------------ env.py:373-424
     def prepare_MPC(self, hzn, settings=None, warm_start=False, weights=None):
@@ -453,6 +502,7 @@ class F16Batch:
             self._check(self.lib.f16_mpc_plan_solve_w(self._plan, _vp(self._x), _vp(dem), _vp(xr), _vp(ucmd), _vp(useq), _vp(info),
                                                       _vp(st), self._stream))
             self.last_status, self.last_iters = st, info[0]
+            self.status |= st          # sticky: F16_ST_QP_INFEASIBLE / QP_MAXITER of ANY step stay visible after a closed loop
             if return_info:
                 return ucmd.t(), dict(iters=info[0], r_prim=info[1], r_dual=info[2], rho=info[3], u_seq=useq.t(), status=st)
             return ucmd.t()
@@ -466,6 +516,7 @@ class F16Batch:
                                              ctypes.byref(w) if w else None, _vp(ucmd), _vp(useq), _vp(info), _vp(st), self.B, self.B,
                                              int(hzn), self.dt, ctypes.byref(s), self._stream))
         self.last_status, self.last_iters = st, info[0]
+        self.status |= st
         if return_info:
             return ucmd.t(), dict(iters=info[0], r_prim=info[1], r_dual=info[2], rho=info[3], u_seq=useq.t(), status=st)
         return ucmd.t()

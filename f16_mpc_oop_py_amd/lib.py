@@ -220,6 +220,7 @@ def load():
     L.f16_nlplant_batch.argtypes = [vp, vp, vp, vp, l, l, d, i, u, vp]
     L.f16_rollout.argtypes = [vp, vp, vp, vp, vp, l, l, i, i, d, d, i, u, vp]
     L.f16_rollout_lqr.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, l, l, i, i, d, d, i, u, vp]
+    L.f16_rollout_lqr_linear.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, l, l, i, i, u, vp]
     L.f16_xdot_na_batch.argtypes = [vp, vp, vp, vp, vp, vp, l, l, d, i, u, vp]
     L.f16_debug_table_lookup.argtypes = [vp, i, vp, vp, vp, i, vp, vp]
     if hasattr(L, "f16_trim_batch"):

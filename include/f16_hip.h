@@ -112,6 +112,20 @@ int f16_rollout(f16_ctx *ctx, double *x, const double *u, double *traj, int32_t 
 int f16_rollout_lqr(f16_ctx *ctx, double *x, const double *u0, const double *K, const double *dem, double *traj,
                     double *u_out, int32_t *status, long B, long ld, int nsteps, int traj_every, double dt, double xcg,
                     int fi_flag, unsigned flags, void *stream);
+/* The reference's LINEAR-model closed loops as ONE launch (9-state reduced model, 3 inputs; one lane per aircraft, its matrices in
+ * registers):   per step   u = -K (x_ref - x) + u0,   x = Ad x + Bd u
+ *   test_env_mk2.py:46-62 `LQR(linear=True)` (what main.py:35 runs): the frozen model ssr.Ad / ssr.Bd under env.py:360-371
+ *     `_calc_LQR_action` -- K as the reference holds it (K = -dlqr, f16_lqr_batch's output), x_ref = the CURRENT state with
+ *     x_ref[4:7] = (p, q, r)_dem: track_mask = 0x70 and x_ref[4..6][ld] = the demands, u0 = u.initial_condition[1:];
+ *   test_env.py:501-576 `test_LQR_lin`: u = -K' (x - x_ref) with K' = dlqr and a FIXED reference: track_mask = 0x1FF, K = -K', u0 NULL.
+ * x9[9][ld] in place (MPC-state order, parameters.py:135); Ad[81][ld], Bd[27][ld], K[27][ld] row-major per aircraft; x_ref[9][ld]
+ * (entries outside track_mask are not read); u0[3][ld] or NULL (= 0).  traj_x (may be NULL) [nsteps / traj_every][9][ld] and traj_u
+ * (may be NULL) [..][3][ld] receive the state AFTER and the action OF every traj_every-th step (x_storage / u_storage of the
+ * reference's loops).  No envelope, no saturation: the reference's loops have none (on the reference's own model the first loop
+ * grows like exp(14 t) -- SURVEY.md 8-Q.3 -- and so does this one, fixture G13). */
+int f16_rollout_lqr_linear(f16_ctx *ctx, double *x9, const double *Ad, const double *Bd, const double *K, const double *x_ref,
+                           const double *u0, double *traj_x, double *traj_u, long B, long ld, int nsteps, int traj_every,
+                           unsigned track_mask, void *stream);
 /* env.py:152-193 _calc_xdot_na: x9[9][ld], u3[3][ld] scattered over x_full[18][ld] -> xdot9[9][ld] */
 int f16_xdot_na_batch(f16_ctx *ctx, const double *x_full, const double *x9, const double *u3, double *xdot9,
                       int32_t *status, long B, long ld, double xcg, int fi_flag, unsigned flags, void *stream);

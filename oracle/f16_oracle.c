@@ -415,7 +415,9 @@ void f16o_nlplant(const double *xu, double *xdot, int fi_flag, double xcg) { /* 
 void Nlplant(double *xu, double *xdot, int fidelity) { f16o_nlplant(xu, xdot, fidelity, g_xcg); }
 
 /* ------------------------------------------------------------- actuators */
-static double clipd(double a, double lo, double hi) { return fmin(fmax(a, lo), hi); }
+/* np.clip (utils.py:303-330): NaN in -> NaN out (fmin / fmax alone would return the bound: a NaN command -- what OSQP hands
+ * back for an infeasible QP, env.py:420-424 -- would become a hard-over at full rate).  Pinned by fixture G3b. */
+static double clipd(double a, double lo, double hi) { return isnan(a) ? a : fmin(fmax(a, lo), hi); }
 static const double PI_NP = 3.141592653589793;  /* numpy.pi */
 
 /* utils.py:289-306 -> (lf1_dot, lf2_dot) */
@@ -574,12 +576,17 @@ void f16o_rollout_lqr(double *x, const double *u0, const double *K, const double
         double x9[9], xr[9];
         for (int i = 0; i < 9; ++i) x9[i] = xr[i] = x[18 * b + MPC_X_IDX[i]];
         xr[4] = dem[3 * b]; xr[5] = dem[3 * b + 1]; xr[6] = dem[3 * b + 2];
+        double un[4] = {u[0], 0.0, 0.0, 0.0};
         for (int i = 0; i < 3; ++i) {
           double s = 0.0;
           for (int j = 0; j < 9; ++j) s += -K[27 * b + 9 * i + j] * (xr[j] - x9[j]);
-          u[1 + i] = s + u0[4 * b + 1 + i];
+          un[1 + i] = s + u0[4 * b + 1 + i];
         }
-        st |= f16o_step(x + 18 * b, u, dt, fi_flag, xcg);
+        const int s1 = f16o_step(x + 18 * b, un, dt, fi_flag, xcg);
+        st |= s1;
+        /* an aircraft found outside its envelope takes no step (the reference exit()s inside step, env.py:121-124): u_out keeps
+         * the action of the last step it TOOK (u0 if none) -- the rule of every device kernel */
+        if (!(s1 & F16O_ST_ENVELOPE)) memcpy(u, un, sizeof u);
       }
       if (traj) memcpy(traj + ((long)t * B + b) * 18, x + 18 * b, 18 * sizeof(double));
     }

@@ -313,6 +313,26 @@ def lqr_action(p_dem, q_dem, r_dem, K, x, u0):
     return -K @ (x_ref - x) + u0
 
 
+def rollout_lqr_linear(x0, Ad, Bd, K, x_ref, u0, T, track=None, every=1):
+    """The reference's LINEAR-model closed loops for one aircraft (9 states, 3 inputs):
+      test_env_mk2.py:54-62 (what main.py:35 runs):  u = _calc_LQR_action(p, q, r, K, x, u0) = -K (x_ref - x) + u0 with
+          x_ref = x except x_ref[4:7] = demands (env.py:360-371), K = -dlqr;  x = ssr.Ad @ x + ssr.Bd @ u      -> track = (4, 5, 6)
+      test_env.py:553-559:  u = -K' (x - x_ref), K' = dlqr, a fixed reference;  x = A @ x + B @ u             -> track = None (all), K = -K'
+    x_ref: the tracked entries are read from it (the others follow the current state).  Returns (x [T/every, 9], u [T/every, 3])."""
+    x = np.array(x0, dtype=float)
+    xr_given = np.asarray(x_ref, dtype=float)
+    idx = list(range(len(x))) if track is None else list(track)
+    xs, us = [], []
+    for t in range(T):
+        xr = np.copy(x)
+        xr[idx] = xr_given[idx]
+        u = -K @ (xr - x) + u0
+        x = Ad @ x + Bd @ u
+        if (t + 1) % every == 0:
+            xs.append(np.copy(x)), us.append(np.copy(u))
+    return np.array(xs), np.array(us)
+
+
 def setup_OSQP(x_ref, A, B, Q, R, hzn, dt, x, act_states,
                x_lb=MPC_X_LB, x_ub=MPC_X_UB, u_lb=MPC_U_LB, u_ub=MPC_U_UB,
                udot_lb=MPC_UDOT_LB, udot_ub=MPC_UDOT_UB):

@@ -51,7 +51,7 @@ def _worker_body(q):
     mx = fdist.max_over_ranks(1.0 + r)
     sm = fdist.sum_over_ranks(10.0 * (r + 1))
     st = torch.zeros(4, dtype=torch.int32)
-    st[r] = 16 if r == 0 else 128
+    st[r] = (16 | (1 << (8 + 13))) if r == 0 else (128 | (1 << (8 + 6)))      # an F16_ST_ENV_STATE(k) bit on each rank
     orv = fdist.or_status(st)
     q.put((r, ok, mx, sm, orv))
     dist.barrier()
@@ -68,7 +68,7 @@ def test_allgather_collates_shards_in_global_order_world2():
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     for r, ok, mx, sm, orv in res:
-        assert ok and mx == 2.0 and sm == 30.0 and orv == (16 | 128)
+        assert ok and mx == 2.0 and sm == 30.0 and orv == (16 | 128 | (1 << 21) | (1 << 14))
 
 
 def test_bench_gpus_2_starts_two_ranks_by_itself():

@@ -43,7 +43,7 @@ def test_world_size_1_nccl_group_runs_every_collective_of_dist_py():
         mx = fdist.max_over_ranks(2.5, dev)
         sm = fdist.sum_over_ranks(4.0, dev)
         st = torch.zeros(B, dtype=torch.int32, device=dev)
-        st[3], st[40] = 16, 128
+        st[3], st[40] = 16 | (1 << (8 + 17)), 128
         orv = fdist.or_status(st)
         # a product rollout collated through the same call (shards of a real trajectory)
         from f16_mpc_oop_py_amd import F16Batch
@@ -66,7 +66,7 @@ def test_world_size_1_nccl_group_runs_every_collective_of_dist_py():
     r = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=600, cwd=REPO)
     assert r.returncode == 0, r.stderr[-3000:]
     rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert rec["ok"] and rec["max"] == 2.5 and rec["sum"] == 4.0 and rec["or"] == (16 | 128)
+    assert rec["ok"] and rec["max"] == 2.5 and rec["sum"] == 4.0 and rec["or"] == (16 | 128 | (1 << 25))
     assert rec["rccl"] and rec["timeout_s"] in (None, 120.0)  # F16_DIST_TIMEOUT honoured (where torch exposes the option)
 
 

@@ -63,6 +63,61 @@ def test_g3_calc_xdot_and_na(oracle, xcg):
     assert rel(out, g[f"xdot_na_xcg{xcg}"]) < TOL
 
 
+@pytest.mark.parametrize("xcg", [25, 35])
+def test_g3b_nan_and_infinite_commands_through_the_actuator_models(oracle, xcg):
+    """np.clip (utils.py:303-330) propagates NaN: a NaN command (OSQP's answer to an infeasible QP, env.py:420-424) gives a NaN
+    actuator derivative in the reference, never a hard-over; +-inf saturates.  Fixture G3b = the reference's `_calc_xdot` / `step`."""
+    g = golden("g3b_nan_actuators.npz")
+    x, u, ref = g[f"x_xcg{xcg}"], g[f"u_xcg{xcg}"], g[f"xdot_xcg{xcg}"]
+    out = np.array([oracle.calc_xdot(a, b, 1, xcg / 100) for a, b in zip(x, u)])
+    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    assert np.isnan(ref).sum() == 1 + 1 + 1 + 1 + 3 + 2                      # (the cases of the fixture really carry NaN)
+    fin = ~np.isnan(ref)
+    assert rel(out[fin], ref[fin]) < TOL
+    assert np.array_equal(out[5:7, 13:15][[0, 1], [0, 1]], [60.0, -80.0])    # +-inf commands saturate
+    # one `step` from the reference's trim point under u[1] = NaN
+    xt = oracle.rollout(golden("g567_trim_lin_lqr.npz")[f"trim_x_xcg{xcg}"][None], g[f"step_u_xcg{xcg}"][None], 1, xcg=xcg / 100, store=False)[0][0]
+    refs = g[f"step1_xcg{xcg}"]
+    assert np.isnan(xt[13]) and np.isnan(refs[13]) and np.isnan(xt).sum() == 1
+    assert rel(np.delete(xt, 13), np.delete(refs, 13)) < 1e-10
+
+
+@pytest.mark.parametrize("xcg", [25, 35])
+def test_g13_linear_model_closed_loops(xcg):
+    """The reference's LINEAR closed loops: test_env_mk2.py:46-62 (`LQR(linear=True)`, what main.py:35 runs: the frozen reduced model
+    under `_calc_LQR_action`, 10,000 steps) and test_env.py:501-576 (`test_LQR_lin`: u = -K (x - x_ref)).  The first one grows like
+    exp(14 t) (the spurious eigenvalue of the swapped flap derivatives) to 1e60: compared relative to the state norm."""
+    g = golden("g13_linear_loops.npz")
+    Ad, Bd, K, u0 = g[f"Ad_xcg{xcg}"], g[f"Bd_xcg{xcg}"], g[f"K_xcg{xcg}"], g[f"u0_xcg{xcg}"]
+    for c in range(3):
+        xr = np.zeros(9)
+        xr[4:7] = g[f"dem_xcg{xcg}"][c]
+        xs, us = mo.rollout_lqr_linear(g[f"x0_xcg{xcg}"][c], Ad, Bd, K, xr, u0, 10000, track=(4, 5, 6), every=100)
+        rx, ru = g[f"xtraj_xcg{xcg}"][c], g[f"utraj_xcg{xcg}"][c]
+        assert np.max(np.linalg.norm(xs - rx, axis=1) / np.linalg.norm(rx, axis=1)) < 1e-10
+        assert np.max(np.linalg.norm(us - ru, axis=1) / np.maximum(1.0, np.linalg.norm(ru, axis=1))) < 1e-10
+    assert np.abs(g[f"xtraj_xcg{xcg}"][0][-1]).max() > 1e50                    # (it does diverge: the reference's own behaviour)
+    xs, us = mo.rollout_lqr_linear(g[f"lin_x0_xcg{xcg}"], g[f"lin_A_xcg{xcg}"], g[f"lin_B_xcg{xcg}"], -g[f"lin_K_xcg{xcg}"],
+                                   g[f"lin_xref_xcg{xcg}"], np.zeros(3), 10000, every=100)
+    assert rel(xs, g[f"lin_xtraj_xcg{xcg}"]) < 1e-9 and rel(us, g[f"lin_utraj_xcg{xcg}"]) < 1e-9
+    # the model and the gain of test_env.py:509-545 themselves: the restated linearise -> ZOH -> dlqr(A, B, I, I)
+    Kl = mo.dlqr(g[f"lin_A_xcg{xcg}"], g[f"lin_B_xcg{xcg}"], np.eye(9), np.eye(3))
+    assert rel(Kl, g[f"lin_K_xcg{xcg}"]) < 1e-8
+
+
+def test_g13_toy_double_integrator_of_test_LQR_lin():
+    """test_env.py:528-541 (f16=False): the 2-state toy, here as a 9-state system padded with zeros -- the shape the device kernel has."""
+    g = golden("g13_linear_loops.npz")
+    A, B = np.zeros((9, 9)), np.zeros((9, 3))
+    A[:2, :2] = [[1, 1.0], [0, 1]]
+    B[1, 0] = 1.0
+    K = np.zeros((3, 9))
+    K[0, :2] = mo.dlqr(A[:2, :2], B[:2, :1], np.array([[1.0, 0.0], [0.0, 0.0]]), np.array([[1.0]]))
+    assert rel(K[:1, :2], g["toy_K"]) < 1e-10
+    xs, us = mo.rollout_lqr_linear([3, 1, 0, 0, 0, 0, 0, 0, 0], A, B, -K, [-3, 0, 0, 0, 0, 0, 0, 0, 0], np.zeros(3), 30)
+    assert rel(xs[:, :2], g["toy_xtraj"]) < 1e-10 and rel(us[:, :1], g["toy_utraj"]) < 1e-10
+
+
 def test_reference_asserting_tests(oracle):
     """test_env.py:40-147 (test_act_cmd_lims, test_act_rate_lims) restated on the oracle."""
     g = golden("g567_trim_lin_lqr.npz")

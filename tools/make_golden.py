@@ -435,8 +435,129 @@ def g12_lqr_loop_and_g8b_weights():
     print("g8b_mpc_qp_weights.npz", os.path.getsize(os.path.join(OUT, "g8b_mpc_qp_weights.npz")))
 
 
+def g13_round5():
+    """Round-5 fixtures, generated by RUNNING the reference (no osqp needed).
+    G3b: NaN through the actuator models -- `_calc_xdot` (env.py:65-103; np.clip of utils.py:303-330 PROPAGATES NaN) with NaN in
+    each surface command, in the thrust command and in the flap state lf1, +-inf and far-out-of-box commands, and ONE `step`
+    (env.py:105-130) under a NaN elevator command: what the reference does with the NaN command OSQP hands back for an infeasible
+    QP (env.py:420-424).  (Every case keeps the plant's own inputs xu[0:17] finite: with NaN INSIDE them the reference's interpn
+    finds no bracket, mexndinterp.c:125-138, and reads an undefined cell -- which is why a second step is not taken.)
+    G13: the linear-model closed loops -- what main.py:35 runs (test_env_mk2.py:46-62 `LQR(linear=True)`: x = ssr.Ad @ x + ssr.Bd @ u
+    under `_calc_LQR_action`, 10,000 steps at zero demands as written, plus rate demands and a perturbed start) and
+    test_env.py:501-576 `test_LQR_lin` (f16 model: K = dlqr(A, B, I, I), u = -K (x - x_ref), x = A x + B u; and its toy double
+    integrator).  Every 100th state / action of the long runs, every step of the toy."""
+    parameters, env, utils = import_reference()
+    libs = {25: ctypes.CDLL(os.path.join(REF, "C", "nlplant_xcg25.so")),
+            35: ctypes.CDLL(os.path.join(REF, "C", "nlplant_xcg35.so"))}
+    f16 = make_f16_objects(parameters, env, libs)
+    for k in libs:
+        if not clr_reads_zero(libs[k]):
+            raise SystemExit("this process's _CLr does not read ~0 (uninitialised heap): run the script again")
+    rng = np.random.default_rng(20261006)
+    nan = float("nan")
+    g3b = {}
+    for k, f in f16.items():
+        f.reset()
+        x0 = np.copy(f.x.values)
+        u0 = np.copy(f.u.values)
+        xs, us, xd = [], [], []
+        for case in range(10):
+            x, u = np.copy(x0), np.copy(u0)
+            x[3:6] += rng.uniform(-0.05, 0.05, 3)
+            x[13:16] += rng.uniform(-1, 1, 3)
+            if case < 4:
+                u[case] = nan                   # NaN thrust / elevator / aileron / rudder command
+            elif case == 4:
+                u[1:] = nan                     # what env.py:424 returns for an infeasible QP
+            elif case == 5:
+                u[1] = np.inf                   # np.clip(inf) = the bound
+            elif case == 6:
+                u[2] = -np.inf
+            elif case == 7:
+                x[17] = nan                     # lf1 (not a plant input: xu[0:17]) -> both flap derivatives
+            elif case == 8:
+                u[:] = [1e9, -1e9, 1e9, -1e9]   # far outside the command boxes
+            xs.append(np.copy(x)), us.append(np.copy(u)), xd.append(np.copy(f._calc_xdot(x, u)))
+        g3b[f"x_xcg{k}"], g3b[f"u_xcg{k}"], g3b[f"xdot_xcg{k}"] = np.array(xs), np.array(us), np.array(xd)
+        # one step under a NaN elevator command (the envelope test of env.py:117-124 lets NaN through: every comparison is False)
+        f.reset()
+        f.u.values[1] = nan
+        f.step(f.u.values)
+        g3b[f"step1_xcg{k}"] = np.copy(f.x.values)
+        g3b[f"step_u_xcg{k}"] = np.copy(f.u.values)
+        f.reset()
+    for k in libs:
+        if not clr_reads_zero(libs[k]):
+            raise SystemExit("_CLr stopped reading ~0 during the run: run the script again")
+    np.savez_compressed(os.path.join(OUT, "g3b_nan_actuators.npz"), **g3b)
+    print("g3b_nan_actuators.npz", os.path.getsize(os.path.join(OUT, "g3b_nan_actuators.npz")))
+
+    from scipy.signal import cont2discrete
+    g13 = {}
+    T = 10000                                                     # test_env_mk2.py:28-30: time_end 10 at dt 0.001
+    for k, f in f16.items():
+        f.reset()
+        K = f._calc_LQR_gain()                                    # test_env_mk2.py:37
+        g13[f"K_xcg{k}"], g13[f"Ad_xcg{k}"], g13[f"Bd_xcg{k}"] = K, np.copy(f.ssr.Ad), np.copy(f.ssr.Bd)
+        x_init = f.x._get_mpc_x()
+        u0 = np.copy(f.u.initial_condition[1:])
+        g13[f"u0_xcg{k}"] = u0
+        x0s, dems, xt, ut = [], [], [], []
+        for case in range(3):
+            x = np.copy(x_init)
+            dem = np.zeros(3)                                     # test_env_mk2.py:40-42 as written
+            if case == 1:
+                dem = np.array([0.1, -0.05, 0.02])
+            elif case == 2:
+                dem = np.array([-0.05, 0.08, 0.03])
+                x[:7] += rng.uniform(-0.05, 0.05, 7)
+            x0s.append(np.copy(x)), dems.append(dem)
+            xs_, us_ = [], []
+            for idx in range(T):                                  # test_env_mk2.py:54-62
+                u = f._calc_LQR_action(dem[0], dem[1], dem[2], K, x, u0)
+                x = f.ssr.Ad @ x + f.ssr.Bd @ u
+                if (idx + 1) % 100 == 0:
+                    xs_.append(np.copy(x)), us_.append(np.copy(u))
+            xt.append(np.array(xs_)), ut.append(np.array(us_))
+        g13[f"x0_xcg{k}"], g13[f"dem_xcg{k}"] = np.array(x0s), np.array(dems)
+        g13[f"xtraj_xcg{k}"], g13[f"utraj_xcg{k}"] = np.array(xt), np.array(ut)
+        # test_env.py:501-576 with f16=True (the trim of the object as built, env.py:42: same call as test_env.py:506)
+        f.reset()
+        A, B, C, D = f.linearise(f.x._get_mpc_x(), f.u._get_mpc_u(), _calc_xdot=f._calc_xdot_na, get_obs=f._get_obs_na)
+        A, B, C, D = cont2discrete((A, B, C, D), f.paras.dt)[0:4]
+        x = f.x._get_mpc_x()[:, None]
+        x_ref = np.copy(x)
+        Kl = utils.dlqr(A, B, np.eye(9), np.eye(3))
+        x = x + rng.uniform(-0.02, 0.02, (9, 1))                  # (as written x = x_ref and u = 0 for ever: start off the reference)
+        g13[f"lin_x0_xcg{k}"], g13[f"lin_xref_xcg{k}"], g13[f"lin_K_xcg{k}"] = x[:, 0].copy(), x_ref[:, 0].copy(), Kl
+        g13[f"lin_A_xcg{k}"], g13[f"lin_B_xcg{k}"] = A, B
+        xs_, us_ = [], []
+        for i in range(T):                                        # test_env.py:553-559
+            u = - Kl @ (x - x_ref)
+            x = A @ x + B @ u
+            if (i + 1) % 100 == 0:
+                xs_.append(x[:, 0].copy()), us_.append(u[:, 0].copy())
+        g13[f"lin_xtraj_xcg{k}"], g13[f"lin_utraj_xcg{k}"] = np.array(xs_), np.array(us_)
+    # test_env.py:528-541: the toy double integrator (dt 0.1, 3 s)
+    x = np.array([3, 1])[np.newaxis].T
+    x_ref = np.array([-3, 0])[np.newaxis].T
+    A = np.array([[1, 1.0], [0, 1]])
+    B = np.array([0.0, 1])[:, None]
+    Kt = utils.dlqr(A, B, np.array([[1.0, 0.0], [0.0, 0.0]]), np.array([[1.0]]))
+    xs_, us_ = [], []
+    for i in range(30):
+        u = - Kt @ (x - x_ref)
+        x = A @ x + B @ u
+        xs_.append(x[:, 0].copy()), us_.append(u[:, 0].copy())
+    g13["toy_K"], g13["toy_xtraj"], g13["toy_utraj"] = Kt, np.array(xs_), np.array(us_)
+    np.savez_compressed(os.path.join(OUT, "g13_linear_loops.npz"), **g13)
+    print("g13_linear_loops.npz", os.path.getsize(os.path.join(OUT, "g13_linear_loops.npz")))
+
+
 if __name__ == "__main__":
-    if "--g12" in sys.argv:
+    if "--g13" in sys.argv:
+        g13_round5()
+    elif "--g12" in sys.argv:
         g12_lqr_loop_and_g8b_weights()
     elif "--g10" in sys.argv:
         g10_time_histories()
