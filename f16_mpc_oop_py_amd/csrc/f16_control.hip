@@ -23,6 +23,7 @@
 #include "f16_plant.hpp"
 #include "f16_smallmat.hpp"
 #include "f16_mpc.hpp"
+#include "f16_mpc_state.hpp"
 
 namespace f16 {
 
@@ -239,11 +240,6 @@ __device__ __forceinline__ d4_t tile9(const double *M, bool transpose) {
   return t;
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
-
 // W <- M^-1 for the 9x9 tile M: Gauss-Jordan with partial pivoting on [M | I] held one COLUMN per lane (lanes 0..17,
 // nine rows in registers).  A pivot step broadcasts the pivot column from its lane (v_readlane -> scalars), so the pivot
 // search and the multipliers are wave-uniform and the step needs no LDS and no barrier; rows are not swapped, the row
@@ -428,25 +424,6 @@ __global__ __launch_bounds__(64, 3) void k_lqr(LqrArgs a) {
 }
 
 // ------------------------------------------------------------------------------------ MPC (QP build + ADMM)
-// out[3j+c] = sum_{i>=j} sum_{r in rows} G_{i-j}[r][c] * v[i*NR + rr]   (CC' v restricted to `rows`)
-template <int NR>
-__device__ __forceinline__ void conv_adjoint(double *out, const double *G, const double *v, int N, const int *rows) {
-  for (int e = lane_id(); e < 3 * N; e += F16_WAVE) {
-    const int j = e / 3, c = e - 3 * j;
-    double s = 0.0;
-#pragma unroll 2
-    for (int i = j; i < N; ++i) {              // per-step dot products are independent chains; only the final add is serial
-      const double *g = G + (i - j) * 27 + c;
-      const double *vi = v + i * NR;
-      double t = 0.0;
-#pragma unroll
-      for (int rr = 0; rr < NR; ++rr) t += g[(NR == 9 ? rr : rows[rr]) * 3] * vi[rr];
-      s += t;
-    }
-    out[e] = s;
-  }
-}
-
 // (CC U)[i][r] = sum_{j<=i} sum_c G_{i-j}[r][c] U[3j+c]
 __device__ __forceinline__ double conv_forward_row(const double *G, const double *U, int i, int r) {
   double s = 0.0;
@@ -531,6 +508,11 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
                        : ((l >= 5 && l < 8 && a.dem) ? a.dem[(l - 5) * a.ld + b] : v);   // env.py:380-383 (x_ref[5:8] = demands)
     }
     __syncthreads();
+    // a state that is not finite leaves no QP to solve (f16_mpc.hpp: mpc_job_nonfinite)
+    bool fin_ = l < 9 ? (isfinite(x9[l]) && isfinite(xref[l])) : true;
+    if (l < 3 && a.x) fin_ = fin_ && isfinite(a.x[(13 + l) * a.ld + b]);
+    const bool nonfinite = __ballot(!fin_) != 0;
+    if (a.ext && l == 0) a.ext[(size_t)b * mpc_ext_doubles(N) + mpc_ext_flag(N)] = nonfinite ? 1.0 : 0.0;
     BSTAMP(0)
     if (!update_only) {
     dare_sda_wave(A, Bm, Q, X, scr, a.pb.custom_r ? a.pb.Rinv : nullptr);
@@ -563,35 +545,10 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
     }
     BSTAMP(2)
     }
-    {   // pred_i = A pred_(i-1): lane r < 9 carries component r, the operands come by v_readlane
-      const int r = l < 9 ? l : 0;
-      double ar[9], pv = x9[r];
-#pragma unroll
-      for (int p = 0; p < 9; ++p) ar[p] = A[r * 9 + p];
-      for (int i = 0; i < N; ++i) {
-        double sacc = 0.0;
-#pragma unroll
-        for (int p = 0; p < 9; ++p) sacc += ar[p] * readlane_f64(pv, p);
-        pv = sacc;
-        if (l < 9) pred[i * 9 + l] = pv;
-      }
-      __syncthreads();
-    }
+    // ---------------- pred_i = A^(i+1) x and q = -2 CC' QQ (x_ref - MM x)   (utils.py:112; f16_mpc_state.hpp: the closed-loop
+    // rollout kernel of f16_mpc_wave.hip runs the very same code per step)
+    mpc_state_vectors(A, Q, Qb, G, x9, xref, pred, wbuf, qv, N);
     BSTAMP(3)
-    // ---------------- q = -2 CC' QQ (x_ref - MM x)   (utils.py:112)
-    for (int e = l; e < 9 * N; e += F16_WAVE) {
-      const int i = e / 9, r = e - 9 * i;
-      const double *Qi = (i == N - 1) ? Qb : Q;
-      double s = 0.0;
-      for (int p = 0; p < 9; ++p) s += Qi[r * 9 + p] * (xref[p] - pred[i * 9 + p]);
-      wbuf[e] = s;                                       // (m = 12N >= 9N)
-    }
-    __syncthreads();
-    conv_adjoint<9>(qv, G, wbuf, N, nullptr);
-    __syncthreads();
-    for (int e = l; e < n; e += F16_WAVE) qv[e] = -2.0 * qv[e];
-    __threadfence_block();
-    __syncthreads();
     BSTAMP(4)
     // ---------------- P = 2 (CC' QQ CC + RR), packed lower, to the workspace.  (A'A is no longer formed here: the solvers
     // need the row-WEIGHTED Gram A'WA of the equilibrated problem, which has no Toeplitz recursion, and build it themselves.)
@@ -691,6 +648,7 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
     if (SETUP_ONLY && a.useq && l == 0) for (int i = 0; i < 7; ++i) { a.useq[i * a.ld + b] = (double)tB[i]; tB[i] = 0; }
 #endif
     if (SETUP_ONLY) { __syncthreads(); continue; }
+    if (nonfinite) { mpc_write_nonfinite(a, b, l, F16_WAVE); __syncthreads(); continue; }
     // ---------------- the solve (the published OSQP algorithm; same coordinates as f16_mpc_solve.hip:
     // x stays unscaled, the linear system is (c P + sigma D^-2 + rho A'WA) x~ = sigma D^-2 x - c q + A' E (rho zb - yb))
     const double sigma = a.s.sigma, alpha = a.s.alpha;
@@ -1366,6 +1324,7 @@ struct f16_mpc_plan {
   int32_t *sched;      // [2][B]: iteration counts of the last solve | dispatch order of the next (longest first)
   bool have_order;
   void *last_stream;   // the stream of the creation / the last solve: what f16_mpc_plan_destroy waits for
+  void *roll_sync;     // f16_rollout_mpc: ticket counter + per-aircraft progress counters (allocated by its first call)
   MpcArgs a;
 };
 
@@ -1393,6 +1352,7 @@ extern "C" int f16_mpc_plan_create_w(f16_ctx *ctx, f16_mpc_plan **plan, const do
   f16_mpc_plan *p = new f16_mpc_plan();
   p->ctx = ctx; p->B = B; p->ld = ld; p->N = hzn; p->dt = dt;
   p->warm = nullptr; p->warm_on = false; p->have_prev = false; p->sched = nullptr; p->have_order = false; p->last_stream = stream;
+  p->roll_sync = nullptr;
   if (s) p->s = *s; else f16_qp_default_settings(&p->s);
   if (p->s.check_every < 1 || p->s.rho_every < 1 || !(p->s.rho >= 0) || !(p->s.sigma > 0) || p->s.max_iter < 1 || p->s.scaling < 0 ||
       p->s.scaling > 100 || (p->s.scaling > 0 && !(p->s.rho > 0)) || (p->s.adaptive_rho && p->s.rho_every % p->s.check_every != 0)) {
@@ -1460,6 +1420,26 @@ extern "C" int f16_mpc_plan_solve_w(f16_mpc_plan *p, const double *x, const doub
   return F16_OK;
 }
 
+extern "C" int f16_rollout_mpc(f16_mpc_plan *p, double *x, double *u, const double *dem, double *traj, double *cmd_traj,
+                               int32_t *iters_traj, int32_t *status, int nsteps, int traj_every, double xcg, int fi_flag,
+                               unsigned flags, void *stream) {
+  if (!p || !x || !u || !dem) return set_error(F16_EINVAL, "bad argument to f16_rollout_mpc");
+  if (p->N > WAVE_MAXN || p->s.scaling <= 0 || p->warm_on)
+    return set_error(F16_EINVAL, "f16_rollout_mpc needs a plan with hzn <= 30, equilibrated solves (scaling > 0) and no warm start; "
+                                 "other plans run the host loop (f16_mpc_plan_solve + f16_rollout per step)");
+  if (nsteps < 0 || (traj && (traj_every < 1 || nsteps % traj_every != 0)))
+    return set_error(F16_EINVAL, "nsteps must be >= 0 and a multiple of traj_every >= 1 when traj is given");
+  if (nsteps == 0) return F16_OK;
+  if (!p->roll_sync) {
+    if (int rc = hip_check(hipMalloc(&p->roll_sync, 8 + (size_t)p->B * sizeof(int32_t)), "hipMalloc f16_rollout_mpc counters")) return rc;
+  }
+  p->last_stream = stream;
+  RolloutMpcCall c{};
+  c.x = x; c.u = u; c.dem = dem; c.traj = traj; c.cmd_traj = cmd_traj; c.iters_traj = iters_traj; c.status = status;
+  c.sync = p->roll_sync; c.T = nsteps; c.every = traj ? traj_every : nsteps + 1; c.xcg = xcg; c.fi = fi_flag; c.flags = flags;
+  return mpc_wave_rollout_launch(p->ctx, p->a, c, stream);
+}
+
 extern "C" int f16_mpc_plan_warm_start(f16_mpc_plan *p, int on) {
   if (!p) return set_error(F16_EINVAL, "bad argument to f16_mpc_plan_warm_start");
   if (on && p->N > FAST_MAXN) return set_error(F16_EINVAL, "warm start needs hzn <= 32 (the long-horizon solver starts cold)");
@@ -1478,6 +1458,7 @@ extern "C" void f16_mpc_plan_destroy(f16_mpc_plan *p) {
   (void)hipFree(p->buf);
   if (p->sched) (void)hipFree(p->sched);
   if (p->warm) (void)hipFree(p->warm);
+  if (p->roll_sync) (void)hipFree(p->roll_sync);
   delete p;
 }
 

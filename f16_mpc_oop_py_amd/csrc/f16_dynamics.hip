@@ -855,6 +855,15 @@ static int rollout_dispatch(f16_ctx *ctx, DynArgs &a, void *stream) {
   const int fi_flag = a.fi;
   static const long max4w = [] { const char *e = getenv("F16_ROLLOUT_4W_MAXB"); return e ? atol(e) : 64L * 256; }();
   static const long maxq = [] { const char *e = getenv("F16_ROLLOUT_QUAD_MAXB"); return e ? atol(e) : 16L * 256; }();
+  if (a.flags & F16_FLAG_ONE_LANE) {
+    // results independent of the batch size: one instantiation (64-lane workgroups, one lane per aircraft, fp64 table image) for every B
+    const long blocks = (B + 63) / 64;
+    const unsigned grid = (unsigned)(blocks < 256 ? blocks : 256);
+    const hipStream_t st = (hipStream_t)stream;
+    if (fi_flag == 0) hipLaunchKernelGGL((k_rollout<64, 0, LQR>), dim3(grid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_rollout<64, -1, LQR>), dim3(grid), dim3(64), 0, st, a);
+    return hip_check(hipGetLastError(), "f16_rollout launch");
+  }
   if (fi_flag == 1 && B <= maxq) {
     // at most 16 aircraft per CU: four lanes per aircraft, one 16-aircraft workgroup per CU
     hipLaunchKernelGGL((k_rollout_q<1, LQR>), dim3((unsigned)((B + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a);

@@ -80,9 +80,29 @@ struct MpcArgs {
 };
 
 
-// per-aircraft extras written by the setup kernel: q[n] | G[27N] | pred[9N] | A[81] Q[81] Qbar[81] | rho, ok
-__host__ __device__ inline size_t mpc_ext_doubles(int N) { return (size_t)3 * N + 27 * N + 9 * N + 243 + 2; }
+// per-aircraft extras written by the setup kernel: q[n] | G[27N] | pred[9N] | A[81] Q[81] Qbar[81] | rho, ok | nonfinite, pad
+__host__ __device__ inline size_t mpc_ext_doubles(int N) { return (size_t)3 * N + 27 * N + 9 * N + 243 + 4; }
 __host__ __device__ inline size_t mpc_ext_model(int N) { return (size_t)3 * N + 27 * N + 9 * N; }      // offset of A | Q | Qbar | rho
+__host__ __device__ inline size_t mpc_ext_flag(int N) { return mpc_ext_model(N) + 245; }              // 1.0: the state of this call is not finite
+// A call whose state (x9, the actuator positions, the reference) is not finite has no QP to solve: OSQP would iterate on NaN up to
+// max_iter (40,000 iterations, env.py:421) and hand back NaN.  Same answer here without the iterations: the build kernel raises the
+// flag, every solver asks for it first and writes NaN commands, zero iterations and F16_ST_NONFINITE.  (A NaN state is what the
+// reference's loop is left with one step after an infeasible QP: NaN command -> NaN actuator state, utils.py:308-330.)
+__device__ __forceinline__ bool mpc_job_nonfinite(const MpcArgs &a, long b) {
+  return a.ext && a.ext[(size_t)b * mpc_ext_doubles(a.N) + mpc_ext_flag(a.N)] != 0.0;
+}
+__device__ __forceinline__ void mpc_write_nonfinite(const MpcArgs &a, long b, int tid, int nthreads) {
+  const double nan_ = __builtin_nan("");
+  for (int e = tid; e < 3 * a.N; e += nthreads) {
+    if (e < 3) a.ucmd[e * a.ld + b] = nan_;
+    if (a.useq) a.useq[e * a.ld + b] = nan_;
+  }
+  if (tid == 0) {
+    if (a.iters_out) a.iters_out[b] = 0;
+    if (a.info) { a.info[0 * a.ld + b] = 0.0; a.info[1 * a.ld + b] = nan_; a.info[2 * a.ld + b] = nan_; a.info[3 * a.ld + b] = a.s.rho; }
+    if (a.status) a.status[b] |= F16_ST_NONFINITE;
+  }
+}
 __host__ __device__ inline size_t mpc_big_doubles(int N) {      // (see k_mpc<false, true>)
   const size_t rows = (size_t)64 * ((12 * N + 63) / 64), n = (size_t)3 * N;
   return 7 * rows + n * (n + 1) / 2;
@@ -97,6 +117,19 @@ constexpr int WAVE_SCAL_OFF = 7936;
 constexpr int WAVE_PBLK_DOUBLES = 2 * 36 * 64 * 2;      // P block image | per-lane image of the Toeplitz operands
 bool mpc_wave_enabled(const MpcArgs &a);
 int mpc_wave_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream);
+// the closed-loop rollout (f16_rollout_mpc): per-call arguments beside the plan's MpcArgs
+struct RolloutMpcCall {
+  double *x, *u;
+  const double *dem;
+  double *traj, *cmd_traj;
+  int32_t *iters_traj, *status;
+  void *sync;                 // [8 bytes ticket counter | B x int32 progress], zeroed by the launch
+  int T, every;
+  double xcg;
+  int fi;
+  unsigned flags;
+};
+int mpc_wave_rollout_launch(f16_ctx *ctx, const MpcArgs &a, const RolloutMpcCall &c, void *stream);
 
 // f16_mpc_big.hip: one 512-lane workgroup per aircraft, 33 <= N <= 150 (operands in the HBM workspace `bigws`)
 size_t mpc_big_ws_doubles(int N);

@@ -24,6 +24,8 @@
 #include <type_traits>
 
 #include "f16_mpc.hpp"
+#include "f16_mpc_state.hpp"
+#include "f16_plant.hpp"
 #include "f16_smallmat.hpp"
 #include "f16_wave_tables.inc"
 
@@ -1360,28 +1362,17 @@ __device__ __noinline__ void p_block_image(const double *Pg, double *pb, int n) 
 // the measured durations of the same launch).  With `wave_queue` the grid is one workgroup per SIMD and the queue is ours: a
 // workgroup takes the next aircraft of the dispatch order from an atomic counter whenever it is free, until the counter passes B
 // (an exit every workgroup reaches, whatever the number of resident ones).
-__global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
-  const int N = a.N, n = 3 * N;
-  const Role R = role(N);
-  const int l = R.l;
-  for (long job = blockIdx.x;; ) {
-  if (a.wave_queue) {
-    unsigned q = 0;
-    if (l == 0) q = atomicAdd(a.wave_queue, 1u);
-    job = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)q);
-    if (job >= a.B) break;
-    wave_lds_sync();                                         // (the previous aircraft's LDS traffic is over on every lane)
-  }
+// ... of aircraft b by this wavefront: prologue, equilibration, factorise / iterate / test until done.  Leaves the solution in
+// `st` (lane 0 holds the first move st.x[0..2]) and, with a warm-start buffer, the solution for the next call; returns whether every
+// factorisation succeeded.  Called by k_mpc_wave (one calc_MPC_action per aircraft) and by k_rollout_mpc (one per aircraft and step).
+__device__ __forceinline__ bool solve_aircraft(const MpcArgs &a, long b, long job, const Role &R, SolveState &st
 #ifdef F16_EXP_STAMPW
-  const unsigned long long wc0_ = wall_clock64();
-  if (job == 0 && l == 0) g_stamp_wg = (int)blockIdx.x;
+                                               , unsigned long long &tK0
 #endif
-  // No order from a previous call (first call on this stream / batch size): NOT the caller's order either -- workgroup ids go to
-  // the XCDs round-robin, and how hard an aircraft is tends to follow its index (the config-4 workload: every aircraft = 0, 3, 6
-  // mod 8 needs twice the iterations), so the identity gives three XCDs twice the work of the others.  A fixed stride coprime to
-  // B spreads any such pattern; the results do not depend on the map.
-  const long b = a.order ? (long)__builtin_amdgcn_readfirstlane(a.order[job])
-                         : (a.wave_stride ? (long)(((unsigned long long)job * a.wave_stride) % (unsigned long long)a.B) : job);
+                                               ) {
+  const int N = a.N, n = 3 * N;
+  const int l = R.l;
+  (void)job;
   double *const exw = a.ext + (size_t)b * mpc_ext_doubles(N);
   const double *Pg = a.Ppk + (size_t)b * (n * (n + 1) / 2);
   const double *Gg = exw + n, *pred = exw + n + 27 * N;
@@ -1454,7 +1445,6 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
   }
   wave_lds_sync();
   gram_tiles(gw, N);                                         // A'WA -> workspace (every lane reads back what it wrote itself)
-  SolveState st;
 #pragma unroll
   for (int c = 0; c < 3; ++c) { st.x[c] = 0.0; st.zA[c] = 0.0; st.yA[c] = 0.0; st.zB[c] = 0.0; st.yB[c] = 0.0; st.dyA[c] = 0.0; st.dyB[c] = 0.0; }
   st.rp = INFINITY; st.rd = INFINITY; st.it = 0; st.to_check = a.s.check_every > 0 ? a.s.check_every : 1;
@@ -1477,7 +1467,7 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
 #ifdef F16_EXP_STAMPW
   if (job == 0 && l < 16) g_wstamp[l] = 0;
   if (job == 0 && l < 8) g_tstamp[l] = 0;
-  const unsigned long long tK0 = __builtin_amdgcn_s_memtime();
+  tK0 = __builtin_amdgcn_s_memtime();
 #endif
   IterSettings o;
   o.alpha = a.s.alpha; o.eps_abs = a.s.eps_abs; o.eps_rel = a.s.eps_rel; o.eps_prim_inf = a.s.eps_prim_inf;
@@ -1485,15 +1475,53 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
   const bool anyeq = __ballot((C.eqA | C.eqB) != 0) != 0;      // (wave-uniform)
   const bool ok = anyeq ? solve_loop<true>(&st, &C, Pg, pb, gw, gimg, exw, scal, N, cs, o, R)
                         : solve_loop<false>(&st, &C, Pg, pb, gw, gimg, exw, scal, N, cs, o, R);
-  const bool converged = st.converged != 0, infeasible = st.infeasible != 0;
   if (wm) {                                                  // keep the solution for the next warm start
-    const bool good = converged && !infeasible;
+    const bool good = st.converged != 0 && st.infeasible == 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       wm[c * 64] = good ? st.x[c] : NAN; wm[(3 + c) * 64] = good ? st.zA[c] : NAN; wm[(9 + c) * 64] = good ? st.zB[c] : NAN;
       wm[(6 + c) * 64] = good ? C.WA[c] * st.yA[c] / cs : NAN; wm[(12 + c) * 64] = good ? C.WB[c] * st.yB[c] / cs : NAN;
     }
   }
+  return ok;
+}
+
+__global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
+  const int N = a.N;
+  const Role R = role(N);
+  const int l = R.l;
+  for (long job = blockIdx.x;; ) {
+  if (a.wave_queue) {
+    unsigned q = 0;
+    if (l == 0) q = atomicAdd(a.wave_queue, 1u);
+    job = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)q);
+    if (job >= a.B) break;
+    wave_lds_sync();                                         // (the previous aircraft's LDS traffic is over on every lane)
+  }
+#ifdef F16_EXP_STAMPW
+  const unsigned long long wc0_ = wall_clock64();
+  if (job == 0 && l == 0) g_stamp_wg = (int)blockIdx.x;
+  unsigned long long tK0 = 0;
+#endif
+  // No order from a previous call (first call on this stream / batch size): NOT the caller's order either -- workgroup ids go to
+  // the XCDs round-robin, and how hard an aircraft is tends to follow its index (the config-4 workload: every aircraft = 0, 3, 6
+  // mod 8 needs twice the iterations), so the identity gives three XCDs twice the work of the others.  A fixed stride coprime to
+  // B spreads any such pattern; the results do not depend on the map.
+  const long b = a.order ? (long)__builtin_amdgcn_readfirstlane(a.order[job])
+                         : (a.wave_stride ? (long)(((unsigned long long)job * a.wave_stride) % (unsigned long long)a.B) : job);
+  if (mpc_job_nonfinite(a, b)) {                             // (wave-uniform) no QP to solve: NaN command, zero iterations
+    mpc_write_nonfinite(a, b, l, 64);
+    if (!a.wave_queue) break;
+    continue;
+  }
+  SolveState st;
+#ifdef F16_EXP_STAMPW
+  const bool ok = solve_aircraft(a, b, job, R, st, tK0);
+#else
+  const bool ok = solve_aircraft(a, b, job, R, st);
+#endif
+  const int kx = 3 * R.istep;
+  const bool converged = st.converged != 0, infeasible = st.infeasible != 0;
   // res.x[0:3] (env.py:424); OSQP hands back NaN for a problem it certifies infeasible
   if (R.act && R.par == 0) {
 #pragma unroll
@@ -1531,6 +1559,186 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
   if (job == 0 && l == 0) g_stamp_wg = -1;
 #endif
   if (!a.wave_queue) break;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// The closed-loop MPC rollout as ONE launch (BASELINE config 5; the reference's loop test_env.py:480-495:
+//     cmd = _calc_MPC_action(p, q, r, hzn);  u.values[1:] = cmd;  step(u.values)
+// per step, the model frozen as env.py:49-60 freezes it).  Aircraft never interact, so nothing in the loop needs a step to END for
+// every aircraft before the next one starts -- the host loop (dist.closed_loop_mpc_rollout: six launches per step) joins the whole
+// batch after every solve and a step lasts as long as its slowest aircraft (mean 458 iterations, longest 4,503 in the recorded
+// config-5 run).  Here the grid is one wavefront-workgroup per SIMD, as in k_mpc_wave's queue mode, and the work items are the
+// (step, aircraft) pairs in step-major order, drawn from ONE ticket counter: ticket k = step k / B of aircraft perm(k % B).  A
+// wavefront does everything of its pair: the state-dependent vectors of the QP (f16_mpc_state.hpp, the build kernel's own code),
+// the solve (solve_aircraft above), the command into u.values, one Euler step of the plant (env.py:105-130; the table image is read
+// from global memory -- it stays in L2 -- because the solver's 40 KB of LDS per wavefront leave no room for it), the trajectory
+// sample.  Step t of an aircraft needs step t - 1 of the SAME aircraft only: the wavefront that draws (t, b) waits for
+// progress[b] == t, a per-aircraft counter the finisher of (t - 1, b) bumps behind an agent-scope release; the taker runs an
+// agent-scope acquire before it reads x / u / status (MI355X_MICROARCH.md, "inter-workgroup visibility": plain stores -> vmcnt(0)
+// -> barrier -> release fence -> vmcnt(0) -> relaxed flag store | relaxed poll -> acquire fence -> vmcnt(0) -> barrier -> plain
+// loads).  No deadlock: tickets are handed out in order, so the pair a wavefront waits for was drawn earlier, i.e. by a wavefront
+// that is resident and itself waits only for an even earlier ticket; every wavefront leaves when the counter passes T x B.
+// With B >> 1024 the predecessor ticket is B tickets old -- finished long ago unless it is a many-times-the-mean straggler.
+struct RollMpcArgs {
+  MpcArgs m;                     // the plan's arguments: workspace, settings, weights (m.x = x: the solver reads the actuator states)
+  double *x;                     // [18][ld] x.values, in place
+  double *u;                     // [4][ld] u.values: thrust command held, u[1:4] <- the command of every step
+  const double *dem;             // [3][ld] (p, q, r) demands
+  double *traj;                  // [T / every][18][ld] or null
+  double *cmd_traj;              // [T][3][ld] or null: what calc_MPC_action returned at each step (NaN: infeasible / not finite / no solve)
+  int32_t *iters_traj;           // [T][ld] or null
+  int32_t *status;               // [ld], sticky
+  unsigned long long *queue;     // ticket counter, zero at the launch
+  int32_t *progress;             // [B] steps completed per aircraft, zero at the launch
+  const double *tab, *lofi;      // table images (global)
+  int T, every;
+  double xcg;
+  int fi;
+  unsigned flags, stride;
+};
+
+__device__ __forceinline__ double bcast0_f64(double v) {       // lane 0's value on every lane
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+constexpr int RU_A = 0, RU_Q = 81, RU_QB = 162, RU_G = 256, RU_X9 = RU_G + 27 * WN + 6, RU_XREF = RU_X9 + 10, RU_PRED = RU_XREF + 10,
+              RU_WBUF = RU_PRED + 9 * WN + 2, RU_QV = RU_WBUF + 9 * WN + 2;
+static_assert(RU_QV + 3 * WN <= LDS_DOUBLES, "state-vector scratch of the rollout kernel");
+
+__global__ __launch_bounds__(64, 1) void k_rollout_mpc(RollMpcArgs ra) {
+  const MpcArgs &a = ra.m;
+  const int N = a.N, n = 3 * N;
+  const Role R = role(N);
+  const int l = R.l;
+  const unsigned long long B = (unsigned long long)a.B, total = (unsigned long long)ra.T * B;
+  const long ld = a.ld;
+  for (;;) {
+    unsigned long long k = 0;
+    if (l == 0) k = atomicAdd(ra.queue, 1ull);
+    k = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(k >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)k);
+    if (k >= total) break;
+    const int t = (int)(k / B);
+    const unsigned long long j = k - (unsigned long long)t * B;
+    const long b = ra.stride ? (long)((j * ra.stride) % B) : (long)j;
+    // ---- wait for step t - 1 of this aircraft, then acquire what its wavefront published
+    if (t > 0 && l == 0) {
+      while (__hip_atomic_load(&ra.progress[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t) __builtin_amdgcn_s_sleep(16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- the aircraft at the start of the step (every lane holds it: the loads are broadcasts)
+    double x[18], u[4];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) x[i] = ra.x[i * ld + b];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = ra.u[i * ld + b];
+    int stw = ra.status ? ra.status[b] : 0;
+    // env.py:117-124 comes first in `step`; the reference exit()s there: the aircraft is frozen and flagged, and it is not solved for
+    // any more (the host loop goes on solving for it: same states, wasted iterations)
+    if (!(stw & ST_ENVELOPE) && !(ra.flags & FLAG_NO_ENVELOPE) && outside_envelope(x)) stw |= ST_ENVELOPE | envelope_state_bits(x);
+    const bool live = !(stw & ST_ENVELOPE);
+    double cmd[3] = {NAN, NAN, NAN};
+    int iters = 0;
+    if (live) {
+      bool fin = true;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { const int MX[9] = {3, 4, 7, 8, 9, 10, 11, 17, 16}; fin = fin && isfinite(x[MX[i]]); }
+      fin = fin && isfinite(x[13]) && isfinite(x[14]) && isfinite(x[15]);
+      double dm[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { dm[c] = ra.dem[c * ld + b]; fin = fin && isfinite(dm[c]); }
+      if (fin) {
+        // the state-dependent vectors of the QP into this aircraft's workspace block (what the build kernel does per call)
+        double *const exw = a.ext + (size_t)b * mpc_ext_doubles(N);
+        const double *exm = exw + mpc_ext_model(N);
+        wave_lds_sync();
+        for (int e = l; e < 81; e += 64) { s_w[RU_A + e] = exm[e]; s_w[RU_Q + e] = exm[81 + e]; s_w[RU_QB + e] = exm[162 + e]; }
+        for (int e = l; e < 27 * N; e += 64) s_w[RU_G + e] = exw[n + e];
+        if (l < 9) {
+          const int MX[9] = {3, 4, 7, 8, 9, 10, 11, 17, 16};
+          double v = x[0];
+#pragma unroll
+          for (int i = 0; i < 18; ++i) v = MX[l] == i ? x[i] : v;
+          s_w[RU_X9 + l] = v;
+          s_w[RU_XREF + l] = (l >= 5 && l < 8) ? (l == 5 ? dm[0] : (l == 6 ? dm[1] : dm[2])) : v;          // env.py:380-383
+        }
+        __syncthreads();
+        mpc_state_vectors(s_w + RU_A, s_w + RU_Q, s_w + RU_QB, s_w + RU_G, s_w + RU_X9, s_w + RU_XREF, s_w + RU_PRED, s_w + RU_WBUF,
+                          s_w + RU_QV, N);
+        for (int e = l; e < n; e += 64) exw[e] = s_w[RU_QV + e];
+        for (int e = l; e < 9 * N; e += 64) exw[n + 27 * N + e] = s_w[RU_PRED + e];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        SolveState st;
+#ifdef F16_EXP_STAMPW
+        unsigned long long tK0 = 0;
+        const bool ok = solve_aircraft(a, b, (long)k + 1, R, st, tK0);
+#else
+        const bool ok = solve_aircraft(a, b, (long)k + 1, R, st);
+#endif
+        const bool infeasible = __builtin_amdgcn_readfirstlane(st.infeasible) != 0;
+        const bool converged = __builtin_amdgcn_readfirstlane(st.converged) != 0;
+        iters = __builtin_amdgcn_readfirstlane(st.it);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) cmd[c] = infeasible ? NAN : bcast0_f64(st.x[c]);       // res.x[0:3], env.py:424 (lane 0 owns step 0)
+        if (infeasible) stw |= F16_ST_QP_INFEASIBLE;
+        else if (!converged || !__builtin_amdgcn_readfirstlane((int)ok)) stw |= F16_ST_QP_MAXITER;
+        wave_lds_sync();
+      } else {
+        stw |= ST_NONFINITE;                                   // no QP to solve (f16_mpc.hpp: mpc_job_nonfinite): NaN command
+      }
+      // u.values[1:] = cmd (test_env.py:490-493); F16_FLAG_HOLD_COMMAND: a step without a command keeps the previous one
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (!((ra.flags & F16_FLAG_HOLD_COMMAND) && cmd[c] != cmd[c])) u[1 + c] = cmd[c];
+      // step(u.values): env.py:126, the one-lane rollout kernel's own step (f16_dynamics.hip: rollout_lanes, exact trigonometry)
+      {
+        const TrigSlots ts{s_w, 1};
+        Trig5 g;
+        trig_exact(x, g);
+        trig_store(ts, g);
+        double xd[18];
+        int sa = 0;
+        if (ra.fi == 0) calc_xdot<0, const double *, true>(ra.tab, ra.lofi, x, u, xd, ra.xcg, ra.fi, ra.flags, sa, &ts);
+        else calc_xdot<-1, const double *, true>(ra.tab, ra.lofi, x, u, xd, ra.xcg, ra.fi, ra.flags, sa, &ts);
+        stw |= sa;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) x[i] += xd[i] * a.dt;
+      }
+      bool finx = true;
+#pragma unroll
+      for (int i = 0; i < 18; ++i) finx = finx && isfinite(x[i]);
+      if (!finx) stw |= ST_NONFINITE;
+    }
+    // ---- publish: state, command, flags, samples (one lane), then the release
+    if (l == 0) {
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) ra.x[i * ld + b] = x[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ra.u[(1 + c) * ld + b] = u[1 + c];
+      }
+      if (ra.status) ra.status[b] = stw;
+      if (ra.traj && (t + 1) % ra.every == 0) {
+        double *tr = ra.traj + (size_t)((t + 1) / ra.every - 1) * 18 * ld + b;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) __builtin_nontemporal_store(x[i], tr + i * ld);
+      }
+      if (ra.cmd_traj) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ra.cmd_traj[((size_t)t * 3 + c) * ld + b] = cmd[c];
+      }
+      if (ra.iters_traj) ra.iters_traj[(size_t)t * ld + b] = iters;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (l == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&ra.progress[b], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -1572,6 +1780,39 @@ int mpc_wave_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
   }
   hipLaunchKernelGGL(wave::k_mpc_wave, dim3(grid), dim3(64), 0, (hipStream_t)stream, w);
   return hip_check(hipGetLastError(), "f16_mpc_batch wavefront solve launch");
+}
+
+// f16_rollout_mpc: the closed loop as one launch (k_rollout_mpc).  `sync` = the plan's [8 bytes ticket counter | B x int32 progress].
+int mpc_wave_rollout_launch(f16_ctx *ctx, const MpcArgs &a, const RolloutMpcCall &c, void *stream) {
+  if (a.N < 1 || a.N > WAVE_MAXN || !a.gramws || !a.pblk || !a.ext || !a.Ppk) return set_error(F16_EINVAL, "closed-loop MPC rollout needs a plan with 1 <= hzn <= 30");
+  if (a.B > 0x7fffffffL) return set_error(F16_EINVAL, "batch too large for one launch");
+  wave::RollMpcArgs r{};
+  r.m = a;
+  r.m.x = c.x; r.m.dem = c.dem; r.m.xref = nullptr; r.m.ucmd = nullptr; r.m.useq = nullptr; r.m.info = nullptr; r.m.status = nullptr;
+  r.m.mode = 0; r.m.wave_ruiz = 1; r.m.order = nullptr; r.m.iters_out = nullptr; r.m.warm = nullptr; r.m.warm_load = 0; r.m.wave_queue = nullptr;
+  r.x = c.x; r.u = c.u; r.dem = c.dem; r.traj = c.traj; r.cmd_traj = c.cmd_traj; r.iters_traj = c.iters_traj; r.status = c.status;
+  r.queue = reinterpret_cast<unsigned long long *>(c.sync);
+  r.progress = reinterpret_cast<int32_t *>(c.sync) + 2;
+  r.tab = ctx->d_tab; r.lofi = ctx->d_lofi;
+  r.T = c.T; r.every = c.every; r.xcg = c.xcg; r.fi = c.fi; r.flags = c.flags;
+  r.stride = 0;
+  static const bool spread = [] { const char *e = getenv("F16_MPC_SPREAD"); return !(e && e[0] == '0'); }();
+  if (spread && a.B > 16) {
+    static const unsigned primes[] = {2053, 2063, 2069, 2081, 2083, 2087, 2089, 2099};
+    for (unsigned p : primes)
+      if (a.B % p != 0) { r.stride = p; break; }
+  }
+  if (int rc = hip_check(hipMemsetAsync(c.sync, 0, 8 + (size_t)a.B * sizeof(int32_t), (hipStream_t)stream), "f16_rollout_mpc counters")) return rc;
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? n : 0;
+  }();
+  // one wavefront-workgroup per SIMD (all resident: 40 KB of LDS each, four per CU); never more than aircraft -- the surplus could
+  // only wait
+  const long slots = cus > 0 ? 4L * cus : 1024;
+  const unsigned grid = (unsigned)(a.B < slots ? a.B : slots);
+  hipLaunchKernelGGL(wave::k_rollout_mpc, dim3(grid), dim3(64), 0, (hipStream_t)stream, r);
+  return hip_check(hipGetLastError(), "f16_rollout_mpc launch");
 }
 
 }  // namespace f16

@@ -144,35 +144,64 @@ def or_status(status):
     return int(sum(int(b) << k for k, b in enumerate(flags.tolist())))
 
 
-def closed_loop_mpc_rollout(env, steps, hzn, p_dem=0.0, q_dem=0.0, r_dem=0.0, traj_every=1, gather=True, use_plan=True, stats=None):
+def closed_loop_mpc_rollout(env, steps, hzn, p_dem=0.0, q_dem=0.0, r_dem=0.0, traj_every=1, gather=True, use_plan=True, stats=None,
+                            fused=False, hold_command=False, one_lane=False):
     """BASELINE config 5 / test_env.py:480-495 pattern on this rank's shard, then one all-gather:
     per step  cmd = calc_MPC_action(p,q,r,hzn); u.values[1:] = cmd; step(u.values).
+    fused=True: the whole loop of the shard as ONE launch (F16Batch.rollout_MPC / C-ABI f16_rollout_mpc: (step, aircraft) pairs from
+    a work queue, no join per step); the host loop below is its checker (bit-identical with one_lane=True).
     use_plan: the model is frozen (env.py:49-60), so the model-only part of the QP is prepared once
     (F16Batch.prepare_MPC) -- same commands bit for bit.  With the reference's solver settings (OSQP defaults) a plan saves
     the QP build only: the equilibration looks at q, i.e. at the state of the call, so it and the factorisation are redone
     per solve (bench.py reports both legs at equal length); with the opt-in rule the factorisation is cached as well.
     (A HIP-graph replay of the step was measured and is SLOWER than the six eager launches on ROCm 7.2: 0.50 vs
     0.19 ms per step at B = 256, 3.36 vs 3.15 ms at B = 8192 -- the step is kept capture-safe but launched eagerly.)
-    stats (dict, optional): receives "iters_mean" = mean ADMM iterations per solve over the whole loop and "iters_max_mean" = the mean over
-    the steps of the LONGEST solve of the step (device-side reductions, read once at the end): a step cannot end before its longest solve.
+    hold_command: a step whose QP is infeasible (NaN command, as OSQP returns it) keeps the previous command instead of writing the
+    NaN into u.values (lib.F16_FLAG_HOLD_COMMAND; default: the reference's behaviour -- NaN command -> NaN actuator states).
+    one_lane: step with the one-lane-per-aircraft rollout kernel whatever the shard size (lib.F16_FLAG_ONE_LANE: the fused kernel's step).
+    stats (dict, optional): receives "iters_mean" = mean ADMM iterations per solve over the whole loop, "iters_max_mean" = the mean over
+    the steps of the LONGEST solve of the step (device-side reductions, read once at the end; the host loop cannot end a step before
+    its longest solve) and "flagged_per_step" = per step the number of aircraft whose solve raised F16_ST_QP_INFEASIBLE / QP_MAXITER /
+    NONFINITE (host loop only).
     Returns the collated trajectory [steps//traj_every, 18, B_total] (or the local shard if gather=False)."""
+    from . import lib as _lib
     T = steps // traj_every
+    if fused:
+        traj, info = env.rollout_MPC(steps, p_dem, q_dem, r_dem, hzn, traj_every=traj_every, return_info=True, hold_command=hold_command)
+        if stats is not None:
+            its = info["iters"].to(torch.float64)
+            stats["iters_mean"] = float(its.mean())
+            stats["iters_max_mean"] = float(its.max(1).values.mean())
+        return all_gather_trajectories(traj) if gather else traj
     traj = torch.empty((T, 18, env.B), dtype=torch.float64, device=env.device)
     dem = torch.empty((3, env.B), dtype=torch.float64, device=env.device)      # demands on the device once
     for k, v in enumerate((p_dem, q_dem, r_dem)):
         dem[k] = torch.as_tensor(v, dtype=torch.float64, device=env.device)
     it_sum = torch.zeros((), dtype=torch.float64, device=env.device) if stats is not None else None
     it_max = torch.zeros((), dtype=torch.float64, device=env.device) if stats is not None else None
-    for k in range(steps):
-        cmd = env._calc_MPC_action(dem, None, None, hzn, use_plan=use_plan)
-        if it_sum is not None:
-            it_sum += env.last_iters.sum()
-            it_max += env.last_iters.max()
-        env._u[1:4] = cmd.t()
-        env.rollout(1)
-        if (k + 1) % traj_every == 0:
-            traj[(k + 1) // traj_every - 1] = env._x
+    flagged = torch.zeros((steps, 3), dtype=torch.int64, device=env.device) if stats is not None else None
+    flags0 = env.flags
+    if one_lane:
+        env.flags = env.flags | _lib.F16_FLAG_ONE_LANE
+    try:
+        for k in range(steps):
+            cmd = env._calc_MPC_action(dem, None, None, hzn, use_plan=use_plan)
+            if it_sum is not None:
+                it_sum += env.last_iters.sum()
+                it_max += env.last_iters.max()
+                st = env.last_status
+                flagged[k, 0] = ((st & _lib.F16_ST["QP_INFEASIBLE"]) != 0).sum()
+                flagged[k, 1] = ((st & _lib.F16_ST["QP_MAXITER"]) != 0).sum()
+                flagged[k, 2] = ((st & _lib.F16_ST["NONFINITE"]) != 0).sum()
+            c = cmd.t()
+            env._u[1:4] = torch.where(torch.isnan(c), env._u[1:4], c) if hold_command else c
+            env.rollout(1)
+            if (k + 1) % traj_every == 0:
+                traj[(k + 1) // traj_every - 1] = env._x
+    finally:
+        env.flags = flags0
     if stats is not None:
         stats["iters_mean"] = float(it_sum) / max(1, steps * env.B)
         stats["iters_max_mean"] = float(it_max) / max(1, steps)
+        stats["flagged_per_step"] = flagged.cpu().numpy()
     return all_gather_trajectories(traj) if gather else traj

@@ -523,6 +523,32 @@ class F16Batch:
 
     calc_MPC_action = _calc_MPC_action
 
+    def rollout_MPC(self, nsteps, p_dem, q_dem, r_dem, hzn, traj_every=None, return_info=False, hold_command=False):
+        """The reference's closed MPC loop (test_env.py:480-495; BASELINE config 5) as ONE launch (C-ABI f16_rollout_mpc): per step
+        `cmd = _calc_MPC_action(p_dem, q_dem, r_dem, hzn); u.values[1:] = cmd; step(u.values)` from the frozen reduced model
+        (env.py:49-60) with OSQP's default settings.  Work items are (step, aircraft) pairs taken from one queue by one wavefront per
+        SIMD, so no step waits for another aircraft's solve -- the host loop `dist.closed_loop_mpc_rollout` (the checker of this
+        call) joins the batch after every solve.  Uses the prepared plan of horizon hzn (prepare_MPC; made here if absent).
+        Returns the states after every traj_every-th step [nsteps//k, 18, B] (None without traj_every); with return_info also
+        dict(cmd [nsteps, 3, B]: what calc_MPC_action returned per step, iters [nsteps, B]).  x.values / u.values / status are
+        updated in place; u.values ends up holding the last command.  hold_command: F16_FLAG_HOLD_COMMAND."""
+        if getattr(self, "_plan", None) is None or self._plan_hzn != int(hzn):
+            self.prepare_MPC(hzn)
+        dem = p_dem if (torch.is_tensor(p_dem) and p_dem.dim() == 2) else self._demands(p_dem, q_dem, r_dem)
+        traj = None
+        if traj_every:
+            assert nsteps % traj_every == 0
+            traj = torch.empty((nsteps // traj_every, 18, self.B), dtype=torch.float64, device=self.device)
+        cmd = torch.empty((nsteps, 3, self.B), dtype=torch.float64, device=self.device) if return_info else None
+        its = torch.empty((nsteps, self.B), dtype=torch.int32, device=self.device) if return_info else None
+        flags = self.flags | (_lib.F16_FLAG_HOLD_COMMAND if hold_command else 0)
+        self._check(self.lib.f16_rollout_mpc(self._plan, _vp(self._x), _vp(self._u), _vp(dem), _vp(traj), _vp(cmd), _vp(its),
+                                             _vp(self.status), int(nsteps), int(traj_every or 1), self.xcg, self.fi_flag, flags,
+                                             self._stream))
+        if return_info:
+            return traj, dict(cmd=cmd, iters=its)
+        return traj
+
     def _calc_constr_checking_hzn(self, max_hzn=150, settings=None, return_info=False):
         """env.py:426-436: the first move of calc_MPC_action(0, 0, 0, N) for every horizon N = 1..max_hzn (the reference
         fills u[:, N-1] for one aircraft; here [B, 3, max_hzn]).  One library call (f16_mpc_hzn_sweep): the long horizons

@@ -30,6 +30,8 @@ F16_ST = dict(ALPHA1=1, ALPHA2=2, BETA=4, EL=8, ENVELOPE=16, NONFINITE=32, QP_MA
 F16_ST_ENV_STATE = lambda k: 1 << (8 + k)      # with ENVELOPE: state k was outside its box (env.py:117-124)
 F16_FLAG_FIX_CLR = 1
 F16_FLAG_NO_ENVELOPE = 2
+F16_FLAG_ONE_LANE = 4          # rollouts: the one-lane-per-aircraft kernel whatever the batch size (results independent of B)
+F16_FLAG_HOLD_COMMAND = 8      # closed MPC loops: a step without a command (infeasible QP, state not finite) keeps the previous one
 
 
 class F16HipError(RuntimeError):
@@ -247,6 +249,7 @@ def load():
         L.f16_mpc_plan_create_w.argtypes = [vp, ctypes.POINTER(vp), vp, vp, vp, wp, l, l, i, d, ctypes.POINTER(QPSettings), vp]
         L.f16_mpc_plan_solve_w.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.f16_mpc_qp_debug_w.argtypes = [vp, vp, vp, vp, vp, vp, vp, wp, l, l, i, d, vp, vp, vp, vp, vp]
+        L.f16_rollout_mpc.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, d, i, u, vp]
         L.f16_mpc_plan_warm_start.argtypes = [vp, i]
         L.f16_mpc_plan_destroy.argtypes = [vp]
         L.f16_mpc_plan_destroy.restype = None

@@ -53,6 +53,13 @@ typedef struct f16_ctx f16_ctx;
 /* behaviour flags */
 #define F16_FLAG_FIX_CLR 1u      /* use the real CLr table (reference never loads it: hifi_F16_AeroData.c:964-972) */
 #define F16_FLAG_NO_ENVELOPE 2u  /* skip the env.py:117-124 box check in step/rollout                               */
+#define F16_FLAG_ONE_LANE 4u     /* f16_rollout / f16_rollout_lqr: always the one-lane-per-aircraft kernel (64-lane workgroups), whatever
+                                    the batch size -- results then do not depend on B bit for bit (the launch rules otherwise pick a
+                                    four-lanes-per-aircraft or four-wavefront kernel for small batches: same terms, the six coefficient
+                                    totals summed in another order, ulp-level differences).  f16_rollout_mpc steps with exactly this code. */
+#define F16_FLAG_HOLD_COMMAND 8u /* closed MPC loops (f16_rollout_mpc; dist.closed_loop_mpc_rollout(hold_command=True)): a step whose QP
+                                    is infeasible (or whose state is not finite) keeps the PREVIOUS surface commands instead of the NaN
+                                    the reference would write into u.values (env.py:420-424 -> test_env.py:490-493)                  */
 
 /* ---- lifetime --------------------------------------------------------------------------- */
 /* Builds the fp64 table image (int/1e5, IEEE division) and uploads it to `device`. */
@@ -239,6 +246,27 @@ int f16_mpc_hzn_sweep(f16_ctx *ctx, const double *Ad, const double *Bd, const do
  * long-horizon solver; no warm start there).  (Ad,Bd,Cd) are read during
  * f16_mpc_plan_create only. */
 typedef struct f16_mpc_plan f16_mpc_plan;
+/* The reference's closed MPC loop (test_env.py:480-495; BASELINE config 5) as ONE launch on a prepared plan (hzn <= 30, OSQP's
+ * default settings: scaling > 0; cold start):  per step  cmd = _calc_MPC_action(p, q, r, hzn);  u.values[1:] = cmd;  step(u.values).
+ * x[18][ld] in place; u[4][ld] = u.values in place (thrust command held, u[1:4] receives every step's command and ends up
+ * holding the last one, as the reference's u.values does); dem[3][ld].  traj (may be NULL) [nsteps / traj_every][18][ld]: the state
+ * after every traj_every-th step; cmd_traj (may be NULL) [nsteps][3][ld]: what calc_MPC_action returned at each step; iters_traj
+ * (may be NULL) [nsteps][ld] int32: its ADMM iterations; status[ld] (may be NULL): sticky OR of the step's and the solves' bits.
+ * Work items are (step, aircraft) pairs drawn from one ticket counter by one wavefront per SIMD; a wavefront builds the state-
+ * dependent vectors of the QP, solves it, writes the command and takes the Euler step of its pair, so that no step waits for another
+ * aircraft's solve (the host loop joins the batch after every solve).  Results: bit-identical to the host loop
+ * (f16_mpc_plan_solve + f16_rollout(..., nsteps = 1, flags | F16_FLAG_ONE_LANE) per step) for every aircraft that stays inside
+ * its envelope.  Per-aircraft conditions:
+ *   - QP certified infeasible: the command is NaN, as OSQP returns it (F16_ST_QP_INFEASIBLE): the actuator models propagate it
+ *     (np.clip, utils.py:308-330), the surface states turn NaN (F16_ST_NONFINITE) and every later solve of that aircraft is skipped
+ *     (NaN command, zero iterations) -- the reference's own loop is left with NaN states from there.  F16_FLAG_HOLD_COMMAND keeps
+ *     the previous command instead and the aircraft flies on.
+ *   - outside the envelope at the start of a step (env.py:117-124: the reference exit()s): frozen, flagged
+ *     (F16_ST_ENVELOPE | F16_ST_ENV_STATE(k)) and NOT solved for any more: cmd_traj holds NaN, iters_traj 0, u keeps its value.
+ * Not capturable on its first call on a plan (allocates the ticket / progress counters). */
+int f16_rollout_mpc(f16_mpc_plan *plan, double *x, double *u, const double *dem, double *traj, double *cmd_traj,
+                    int32_t *iters_traj, int32_t *status, int nsteps, int traj_every, double xcg, int fi_flag, unsigned flags,
+                    void *stream);
 int f16_mpc_plan_create(f16_ctx *ctx, f16_mpc_plan **plan, const double *Ad, const double *Bd, const double *Cd,
                         long B, long ld, int hzn, double dt, const f16_qp_settings *s, void *stream);
 int f16_mpc_plan_solve(f16_mpc_plan *plan, const double *x, const double *dem, double *u_cmd, double *u_seq,

@@ -474,3 +474,60 @@ void f16o_mpc_batch(const double *x, long B, int N, double dt, double xcg, int f
     free(P);
   }
 }
+
+/* The reference's closed MPC loop (test_env.py:480-495: cmd = _calc_MPC_action(p, q, r, N); u.values[1:] = cmd; step(u.values)) for B
+ * aircraft on the CPU, the reduced model FROZEN per aircraft as env.py:49-60 freezes it (Ad [B][81], Bd [B][27], Cd [B][81] given).
+ * The checker of the product's f16_rollout_mpc / dist.closed_loop_mpc_rollout, with the product's stated rules for the cases the
+ * reference does not survive:
+ *   - outside the envelope at the start of a step (env.py:117-124 exit()s): frozen, F16O_ST_ENVELOPE | which-state bits, no solve;
+ *   - state / demands not finite: no QP to solve (OSQP would iterate on NaN to max_iter and return NaN): NaN command, 0 iterations, bit 32;
+ *   - QP certified infeasible: NaN command as OSQP returns it (bit 128); hit max_iter / factorisation failed: bit 64;
+ *   - hold != 0: a step without a command keeps the previous one; else the NaN goes into u (np.clip propagates it, utils.py:308-330).
+ * x [B][18], u [B][4] in place; dem [B][3]; cmds [T][B][3], iters [T][B], traj [T][B][18] may be NULL; status [B] in/out (sticky). */
+void f16o_mpc_closed_loop(double *x, double *u, const double *Ad, const double *Bd, const double *Cd, long B, int N, int T, double dt,
+                          double xcg, int fi_flag, const double *dem, const f16o_qp_settings *s, int mode, int hold, double *cmds,
+                          int *iters, int *status, double *traj, int nthreads) {
+  const int n = 3 * N, m = 15 * N;
+#pragma omp parallel num_threads(nthreads > 1 ? nthreads : 1)
+  {
+    double *P = (double *)malloc(sizeof(double) * ((size_t)n * n + n + (size_t)m * n + 2 * m + n));
+    double *q = P + (size_t)n * n, *A = q + n, *l = A + (size_t)m * n, *uu = l + m, *xo = uu + m;
+#pragma omp for schedule(dynamic, 1)
+    for (long b = 0; b < B; ++b) {
+      double *xf = x + 18 * b, *uf = u + 4 * b;
+      int st = status ? status[b] : 0;
+      for (int t = 0; t < T; ++t) {
+        double cmd[3] = {NAN, NAN, NAN};
+        int it = 0;
+        if (!(st & 16)) st |= f16o_envelope_bits(xf);
+        if (!(st & 16)) {
+          int fin = 1;
+          for (int k = 0; k < 9; ++k) fin = fin && isfinite(xf[MPC_X_IDX[k]]);
+          for (int k = 0; k < 3; ++k) fin = fin && isfinite(xf[13 + k]) && isfinite(dem[3 * b + k]);
+          if (fin) {
+            double info[4];
+            f16o_mpc_qp(xf, Ad + 81 * b, Bd + 27 * b, Cd + 81 * b, N, dt, dem + 3 * b, P, q, A, l, uu);
+            const int rc = f16o_admm(n, m, P, q, A, l, uu, s, mode, xo, info);
+            it = (int)info[0];
+            if (rc == 2) st |= 128;
+            else if (rc != 0) st |= 64;
+            for (int k = 0; k < 3; ++k) cmd[k] = rc == 2 ? NAN : xo[k];
+          } else {
+            st |= 32;
+          }
+          for (int k = 0; k < 3; ++k)
+            if (!(hold && isnan(cmd[k]))) uf[1 + k] = cmd[k];
+          st |= f16o_step(xf, uf, dt, fi_flag, xcg);
+          for (int k = 0; k < 18; ++k)
+            if (!isfinite(xf[k])) st |= 32;
+        }
+        if (cmds) memcpy(cmds + ((size_t)t * B + b) * 3, cmd, sizeof cmd);
+        if (iters) iters[(size_t)t * B + b] = it;
+        if (traj) memcpy(traj + ((size_t)t * B + b) * 18, xf, 18 * sizeof(double));
+      }
+      if (status) status[b] = st;
+    }
+    free(P);
+  }
+}
+

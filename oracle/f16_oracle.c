@@ -471,10 +471,15 @@ static const double X_LB[18] = {-INFINITY, -INFINITY, 0, -INFINITY, -INFINITY, -
 static const double X_UB[18] = {INFINITY, INFINITY, 100000, INFINITY, INFINITY, INFINITY, 900, 90, 30, 300, 100, 50,
                                 19000, 25, 21.5, 30, 25, INFINITY};
 
-int f16o_step(double *x, const double *u, double dt, int fi_flag, double xcg) { /* env.py:105-130 */
+int f16o_envelope_bits(const double *x) { /* env.py:117-124: 0 inside, else F16O_ST_ENVELOPE | bit 8 + i per state outside */
   int out = 0;
   for (int i = 0; i < 18; ++i)
     if (x[i] < X_LB[i] || x[i] > X_UB[i]) out |= F16O_ST_ENVELOPE | (1 << (8 + i));      /* bit 8 + i: state i was outside (env.py:121-123 prints it) */
+  return out;
+}
+
+int f16o_step(double *x, const double *u, double dt, int fi_flag, double xcg) { /* env.py:105-130 */
+  const int out = f16o_envelope_bits(x);
   if (out) return out;
   double xd[18];
   f16o_calc_xdot(x, u, xd, fi_flag, xcg);

@@ -45,6 +45,7 @@ void f16o_nlplant(const double *xu, double *xdot, int fi_flag, double xcg);
 void f16o_calc_xdot(const double *x, const double *u, double *xdot, int fi_flag, double xcg);
 /* env.py:152-193: x_full/u_full are self.x.values / self.u.values; x9,u3 the MPC vectors */
 void f16o_calc_xdot_na(const double *x_full, const double *x9, const double *u3, double *xdot9, int fi_flag, double xcg);
+int f16o_envelope_bits(const double *x);   /* env.py:117-124 alone */
 /* env.py:105-130; returns status bits (envelope bit => state left untouched) */
 int f16o_step(double *x, const double *u, double dt, int fi_flag, double xcg);
 /* env.py:294-342 with _calc_xdot_na/_get_obs_na: A[9*9] B[9*3] C[9*9] D[9*3], row-major */

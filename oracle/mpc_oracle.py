@@ -86,6 +86,7 @@ class COracle:
         L.f16o_admm.argtypes = [i, i, dp, dp, dp, dp, dp, sp, i, dp, dp]
         L.f16o_qp_default_settings.argtypes = [sp, i]
         L.f16o_mpc_batch.argtypes = [dp, l, i, d, d, i, dp, sp, i, dp, ip, ip, i]
+        L.f16o_mpc_closed_loop.argtypes = [dp, dp, dp, dp, dp, l, i, i, d, d, i, dp, sp, i, i, dp, ip, ip, dp, i]
         L.f16o_init()
 
     @staticmethod
@@ -221,6 +222,26 @@ class COracle:
         self.lib.f16o_mpc_batch(self._p(x), B, hzn, dt, xcg, fi_flag, self._p(dm) if dm is not None else None, ctypes.byref(s), mode,
                                 self._p(u), it.ctypes.data_as(ipt), st.ctypes.data_as(ipt), nthreads)
         return dict(u=u, iters=it, status=st)
+
+    def mpc_closed_loop(self, x0, u0, Ad, Bd, Cd, hzn, T, dem, dt=0.001, xcg=0.35, fi_flag=1, mode=2, hold=False, store=False,
+                        nthreads=1, **kw):
+        """test_env.py:480-495 for B aircraft on the CPU with the reduced model frozen per aircraft (Ad [B,9,9], Bd [B,9,3],
+        Cd [B,9,9]): T steps of calc_MPC_action(N = hzn) + step.  dem [B,3] or [3].  The product's rules for frozen / non-finite /
+        infeasible aircraft (oracle/f16_mpc_oracle.c: f16o_mpc_closed_loop).
+        -> dict(x [B,18], u [B,4], cmd [T,B,3], iters [T,B], status [B], traj [T,B,18] or None)."""
+        x = np.array(x0, dtype=np.float64, order="C")
+        B = x.shape[0]
+        u = np.array(np.broadcast_to(u0, (B, 4)), dtype=np.float64, order="C")
+        c = lambda a, shp: np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), shp))
+        Ad, Bd, Cd, dm = c(Ad, (B, 9, 9)), c(Bd, (B, 9, 3)), c(Cd, (B, 9, 9)), c(dem, (B, 3))
+        s = self.qp_settings(mode, **kw)
+        cmds, its, st = np.zeros((T, B, 3)), np.zeros((T, B), dtype=np.int32), np.zeros(B, dtype=np.int32)
+        traj = np.zeros((T, B, 18)) if store else None
+        ipt = ctypes.POINTER(ctypes.c_int)
+        self.lib.f16o_mpc_closed_loop(self._p(x), self._p(u), self._p(Ad), self._p(Bd), self._p(Cd), B, hzn, T, dt, xcg, fi_flag,
+                                      self._p(dm), ctypes.byref(s), mode, 1 if hold else 0, self._p(cmds), its.ctypes.data_as(ipt),
+                                      st.ctypes.data_as(ipt), self._p(traj) if store else None, nthreads)
+        return dict(x=x, u=u, cmd=cmds, iters=its, status=st, traj=traj)
 
     def linearise_full(self, x, u, eps=1e-5, fi_flag=1, xcg=0.25):
         x = np.ascontiguousarray(x, dtype=np.float64)

@@ -1029,3 +1029,120 @@ json.dump(out, open(sys.argv[1], "w"))
             assert np.array_equal(np.isnan(us_w), np.isnan(us_o)), (key, other)
             assert np.nanmax(np.abs(us_w - us_o), initial=0.0) < 2e-7, (key, other, np.nanmax(np.abs(us_w - us_o)))
             assert np.allclose(w["rho"], o["rho"], rtol=1e-6, atol=0), (key, other)
+
+
+# ---------------------------------------------------------------------------------------------------------------- round 5
+def _host_loop(env, steps, N, dem, hold=False):
+    """dist.closed_loop_mpc_rollout's loop, step by step, keeping what every step returned (the checker of f16_rollout_mpc)."""
+    from f16_mpc_oop_py_amd import lib as L
+    env.flags |= L.F16_FLAG_ONE_LANE                   # the step of the fused kernel = the one-lane rollout kernel's
+    cmds, its, trs = [], [], []
+    for _ in range(steps):
+        cmd, info = env._calc_MPC_action(*dem, N, return_info=True, use_plan=True)
+        cmds.append(cmd.t().clone()); its.append(info["iters"].to(torch.int32).clone())
+        c = cmd.t()
+        env._u[1:4] = torch.where(torch.isnan(c), env._u[1:4], c) if hold else c
+        env.rollout(1)
+        trs.append(env._x.clone())
+    return torch.stack(trs), torch.stack(cmds), torch.stack(its)
+
+
+def _same(a, b):
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    return np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("B,N,steps", [(256, 30, 8), (100, 10, 12), (1, 30, 5)])
+def test_fused_closed_loop_mpc_rollout_equals_the_host_loop_bit_for_bit(oracle, B, N, steps):
+    """f16_rollout_mpc (the reference's loop test_env.py:480-495 as ONE launch: (step, aircraft) pairs from a work queue, a wavefront
+    builds the QP vectors, solves, writes the command and steps its pair) against the host loop of six launches per step: every
+    command, every iteration count, every trajectory sample, the final state, u.values and the status words are IDENTICAL; and
+    against the same loop on the CPU twin for a sample (commands <= 1e-4, states <= 1e-6: the bands of the host-loop test)."""
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(B, seed=11)
+    dem = (0.02, -0.01, 0.005)
+    envh = make_env(x0, u0, xcg=0.35)
+    envh.build_ssr(); envh.prepare_MPC(N)
+    trh, ch, ih = _host_loop(envh, steps, N, dem)
+    envf = make_env(x0, u0, xcg=0.35)
+    envf.build_ssr(); envf.prepare_MPC(N)
+    trf, info = envf.rollout_MPC(steps, *dem, N, traj_every=1, return_info=True)
+    assert _same(info["cmd"], ch) and _same(info["iters"], ih) and _same(trf, trh)
+    assert _same(envf._x, envh._x) and _same(envf._u, envh._u) and _same(envf.status, envh.status)
+    assert int(envf.status.max()) == 0 and int(info["iters"].min()) >= 25
+    Ad, Bd, Cd = _model_np(envf)
+    idx = sorted(set([0, B // 3, B - 1]))
+    r = oracle.mpc_closed_loop(x0[idx], u0[idx], Ad[idx], Bd[idx], Cd[idx], N, steps, dem, nthreads=4)
+    assert np.array_equal(r["iters"], info["iters"].cpu().numpy()[:, idx])
+    assert np.abs(r["cmd"] - info["cmd"].permute(0, 2, 1).cpu().numpy()[:, idx]).max() < 1e-4
+    xg = envf.x_values.cpu().numpy()[idx]
+    assert np.max(np.abs(xg - r["x"]) / np.maximum(1.0, np.abs(r["x"]))) < 1e-6
+    # a second call goes on from where the first one stopped (counters of the plan are re-armed per call); samples every 2nd step
+    tr2 = envf.rollout_MPC(4, *dem, N, traj_every=2)
+    _host_loop(envh, 4, N, dem)
+    assert tuple(tr2.shape) == (2, 18, B) and _same(envf._x, envh._x) and _same(tr2[-1], envf._x)
+
+
+def test_fused_closed_loop_flagged_aircraft_nan_commands_hold_and_frozen(oracle):
+    """What a flagged aircraft does next, fused kernel = host loop = CPU loop (oracle/f16_mpc_oracle.c: f16o_mpc_closed_loop):
+    an INFEASIBLE QP returns a NaN command as OSQP does (env.py:420-424); the actuator models propagate it (np.clip,
+    utils.py:308-330: fixture G3b), the surface states turn NaN and every later solve of that aircraft is skipped (NaN, zero
+    iterations) -- status bits QP_INFEASIBLE | NONFINITE are sticky; with F16_FLAG_HOLD_COMMAND the previous command is kept and
+    the aircraft flies on; an aircraft outside its envelope is frozen and not solved for."""
+    from f16_mpc_oop_py_amd.workload import config2_states
+    B, N, steps = 320, 10, 6
+    x0, u0 = config2_states(B, seed=3)                      # (config 2's flap states sit ON their bounds: some QPs are infeasible)
+    x0[5, 13] = 26.0                                        # elevator outside its box: env.py:117-124 would exit()
+    dem = (0.0, 0.0, 0.0)
+    out = {}
+    for hold in (False, True):
+        envh = make_env(x0, u0, xcg=0.35)
+        envh.build_ssr(); envh.prepare_MPC(N)
+        trh, ch, ih = _host_loop(envh, steps, N, dem, hold=hold)
+        envf = make_env(x0, u0, xcg=0.35)
+        envf.build_ssr(); envf.prepare_MPC(N)
+        trf, info = envf.rollout_MPC(steps, *dem, N, traj_every=1, return_info=True, hold_command=hold)
+        live = np.ones(B, bool); live[5] = False            # (the host loop goes on solving for the frozen aircraft)
+        lv = torch.as_tensor(live, device="cuda:0")
+        assert _same(info["cmd"][:, :, lv], ch[:, :, lv]) and _same(info["iters"][:, lv], ih[:, lv]) and _same(trf, trh)
+        assert _same(envf._x, envh._x) and _same(envf._u[:, lv], envh._u[:, lv])
+        sf, sh = envf.status.cpu().numpy(), envh.status.cpu().numpy()
+        assert np.array_equal(sf[live], sh[live])
+        assert sf[5] == 16 | (1 << (8 + 13)) and np.isnan(info["cmd"][:, :, 5].cpu().numpy()).all() and int(info["iters"][:, 5].max()) == 0
+        assert np.array_equal(envf.x_values.cpu().numpy()[5], x0[5]) and np.array_equal(envf.u_values.cpu().numpy()[5], u0[5])
+        Ad, Bd, Cd = _model_np(envf)
+        r = oracle.mpc_closed_loop(x0, u0, Ad, Bd, Cd, N, steps, dem, hold=hold, nthreads=16)
+        assert np.array_equal(r["status"] & (16 | 32 | 64 | 128), sf & (16 | 32 | 64 | 128))
+        assert np.array_equal(r["iters"], info["iters"].cpu().numpy())
+        cg = info["cmd"].permute(0, 2, 1).cpu().numpy()
+        assert np.array_equal(np.isnan(cg), np.isnan(r["cmd"]))
+        fin = ~np.isnan(cg)
+        assert np.abs(cg[fin] - r["cmd"][fin]).max() < 1e-4
+        xg = envf.x_values.cpu().numpy()
+        assert np.array_equal(np.isnan(xg), np.isnan(r["x"]))
+        out[hold] = (sf, xg, info["iters"].cpu().numpy(), cg)
+    sf, xg, it, cg = out[False]
+    inf = (sf & 128) != 0
+    assert 3 <= inf.sum() < B // 2                          # the workload does contain infeasible QPs
+    first = np.array([np.argmax(np.isnan(cg[:, b, 0])) for b in np.where(inf)[0]])
+    for b, t0 in zip(np.where(inf)[0], first):
+        assert sf[b] & 32 and np.isnan(xg[b, 13:16]).all()                            # NaN command -> NaN surface states
+        assert (it[t0 + 1:, b] == 0).all() and np.isnan(cg[t0:, b]).all()              # ... and no QP to solve from then on
+    sfh, xgh, ith, cgh = out[True]
+    assert np.array_equal((sfh & 128) != 0, inf) or ((sfh & 128) != 0).sum() >= inf.sum()
+    assert np.isfinite(np.delete(xgh, 5, 0)).all() and not (np.delete(sfh, 5) & 32).any()   # held commands: everybody flies on
+
+
+def test_fused_closed_loop_argument_checks():
+    from f16_mpc_oop_py_amd import lib as L
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(8, seed=1)
+    env = make_env(x0, u0, xcg=0.35)
+    env.build_ssr()
+    env.prepare_MPC(10, settings=dict(scaling=0, rho=0.0))           # no equilibration: not this kernel's solver
+    with pytest.raises(L.F16HipError):
+        env.rollout_MPC(2, 0, 0, 0, 10)
+    env.prepare_MPC(10)
+    before = env.x_values.clone()
+    assert env.rollout_MPC(0, 0, 0, 0, 10) is None and bool((env.x_values == before).all())
+    assert env.lib.f16_rollout_mpc(None, None, None, None, None, None, None, None, 1, 1, 0.35, 1, 0, None) == -1      # F16_EINVAL
