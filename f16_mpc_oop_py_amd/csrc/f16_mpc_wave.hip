@@ -1589,156 +1589,210 @@ struct RollMpcArgs {
   double *cmd_traj;              // [T][3][ld] or null: what calc_MPC_action returned at each step (NaN: infeasible / not finite / no solve)
   int32_t *iters_traj;           // [T][ld] or null
   int32_t *status;               // [ld], sticky
-  unsigned long long *queue;     // ticket counter, zero at the launch
+  unsigned *queue;               // ticket counter, zero at the launch
   int32_t *progress;             // [B] steps completed per aircraft, zero at the launch
   const double *tab, *lofi;      // table images (global)
   int T, every;
   double xcg;
   int fi;
-  unsigned flags, stride;
+  unsigned flags, stride, total; // total = T x B tickets (< 2^32: checked by the launcher)
 };
 
 __device__ __forceinline__ double bcast0_f64(double v) {       // lane 0's value on every lane
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
+__device__ __forceinline__ bool uniform_flag(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }   // (a scalar branch for what every lane agrees on)
 
 constexpr int RU_A = 0, RU_Q = 81, RU_QB = 162, RU_G = 256, RU_X9 = RU_G + 27 * WN + 6, RU_XREF = RU_X9 + 10, RU_PRED = RU_XREF + 10,
               RU_WBUF = RU_PRED + 9 * WN + 2, RU_QV = RU_WBUF + 9 * WN + 2;
 static_assert(RU_QV + 3 * WN <= LDS_DOUBLES, "state-vector scratch of the rollout kernel");
 
+// The two ends of a (step, aircraft) pair as out-of-line functions with register allocations of their own (as the pieces of the
+// solve are): the kernel's top level then holds little more than k_mpc_wave's does.  (The first version had everything inline in the
+// ticket loop -- ~9,000 instructions around eleven calls, three whole-wave spill registers of scalar state parked in accumulator
+// registers -- and did not survive the compiler: ticket 0's body ran for ever, or the wave stopped behind its first release, depending
+// on unrelated edits; phase markers read from another stream while the kernel ran showed where: tools/gpu_fused_marks.py.)
+struct PairIO {
+  double *x, *u;
+  const double *dem;
+  double *traj, *cmd_traj;
+  int32_t *iters_traj, *status;
+  const double *tab, *lofi;
+  double *exw;                   // this aircraft's extras block of the plan's workspace: q | G | pred | A Q Qbar
+  long ld, b;
+  int t, N, every, fi;
+  unsigned flags;
+  double xcg, dt;
+  double cmd[3];                 // what calc_MPC_action returned (NaN: infeasible / not finite / no solve)
+  int iters, stw;
+};
+enum { PAIR_SOLVE = 0, PAIR_FROZEN = 1, PAIR_NONFINITE = 2 };
+
+// Start of a pair: the aircraft at the start of the step; env.py:117-124 first (the reference exit()s there: frozen, flagged, not solved
+// for any more -- the host loop goes on solving for it: same states, wasted iterations); then the state-dependent vectors of the QP
+// into the aircraft's workspace block (what the build kernel does per call: f16_mpc_state.hpp).
+__device__ __noinline__ int pair_prepare(PairIO *io) {
+  const int l = threadIdx.x;
+  const long ld = io->ld, b = io->b;
+  const int N = __builtin_amdgcn_readfirstlane(io->N), n = 3 * N;
+  const double *xg = io->x, *dg = io->dem;
+  double x[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) x[i] = xg[i * ld + b];
+  int stw = io->status ? io->status[b] : 0;
+  if (!(stw & ST_ENVELOPE) && !(io->flags & FLAG_NO_ENVELOPE) && outside_envelope(x)) stw |= ST_ENVELOPE | envelope_state_bits(x);
+  int code = PAIR_SOLVE;
+  if (uniform_flag((stw & ST_ENVELOPE) != 0)) code = PAIR_FROZEN;
+  else {
+    bool fin = true;
+    const int MX[9] = {3, 4, 7, 8, 9, 10, 11, 17, 16};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fin = fin && isfinite(x[MX[i]]);
+    fin = fin && isfinite(x[13]) && isfinite(x[14]) && isfinite(x[15]);
+    double dm[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { dm[c] = dg[c * ld + b]; fin = fin && isfinite(dm[c]); }
+    if (!uniform_flag(fin)) { code = PAIR_NONFINITE; stw |= ST_NONFINITE; }      // no QP to solve (f16_mpc.hpp: mpc_job_nonfinite)
+    else {
+      double *const exw = io->exw;
+      const double *exm = exw + mpc_ext_model(N);
+      wave_lds_sync();
+      for (int e = l; e < 81; e += 64) { s_w[RU_A + e] = exm[e]; s_w[RU_Q + e] = exm[81 + e]; s_w[RU_QB + e] = exm[162 + e]; }
+      for (int e = l; e < 27 * N; e += 64) s_w[RU_G + e] = exw[n + e];
+      if (l < 9) {
+        double v = x[0];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) v = MX[l] == i ? x[i] : v;
+        s_w[RU_X9 + l] = v;
+        s_w[RU_XREF + l] = (l >= 5 && l < 8) ? (l == 5 ? dm[0] : (l == 6 ? dm[1] : dm[2])) : v;          // env.py:380-383
+      }
+      __syncthreads();
+      mpc_state_vectors(s_w + RU_A, s_w + RU_Q, s_w + RU_QB, s_w + RU_G, s_w + RU_X9, s_w + RU_XREF, s_w + RU_PRED, s_w + RU_WBUF,
+                        s_w + RU_QV, N);
+      for (int e = l; e < n; e += 64) exw[e] = s_w[RU_QV + e];
+      for (int e = l; e < 9 * N; e += 64) exw[n + 27 * N + e] = s_w[RU_PRED + e];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+  io->stw = stw;                   // (private memory: every lane keeps its own copy of *io, all with the same values)
+  return code;
+}
+
+// End of a pair: u.values[1:] = cmd (test_env.py:490-493; F16_FLAG_HOLD_COMMAND: a step without a command keeps the previous one),
+// step(u.values) (env.py:126: the one-lane rollout kernel's own step -- f16_dynamics.hip rollout_lanes, exact trigonometry; the table
+// image from global memory), then the stores of the pair: state, command, flags, samples.
+__device__ __noinline__ void pair_finish(const PairIO *io, int code) {
+  const int l = threadIdx.x;
+  const long ld = io->ld, b = io->b;
+  const int t = __builtin_amdgcn_readfirstlane(io->t);
+  const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)io->flags);
+  double *xg = io->x, *ug = io->u;
+  double x[18], u[4];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) x[i] = xg[i * ld + b];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = ug[i * ld + b];
+  int stw = io->stw;
+  double cmd[3] = {io->cmd[0], io->cmd[1], io->cmd[2]};
+  const bool live = __builtin_amdgcn_readfirstlane(code) != PAIR_FROZEN;
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      if (!((flags & F16_FLAG_HOLD_COMMAND) && cmd[c] != cmd[c])) u[1 + c] = cmd[c];
+    wave_lds_sync();
+    const TrigSlots ts{s_w, 1};
+    Trig5 g;
+    trig_exact(x, g);
+    trig_store(ts, g);
+    double xd[18];
+    int sa = 0;
+    const int fi = __builtin_amdgcn_readfirstlane(io->fi);
+    if (fi == 0) calc_xdot<0, const double *, true>(io->tab, io->lofi, x, u, xd, io->xcg, fi, flags, sa, &ts);
+    else calc_xdot<-1, const double *, true>(io->tab, io->lofi, x, u, xd, io->xcg, fi, flags, sa, &ts);
+    stw |= sa;
+    const double dt = io->dt;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) x[i] += xd[i] * dt;
+    bool finx = true;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) finx = finx && isfinite(x[i]);
+    if (!finx) stw |= ST_NONFINITE;
+  }
+  if (l == 0) {
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < 18; ++i) xg[i * ld + b] = x[i];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ug[(1 + c) * ld + b] = u[1 + c];
+    }
+    if (io->status) io->status[b] = stw;
+    const int every = io->every;
+    if (io->traj && (t + 1) % every == 0) {
+      double *tr = io->traj + (size_t)((t + 1) / every - 1) * 18 * ld + b;
+#pragma unroll
+      for (int i = 0; i < 18; ++i) __builtin_nontemporal_store(x[i], tr + i * ld);
+    }
+    if (io->cmd_traj) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) io->cmd_traj[((size_t)t * 3 + c) * ld + b] = cmd[c];
+    }
+    if (io->iters_traj) io->iters_traj[(size_t)t * ld + b] = io->iters;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(64, 1) void k_rollout_mpc(RollMpcArgs ra) {
   const MpcArgs &a = ra.m;
-  const int N = a.N, n = 3 * N;
+  const int N = a.N;
   const Role R = role(N);
   const int l = R.l;
-  const unsigned long long B = (unsigned long long)a.B, total = (unsigned long long)ra.T * B;
-  const long ld = a.ld;
+  const unsigned Bu = (unsigned)a.B;
   for (;;) {
-    unsigned long long k = 0;
-    if (l == 0) k = atomicAdd(ra.queue, 1ull);
-    k = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(k >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)k);
-    if (k >= total) break;
-    const int t = (int)(k / B);
-    const unsigned long long j = k - (unsigned long long)t * B;
-    const long b = ra.stride ? (long)((j * ra.stride) % B) : (long)j;
-    // ---- wait for step t - 1 of this aircraft, then acquire what its wavefront published
-    if (t > 0 && l == 0) {
-      while (__hip_atomic_load(&ra.progress[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t) __builtin_amdgcn_s_sleep(16);
+    unsigned k = 0;
+    if (l == 0) k = atomicAdd(ra.queue, 1u);
+    k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+    if (k >= ra.total) break;
+    const int t = __builtin_amdgcn_readfirstlane((int)(k / Bu));
+    const unsigned j = k - (unsigned)t * Bu;
+    const long b = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ra.stride ? (unsigned)(((unsigned long long)j * ra.stride) % Bu) : j));
+    // ---- wait for step t - 1 of this aircraft, then acquire what its wavefront published.  (Every lane polls the same word -- one
+    // broadcast load -- and every lane publishes below: no lane-0-only region on either side of the loop's back edge.)
+    if (t > 0) {
+      while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ra.progress[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < t)
+        __builtin_amdgcn_s_sleep(16);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // ---- the aircraft at the start of the step (every lane holds it: the loads are broadcasts)
-    double x[18], u[4];
-#pragma unroll
-    for (int i = 0; i < 18; ++i) x[i] = ra.x[i * ld + b];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) u[i] = ra.u[i * ld + b];
-    int stw = ra.status ? ra.status[b] : 0;
-    // env.py:117-124 comes first in `step`; the reference exit()s there: the aircraft is frozen and flagged, and it is not solved for
-    // any more (the host loop goes on solving for it: same states, wasted iterations)
-    if (!(stw & ST_ENVELOPE) && !(ra.flags & FLAG_NO_ENVELOPE) && outside_envelope(x)) stw |= ST_ENVELOPE | envelope_state_bits(x);
-    const bool live = !(stw & ST_ENVELOPE);
-    double cmd[3] = {NAN, NAN, NAN};
-    int iters = 0;
-    if (live) {
-      bool fin = true;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) { const int MX[9] = {3, 4, 7, 8, 9, 10, 11, 17, 16}; fin = fin && isfinite(x[MX[i]]); }
-      fin = fin && isfinite(x[13]) && isfinite(x[14]) && isfinite(x[15]);
-      double dm[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { dm[c] = ra.dem[c * ld + b]; fin = fin && isfinite(dm[c]); }
-      if (fin) {
-        // the state-dependent vectors of the QP into this aircraft's workspace block (what the build kernel does per call)
-        double *const exw = a.ext + (size_t)b * mpc_ext_doubles(N);
-        const double *exm = exw + mpc_ext_model(N);
-        wave_lds_sync();
-        for (int e = l; e < 81; e += 64) { s_w[RU_A + e] = exm[e]; s_w[RU_Q + e] = exm[81 + e]; s_w[RU_QB + e] = exm[162 + e]; }
-        for (int e = l; e < 27 * N; e += 64) s_w[RU_G + e] = exw[n + e];
-        if (l < 9) {
-          const int MX[9] = {3, 4, 7, 8, 9, 10, 11, 17, 16};
-          double v = x[0];
-#pragma unroll
-          for (int i = 0; i < 18; ++i) v = MX[l] == i ? x[i] : v;
-          s_w[RU_X9 + l] = v;
-          s_w[RU_XREF + l] = (l >= 5 && l < 8) ? (l == 5 ? dm[0] : (l == 6 ? dm[1] : dm[2])) : v;          // env.py:380-383
-        }
-        __syncthreads();
-        mpc_state_vectors(s_w + RU_A, s_w + RU_Q, s_w + RU_QB, s_w + RU_G, s_w + RU_X9, s_w + RU_XREF, s_w + RU_PRED, s_w + RU_WBUF,
-                          s_w + RU_QV, N);
-        for (int e = l; e < n; e += 64) exw[e] = s_w[RU_QV + e];
-        for (int e = l; e < 9 * N; e += 64) exw[n + 27 * N + e] = s_w[RU_PRED + e];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        SolveState st;
+    PairIO io;
+    io.x = ra.x; io.u = ra.u; io.dem = ra.dem; io.traj = ra.traj; io.cmd_traj = ra.cmd_traj; io.iters_traj = ra.iters_traj;
+    io.status = ra.status; io.tab = ra.tab; io.lofi = ra.lofi; io.exw = a.ext + (size_t)b * mpc_ext_doubles(N);
+    io.ld = a.ld; io.b = b; io.t = t; io.N = N; io.every = ra.every; io.fi = ra.fi; io.flags = ra.flags; io.xcg = ra.xcg; io.dt = a.dt;
+    io.cmd[0] = NAN; io.cmd[1] = NAN; io.cmd[2] = NAN; io.iters = 0; io.stw = 0;
+    const int code = __builtin_amdgcn_readfirstlane(pair_prepare(&io));
+    if (code == PAIR_SOLVE) {
+      SolveState st;
 #ifdef F16_EXP_STAMPW
-        unsigned long long tK0 = 0;
-        const bool ok = solve_aircraft(a, b, (long)k + 1, R, st, tK0);
+      unsigned long long tK0 = 0;
+      const bool ok = solve_aircraft(a, b, (long)k + 1, R, st, tK0);
 #else
-        const bool ok = solve_aircraft(a, b, (long)k + 1, R, st);
+      const bool ok = solve_aircraft(a, b, (long)k + 1, R, st);
 #endif
-        const bool infeasible = __builtin_amdgcn_readfirstlane(st.infeasible) != 0;
-        const bool converged = __builtin_amdgcn_readfirstlane(st.converged) != 0;
-        iters = __builtin_amdgcn_readfirstlane(st.it);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) cmd[c] = infeasible ? NAN : bcast0_f64(st.x[c]);       // res.x[0:3], env.py:424 (lane 0 owns step 0)
-        if (infeasible) stw |= F16_ST_QP_INFEASIBLE;
-        else if (!converged || !__builtin_amdgcn_readfirstlane((int)ok)) stw |= F16_ST_QP_MAXITER;
-        wave_lds_sync();
-      } else {
-        stw |= ST_NONFINITE;                                   // no QP to solve (f16_mpc.hpp: mpc_job_nonfinite): NaN command
-      }
-      // u.values[1:] = cmd (test_env.py:490-493); F16_FLAG_HOLD_COMMAND: a step without a command keeps the previous one
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-        if (!((ra.flags & F16_FLAG_HOLD_COMMAND) && cmd[c] != cmd[c])) u[1 + c] = cmd[c];
-      // step(u.values): env.py:126, the one-lane rollout kernel's own step (f16_dynamics.hip: rollout_lanes, exact trigonometry)
-      {
-        const TrigSlots ts{s_w, 1};
-        Trig5 g;
-        trig_exact(x, g);
-        trig_store(ts, g);
-        double xd[18];
-        int sa = 0;
-        if (ra.fi == 0) calc_xdot<0, const double *, true>(ra.tab, ra.lofi, x, u, xd, ra.xcg, ra.fi, ra.flags, sa, &ts);
-        else calc_xdot<-1, const double *, true>(ra.tab, ra.lofi, x, u, xd, ra.xcg, ra.fi, ra.flags, sa, &ts);
-        stw |= sa;
-#pragma unroll
-        for (int i = 0; i < 18; ++i) x[i] += xd[i] * a.dt;
-      }
-      bool finx = true;
-#pragma unroll
-      for (int i = 0; i < 18; ++i) finx = finx && isfinite(x[i]);
-      if (!finx) stw |= ST_NONFINITE;
+      const bool infeasible = __builtin_amdgcn_readfirstlane(st.infeasible) != 0;
+      const bool converged = __builtin_amdgcn_readfirstlane(st.converged) != 0;
+      const double c0 = bcast0_f64(st.x[0]), c1 = bcast0_f64(st.x[1]), c2 = bcast0_f64(st.x[2]);      // res.x[0:3], env.py:424 (lane 0 owns step 0)
+      io.iters = __builtin_amdgcn_readfirstlane(st.it);
+      io.cmd[0] = infeasible ? NAN : c0; io.cmd[1] = infeasible ? NAN : c1; io.cmd[2] = infeasible ? NAN : c2;
+      if (infeasible) io.stw |= F16_ST_QP_INFEASIBLE;         // OSQP hands back NaN for a problem it certifies infeasible
+      else if (!converged || !uniform_flag(ok)) io.stw |= F16_ST_QP_MAXITER;
+      wave_lds_sync();
     }
-    // ---- publish: state, command, flags, samples (one lane), then the release
-    if (l == 0) {
-      if (live) {
-#pragma unroll
-        for (int i = 0; i < 18; ++i) ra.x[i * ld + b] = x[i];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) ra.u[(1 + c) * ld + b] = u[1 + c];
-      }
-      if (ra.status) ra.status[b] = stw;
-      if (ra.traj && (t + 1) % ra.every == 0) {
-        double *tr = ra.traj + (size_t)((t + 1) / ra.every - 1) * 18 * ld + b;
-#pragma unroll
-        for (int i = 0; i < 18; ++i) __builtin_nontemporal_store(x[i], tr + i * ld);
-      }
-      if (ra.cmd_traj) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) ra.cmd_traj[((size_t)t * 3 + c) * ld + b] = cmd[c];
-      }
-      if (ra.iters_traj) ra.iters_traj[(size_t)t * ld + b] = iters;
-    }
+    pair_finish(&io, code);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (l == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&ra.progress[b], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    __hip_atomic_store(&ra.progress[b], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (64 lanes, one word, one value)
   }
 }
 
@@ -1785,16 +1839,17 @@ int mpc_wave_solve_launch(f16_ctx *ctx, const MpcArgs &a, void *stream) {
 // f16_rollout_mpc: the closed loop as one launch (k_rollout_mpc).  `sync` = the plan's [8 bytes ticket counter | B x int32 progress].
 int mpc_wave_rollout_launch(f16_ctx *ctx, const MpcArgs &a, const RolloutMpcCall &c, void *stream) {
   if (a.N < 1 || a.N > WAVE_MAXN || !a.gramws || !a.pblk || !a.ext || !a.Ppk) return set_error(F16_EINVAL, "closed-loop MPC rollout needs a plan with 1 <= hzn <= 30");
-  if (a.B > 0x7fffffffL) return set_error(F16_EINVAL, "batch too large for one launch");
+  if ((unsigned long long)a.B * (unsigned long long)c.T >= 0xffffffffULL) return set_error(F16_EINVAL, "nsteps x B must stay below 2^32 per call");
   wave::RollMpcArgs r{};
   r.m = a;
   r.m.x = c.x; r.m.dem = c.dem; r.m.xref = nullptr; r.m.ucmd = nullptr; r.m.useq = nullptr; r.m.info = nullptr; r.m.status = nullptr;
   r.m.mode = 0; r.m.wave_ruiz = 1; r.m.order = nullptr; r.m.iters_out = nullptr; r.m.warm = nullptr; r.m.warm_load = 0; r.m.wave_queue = nullptr;
   r.x = c.x; r.u = c.u; r.dem = c.dem; r.traj = c.traj; r.cmd_traj = c.cmd_traj; r.iters_traj = c.iters_traj; r.status = c.status;
-  r.queue = reinterpret_cast<unsigned long long *>(c.sync);
+  r.queue = reinterpret_cast<unsigned *>(c.sync);
   r.progress = reinterpret_cast<int32_t *>(c.sync) + 2;
   r.tab = ctx->d_tab; r.lofi = ctx->d_lofi;
   r.T = c.T; r.every = c.every; r.xcg = c.xcg; r.fi = c.fi; r.flags = c.flags;
+  r.total = (unsigned)((unsigned long long)a.B * (unsigned long long)c.T);
   r.stride = 0;
   static const bool spread = [] { const char *e = getenv("F16_MPC_SPREAD"); return !(e && e[0] == '0'); }();
   if (spread && a.B > 16) {

@@ -103,7 +103,14 @@ int f16_nlplant_batch(f16_ctx *ctx, const double *xu, double *xdot, int32_t *sta
                       long B, long ld, double xcg, int fi_flag, unsigned flags, void *stream);
 /* env.py:105-130 step, in place: envelope check, x += xdot*dt.  nsteps Euler steps per launch with the
  * state held in registers; traj (may be NULL) receives the state after every `traj_every`-th step as
- * [nsteps/traj_every][18][ld]. */
+ * [nsteps/traj_every][18][ld].
+ * Split launches: rollout(n) followed by rollout(m) equals rollout(n + m) BIT FOR BIT for B <= 16,384 (the kernels of that
+ * range evaluate every sine / cosine from scratch) and, for larger batches, whenever n is a multiple of 32: the one-lane
+ * kernels of the large-batch range carry the five sin / cos pairs of a step to the next one by the exact increment of their
+ * angles and re-evaluate them exactly at steps 0, 32, 64, ... of the LAUNCH (default build; -DF16_NO_INC_TRIG switches it off), so
+ * a split at another step re-evaluates at other steps: the two results then differ by the rounding of the carried pairs, <= 1e-12
+ * relative over 100 steps (tests/test_gpu_dynamics.py::test_split_launches_*).  For the same reason an aircraft's last bits
+ * depend on which kernel its batch size selects; F16_FLAG_ONE_LANE pins the kernel (not the carried pairs). */
 int f16_rollout(f16_ctx *ctx, double *x, const double *u, double *traj, int32_t *status,
                 long B, long ld, int nsteps, int traj_every, double dt, double xcg, int fi_flag,
                 unsigned flags, void *stream);

@@ -20,6 +20,9 @@ for f in [g for d in dirs for g in glob.glob(os.path.join(d, "**", "*counter_col
         a = acc[(short, r["Counter_Name"])]
         a[0] += float(r["Counter_Value"]); a[1] += 1
 out = os.path.join(REPO, "profiles", f"{tag}_pmc_dyn.csv")
+if not acc:
+    # (round 4: a second run after gpurun_out/ had been cleaned replaced 42 rows with a header line -- and bench.py went on citing it)
+    sys.exit(f"no k_rollout rows under {dirs}: {out} is left as it is")
 with open(out, "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "counter", "dispatch_rows", "mean_per_dispatch"])

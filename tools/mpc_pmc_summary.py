@@ -35,6 +35,8 @@ for d in dirs:
             a = acc[(k, r["Counter_Name"])]
             a[0] += float(r["Counter_Value"]); a[1] += 1
 out = os.path.join(REPO, "profiles", f"{tag}_pmc_mpc.csv")
+if not acc:
+    sys.exit(f"no MPC kernel rows found: {out} is left as it is")
 with open(out, "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "counter", "sum_over_dispatches", "dispatch_rows", "mean_per_launch"])
