@@ -177,6 +177,62 @@ __device__ __forceinline__ void rollout_lanes(const DynArgs &a, TP T, double (*u
   }
 }
 
+// F16_FLAG_ONE_LANE: one lane per aircraft, 64-lane workgroups, every step through the out-of-line euler_step_exact (table image read
+// from global memory: no LDS staging) -- ONE instruction sequence for every batch size, the one the closed MPC loop (f16_rollout_mpc)
+// steps with.  Same rules as rollout_lanes (envelope freeze, status bits, trajectory samples, u_out); a reproducibility path, not a
+// fast one.
+template <bool LQR>
+__global__ __launch_bounds__(64) void k_rollout_exact(DynArgs a) {
+  for (long b = (long)blockIdx.x * 64 + threadIdx.x; b < a.B; b += (long)gridDim.x * 64) {
+    double x[18], u[4];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) x[k] = a.out[k * a.ld + b];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = a.u[k * a.ld + b];
+    double kq[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, u0[3] = {u[1], u[2], u[3]};
+    if (LQR) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) kq[3 * i + j] = a.K[(9 * i + 4 + j) * a.ld + b];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) kq[9 + j] = a.dem[j * a.ld + b];
+    }
+    int st = a.status ? a.status[b] : 0;
+    double *tr = a.traj ? a.traj + b : nullptr;
+    int until_store = a.traj_every;
+    for (int t = 0; t < a.nsteps; ++t) {
+      if (!(a.flags & FLAG_NO_ENVELOPE) && outside_envelope(x)) st |= ST_ENVELOPE;      // env.py:117-124
+      if (!(st & ST_ENVELOPE)) {
+        if (LQR) {
+          const double e0 = kq[9] - x[9], e1 = kq[10] - x[10], e2 = kq[11] - x[11];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) u[1 + i] = lqr_action(kq[3 * i], kq[3 * i + 1], kq[3 * i + 2], e0, e1, e2, u0[i]);
+        }
+        euler_step_exact(a.tab, a.lofi, x, u, a.dt, a.xcg, a.fi, a.flags, &st);
+      }
+      if (tr && --until_store == 0) {
+        until_store = a.traj_every;
+#pragma unroll
+        for (int k = 0; k < 18; ++k) __builtin_nontemporal_store(x[k], tr + k * a.ld);
+        tr += 18 * a.ld;
+      }
+    }
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) finite = finite && isfinite(x[k]);
+    if (!finite) st |= ST_NONFINITE;
+    if (st & ST_ENVELOPE) st |= envelope_state_bits(x);
+#pragma unroll
+    for (int k = 0; k < 18; ++k) a.out[k * a.ld + b] = x[k];
+    if (a.status) a.status[b] = st;
+    if (LQR && a.u_out) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a.u_out[i * a.ld + b] = u[i];
+    }
+  }
+}
+
 template <int BLOCK, int FI, bool LQR = false>
 __global__ __launch_bounds__(BLOCK) void k_rollout(DynArgs a) {
   __shared__ __attribute__((aligned(16))) double tab[TABLE_IMAGE_DOUBLES];
@@ -856,12 +912,9 @@ static int rollout_dispatch(f16_ctx *ctx, DynArgs &a, void *stream) {
   static const long max4w = [] { const char *e = getenv("F16_ROLLOUT_4W_MAXB"); return e ? atol(e) : 64L * 256; }();
   static const long maxq = [] { const char *e = getenv("F16_ROLLOUT_QUAD_MAXB"); return e ? atol(e) : 16L * 256; }();
   if (a.flags & F16_FLAG_ONE_LANE) {
-    // results independent of the batch size: one instantiation (64-lane workgroups, one lane per aircraft, fp64 table image) for every B
+    // results independent of the batch size: ONE kernel for every B, its step an out-of-line function (k_rollout_exact)
     const long blocks = (B + 63) / 64;
-    const unsigned grid = (unsigned)(blocks < 256 ? blocks : 256);
-    const hipStream_t st = (hipStream_t)stream;
-    if (fi_flag == 0) hipLaunchKernelGGL((k_rollout<64, 0, LQR>), dim3(grid), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_rollout<64, -1, LQR>), dim3(grid), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_rollout_exact<LQR>, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(64), 0, (hipStream_t)stream, a);
     return hip_check(hipGetLastError(), "f16_rollout launch");
   }
   if (fi_flag == 1 && B <= maxq) {

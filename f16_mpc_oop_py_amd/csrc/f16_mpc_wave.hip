@@ -1680,8 +1680,8 @@ __device__ __noinline__ int pair_prepare(PairIO *io) {
 }
 
 // End of a pair: u.values[1:] = cmd (test_env.py:490-493; F16_FLAG_HOLD_COMMAND: a step without a command keeps the previous one),
-// step(u.values) (env.py:126: the one-lane rollout kernel's own step -- f16_dynamics.hip rollout_lanes, exact trigonometry; the table
-// image from global memory), then the stores of the pair: state, command, flags, samples.
+// step(u.values) (env.py:126: euler_step_exact, the out-of-line step of the F16_FLAG_ONE_LANE rollout kernel; the table image from
+// global memory), then the stores of the pair: state, command, flags, samples.
 __device__ __noinline__ void pair_finish(const PairIO *io, int code) {
   const int l = threadIdx.x;
   const long ld = io->ld, b = io->b;
@@ -1700,20 +1700,7 @@ __device__ __noinline__ void pair_finish(const PairIO *io, int code) {
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       if (!((flags & F16_FLAG_HOLD_COMMAND) && cmd[c] != cmd[c])) u[1 + c] = cmd[c];
-    wave_lds_sync();
-    const TrigSlots ts{s_w, 1};
-    Trig5 g;
-    trig_exact(x, g);
-    trig_store(ts, g);
-    double xd[18];
-    int sa = 0;
-    const int fi = __builtin_amdgcn_readfirstlane(io->fi);
-    if (fi == 0) calc_xdot<0, const double *, true>(io->tab, io->lofi, x, u, xd, io->xcg, fi, flags, sa, &ts);
-    else calc_xdot<-1, const double *, true>(io->tab, io->lofi, x, u, xd, io->xcg, fi, flags, sa, &ts);
-    stw |= sa;
-    const double dt = io->dt;
-#pragma unroll
-    for (int i = 0; i < 18; ++i) x[i] += xd[i] * dt;
+    euler_step_exact(io->tab, io->lofi, x, u, io->dt, io->xcg, __builtin_amdgcn_readfirstlane(io->fi), flags, &stw);
     bool finx = true;
 #pragma unroll
     for (int i = 0; i < 18; ++i) finx = finx && isfinite(x[i]);

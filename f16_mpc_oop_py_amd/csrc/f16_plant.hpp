@@ -915,4 +915,23 @@ F16_DEV bool outside_envelope(const double *x) {
   return bad;
 }
 
+// ONE explicit-Euler step of ONE aircraft (env.py:105-130 without the envelope test; exact trigonometry), compiled OUT OF LINE: a
+// function of its own has one instruction sequence whoever calls it, so the kernels that step through it -- the F16_FLAG_ONE_LANE
+// rollout (f16_dynamics.hip: k_rollout_exact) and the closed MPC loop (f16_mpc_wave.hip: k_rollout_mpc) -- agree bit for bit.  (The
+// same source inlined into two kernels does not: FMA contraction follows the surrounding code, and the navigation states came out an
+// ulp apart.)  tab: the fp64 table image through a generic pointer (LDS or global); xio[18] in / out, uin[4], *stio |= the grid bits.
+static __device__ __noinline__ void euler_step_exact(const double *tab, const double *lofi, double *xio, const double *uin, double dt,
+                                                     double xcg, int fi, unsigned flags, int *stio) {
+  double x[18], u[4], xd[18];
+#pragma unroll
+  for (int k = 0; k < 18; ++k) x[k] = xio[k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) u[k] = uin[k];
+  int st = 0;
+  calc_xdot<-1>(tab, lofi, x, u, xd, xcg, fi, flags, st);
+#pragma unroll
+  for (int k = 0; k < 18; ++k) xio[k] = x[k] + xd[k] * dt;   // env.py:126
+  *stio |= st;
+}
+
 }  // namespace f16
