@@ -298,6 +298,28 @@ def run(args):
         if "mpc" in out:
             out["mpc"]["cpu_baseline"] = cpu_baseline_mpc(args.mpc_hzn)
         out["config1_reference_style_loop"] = config1_reference_style_loop()
+    # The second half of BASELINE's metric (MPC solves/s) and config 5, compact, INSIDE the object the driver's record keeps verbatim
+    # (`roofline`; the full `mpc` / `config5_closed_loop` blocks stay beside it).  The first-call figure leads: BASELINE config 4 as
+    # written is one call per aircraft on an unseen batch.
+    if "mpc" in out:
+        m = out["mpc"]
+        r = m.get("roofline", {})
+        out["roofline"]["mpc"] = {
+            "workload": "BASELINE config 4: B=%d/GPU, N=%d, xcg 0.35, osqp defaults, one calc_MPC_action per aircraft" % (args.batch, args.mpc_hzn),
+            "first_call_solves_per_s": m.get("first_call_value"), "repeated_solves_per_s": m.get("value"),
+            "ms_per_batch": m.get("ms_per_batch"), "iters_mean": m.get("admm_iters", {}).get("mean"),
+            "frac_issued": (r.get("issued_flop_per_launch") or 0.0) / (m["ms_per_batch"] * 1e-3) / 78.6e12 if r.get("issued_flop_per_launch") else None,
+            "frac_dense_form": r.get("frac"), "mfma_busy_frac": r.get("mfma_busy_frac"),
+            "cpu_solves_per_s": (m.get("cpu_baseline") or {}).get("value"), "cpu_cores": (m.get("cpu_baseline") or {}).get("cores")}
+    if "config5_closed_loop" in out:
+        c = out["config5_closed_loop"]
+        out["roofline"]["config5"] = {
+            "workload": "BASELINE config 5 per GPU: B=%d, N=%d, T=%d closed-loop steps, reference settings, cold start" % (c["batch_per_gpu"], c["hzn"], c["steps"]),
+            "aircraft_steps_per_s_one_launch": c["headline"]["aircraft_steps_per_s"],
+            "aircraft_steps_per_s_host_loop": c["host_loop"]["aircraft_steps_per_s"],
+            "aircraft_steps_per_s_one_launch_hold_command": c["fused_hold_command"]["aircraft_steps_per_s"],
+            "iters_mean": c["headline"]["iters_mean"], "aircraft_infeasible_at_some_step": c["headline"]["aircraft_infeasible_at_some_step"],
+            "aircraft_not_finite_at_the_end": c["headline"]["aircraft_not_finite_at_the_end"]}
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
@@ -678,7 +700,7 @@ def bench_closed_loop(args, dev, rank, world, fdist, barrier):
         # must be finite and unflagged.
         st_ = env.status
         flagged = (st_ & (32 | 128)) != 0
-        assert fdist.or_status(st_) & ~(32 | 64 | 128) == 0
+        assert int((st_[~flagged] & ~64).abs().max()) == 0 if bool((~flagged).any()) else True     # (a NaN surface state also reads as "off the grid": bits 1..8 of flagged aircraft)
         assert bool(torch.isfinite(traj[:, :, ~flagged]).all())
         if hold:
             assert bool(torch.isfinite(traj).all())
