@@ -187,7 +187,7 @@ def run(args):
     import torch
     import torch.distributed as dist
     from f16_mpc_oop_py_amd import F16Batch
-    from f16_mpc_oop_py_amd.workload import config2_states
+    from f16_mpc_oop_py_amd.workload import config2_states, in_grid_on_gpu
     from f16_mpc_oop_py_amd import dist as fdist
     from f16_mpc_oop_py_amd.env import _vp
 
@@ -204,7 +204,9 @@ def run(args):
         torch.cuda.synchronize()
 
     B, T = args.batch, args.euler_steps
-    x0_all, u0_all = config2_states(B * world)        # global batch, contiguous shards
+    # global batch, contiguous shards; 8(d)'s rule: a candidate that leaves the grid within T steps is resampled from
+    # the same seed stream (every rank applies it to the whole global batch on its own GPU: same batch everywhere)
+    x0_all, u0_all = config2_states(B * world, accept=in_grid_on_gpu(0.25, steps=T, device=dev))
     x0, u0 = x0_all[rank * B:(rank + 1) * B], u0_all[rank * B:(rank + 1) * B]
     env = F16Batch(x0, u0, device=dev)
     traj = torch.empty((T, 18, B), dtype=torch.float64, device=dev)

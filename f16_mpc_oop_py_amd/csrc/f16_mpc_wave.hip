@@ -44,6 +44,12 @@ constexpr int FN = 16 * NT;                // 96
 // factorisation before that; the vectors of the iteration sit behind it.
 constexpr int KI_SIZE = 36 * NL * 2;                  // 4320
 constexpr int WS_OFF = KI_SIZE, WS_SIZE = 444;         // state-row vector: six kept rows per step, steps 0..33 (equilibration: E of all nine rows)
+// ... in the iterations six doubles of padding follow every five steps (ws_idx): the lanes of a stage-1 block (s, I) read 16-byte
+// slots at 30 I + 2 s doubles, which put (0,0), (1,1), (2,2) on the same four banks (tools/wave_lds_conflicts.py: 27 extra LDS cycles
+// on the nine reads of an iteration, 9 with the padding)
+constexpr int WS_PAD = 6;
+__host__ __device__ constexpr int ws_idx(int step) { return 6 * step + WS_PAD * (step / 5); }
+static_assert(ws_idx(33) + 6 <= WS_SIZE, "state-row vector with its block padding");
 constexpr int WC_OFF = WS_OFF + WS_SIZE, WC_SIZE = 92;                 // command rows (also: rhs of the linear system)
 constexpr int WR_OFF = WC_OFF + WC_SIZE, WR_SIZE = 96;                 // rate rows (read up to k + 3)
 constexpr int LDS_DOUBLES = 5120;                      // 40,960 B: four wavefront-workgroups per CU
@@ -249,10 +255,10 @@ __device__ __forceinline__ void stage3_totals(const int (&a3)[6], double (&out)[
 // stage 1, block (I, T): partial sums of (CCs' v)_j, j = 5(I - T) + e, all three variables, from rows 2s, 2s + 1 of the state-row
 // vector in LDS (six per step), steps 5I..5I+8 -> record of the lane: [e][3 + one pad]
 __device__ __forceinline__ void stage1_partials(const double (&Gd)[TB][2][3], const TJob &J) {
-  const double2 *wp = reinterpret_cast<const double2 *>(s_w + WS_OFF + 6 * TB * J.I + 2 * J.s);
+  const double2 *wp = reinterpret_cast<const double2 *>(s_w + WS_OFF + ws_idx(TB * J.I) + 2 * J.s);
   double wv[9][2];
 #pragma unroll
-  for (int m = 0; m < 9; ++m) { const double2 a = wp[3 * m]; wv[m][0] = a.x; wv[m][1] = a.y; }
+  for (int m = 0; m < 9; ++m) { const double2 a = wp[ws_idx(m) / 2];      /* step 5 I + m: ws_idx(5 I + m) = ws_idx(5 I) + ws_idx(m) */ wv[m][0] = a.x; wv[m][1] = a.y; }
   WAVE_LDS_PHASE();
   double acc[TB][3];
 #pragma unroll
@@ -389,7 +395,9 @@ __device__ __forceinline__ void load_KA_image(double (&A)[6][6], const double *k
 }
 // x~ = K^-1 rhs in the hot loop: A blocks in registers, B blocks from LDS (chunks 18..35 of the image), rhs in natural order (LDS)
 __device__ __forceinline__ void kkt_matvec(const double (&A)[6][6], const double *v, const Role &R, double (&y)[6]) {
-  const int lb = R.l < NL ? R.l : NL - 1;
+  // (the four idle lanes read the chunks of lanes 36..39 -- lanes of their own 16-lane ds_read_b128 group, i.e. a broadcast; reading
+  //  lane 59's, as before round 5, put them on the banks of lane 43: one extra LDS cycle on each of the 18 reads)
+  const int lb = R.l < NL ? R.l : R.l - 24;
   const int rr = R.r < NB ? R.r : NB - 1;
   double Bk[6][6];
   const double2 *ki = reinterpret_cast<const double2 *>(s_w) + lb;
@@ -738,7 +746,7 @@ struct RowSlots {                                // where a lane's rows live in 
   double *wsn, *wB;
   bool act;
   __device__ __forceinline__ RowSlots(const Role &R) {
-    wsn = s_w + WS_OFF + 6 * R.istep + 3 * R.h;
+    wsn = s_w + WS_OFF + ws_idx(R.istep) + 3 * R.h;
     wB = s_w + (R.par ? WR_OFF : WC_OFF) + 3 * R.istep;
     act = R.act;
   }

@@ -16,6 +16,10 @@ step "kernel-trace + stats of the default bench command"
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_stats -o st -- python3 bench.py --steps 10 --warmup 2 > $O/bench_under_rocprof.json 2> $O/prof_stats.err
 step "kernel-trace + stats of the MPC leg ALONE, headline settings only (B = 4096, N = 30, osqp defaults)"
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_stats_mpc -o stm -- python3 tools/gpu_mpc_only.py > $O/prof_stats_mpc.log 2> $O/prof_stats_mpc.err
+step "kernel-trace + stats of the config-5 closed loop ALONE as one launch (B = 8192, T = 100, N = 30: f16_rollout_mpc), then its issue counters"
+rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_stats_c5 -o c5 -- python3 tools/gpu_config5_only.py > $O/prof_stats_c5.log 2> $O/prof_stats_c5.err
+rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE \
+  -d $O/prof_c5_sq -o c5 -- python3 tools/gpu_config5_only.py > $O/prof_c5_sq.log 2> $O/prof_c5_sq.err
 step "HBM traffic: FETCH_SIZE, WRITE_SIZE (separate passes), B = 4096 and B = 262,144 rollouts"
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/prof_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mpc --no-config5 > /dev/null 2> $O/prof_fetch.err
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/prof_write -o w -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mpc --no-config5 > /dev/null 2> $O/prof_write.err
