@@ -12,6 +12,9 @@ mkdir -p $O
 cd $R
 python3 -c 'from f16_mpc_oop_py_amd import lib; lib.load(); print("library ok:", lib.SO_PATH)'
 step() { echo "== $1 ($(date +%T))"; }
+# bash tools/profile_round.sh [a|b]: the passes in two halves (a gpurun call is limited to 20 minutes); no argument = everything
+HALF=${1:-ab}
+if [[ $HALF == *a* ]]; then
 step "kernel-trace + stats of the default bench command"
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_stats -o st -- python3 bench.py --steps 10 --warmup 2 > $O/bench_under_rocprof.json 2> $O/prof_stats.err
 step "kernel-trace + stats of the MPC leg ALONE, headline settings only (B = 4096, N = 30, osqp defaults)"
@@ -28,6 +31,8 @@ rocprofv3 --output-format csv --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MO
   -d $O/prof_mfma -o m -- python3 tools/gpu_mpc_only.py > $O/prof_mfma.log 2> $O/prof_mfma.err
 rocprofv3 --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_LDS \
   -d $O/prof_lds -o l -- python3 tools/gpu_mpc_only.py > $O/prof_lds.log 2> $O/prof_lds.err
+fi
+if [[ $HALF == *b* ]]; then
 step "dynamics kernels: issue counters, then LDS pipe + fp64 instruction mix"
 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT \
   -d $O/prof_dyn -o d -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mpc --no-config5 > /dev/null 2> $O/prof_dyn.err
@@ -41,4 +46,5 @@ rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VA
   -d $O/prof_sweep_sq -o s -- python3 tools/gpu_sweep_only.py 64 150 > /dev/null 2> $O/prof_sweep_sq.err
 step "plain bench (the record the profile is compared with)"
 python3 bench.py > $O/bench.json 2> $O/bench.err
+fi
 step "done"
