@@ -321,7 +321,8 @@ def run(args):
             "aircraft_steps_per_s_host_loop": c["host_loop"]["aircraft_steps_per_s"],
             "aircraft_steps_per_s_one_launch_hold_command": c["fused_hold_command"]["aircraft_steps_per_s"],
             "iters_mean": c["headline"]["iters_mean"], "aircraft_infeasible_at_some_step": c["headline"]["aircraft_infeasible_at_some_step"],
-            "aircraft_not_finite_at_the_end": c["headline"]["aircraft_not_finite_at_the_end"]}
+            "aircraft_not_finite_at_the_end": c["headline"]["aircraft_not_finite_at_the_end"],
+            "one_launch_equals_host_loop_bit_for_bit": c["one_launch_equals_host_loop_bit_for_bit"]}
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
@@ -679,7 +680,7 @@ def bench_closed_loop(args, dev, rank, world, fdist, barrier):
     res = {}
     short = max(4, T // 5)
 
-    def leg(name, use_plan, steps, keep_traj=False, fused=False, hold=False):
+    def leg(name, use_plan, steps, keep_traj=False, fused=False, hold=False, one_lane=False):
         env = F16Batch(x0[sl], u0[sl], xcg=0.35, device=dev)
         env.build_ssr()
         if use_plan:
@@ -687,7 +688,7 @@ def bench_closed_loop(args, dev, rank, world, fdist, barrier):
             if "builder_rule" in name:
                 st.update(F16Batch.solver_modes()["builder_rule"])
             env.prepare_MPC(args.mpc_hzn, settings=st or None, warm_start="warm_start" in name)
-        kw = dict(hzn=args.mpc_hzn, gather=False, use_plan=use_plan, fused=fused, hold_command=hold)
+        kw = dict(hzn=args.mpc_hzn, gather=False, use_plan=use_plan, fused=fused, hold_command=hold, one_lane=one_lane)
         fdist.closed_loop_mpc_rollout(env, steps=2, stats={}, **kw)    # (stats: the reductions' first launch too)
         env.reset()
         stats = {}
@@ -725,7 +726,14 @@ def bench_closed_loop(args, dev, rank, world, fdist, barrier):
     r, traj, dt = leg("fused", True, T, keep_traj=True, fused=True)
     res["headline_leg"] = "fused (f16_rollout_mpc: one launch, (step, aircraft) pairs from a work queue)"
     res["headline"] = r
-    res["host_loop"] = leg("prepared_plan", True, T)[0]
+    # the host loop over the same T steps, stepping with the one-lane kernel the fused loop steps with (F16_FLAG_ONE_LANE): the two
+    # trajectories must then be IDENTICAL, bit for bit, at full size -- every aircraft, every step, NaN patterns included
+    rh, trajh, _ = leg("prepared_plan", True, T, keep_traj=True, one_lane=True)
+    res["host_loop"] = rh
+    same = bool(torch.equal(torch.nan_to_num(traj, nan=1e300), torch.nan_to_num(trajh, nan=1e300)))
+    res["one_launch_equals_host_loop_bit_for_bit"] = same
+    assert same, "f16_rollout_mpc and the host loop disagree"
+    del trajh
     res["fused_hold_command"] = leg("fused_hold", True, T, fused=True, hold=True)[0]
     barrier()
     t0 = time.perf_counter()

@@ -1769,7 +1769,10 @@ __global__ __launch_bounds__(64, 1) void k_rollout_mpc(RollMpcArgs ra) {
     const int code = __builtin_amdgcn_readfirstlane(pair_prepare(&io));
     if (code == PAIR_SOLVE) {
       SolveState st;
-#ifdef F16_EXP_STAMPW
+#ifdef F16_DBG_SKIP_SOLVE      // (measurement build: what a pair costs WITHOUT its solve -- tools/gpu_config5_only.py under F16HIP_SO)
+      st.infeasible = 0; st.converged = 1; st.it = 0; st.x[0] = -0.5; st.x[1] = 0.0; st.x[2] = 0.0;
+      const bool ok = true;
+#elif defined(F16_EXP_STAMPW)
       unsigned long long tK0 = 0;
       const bool ok = solve_aircraft(a, b, (long)k + 1, R, st, tK0);
 #else
