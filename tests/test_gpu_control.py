@@ -1052,7 +1052,7 @@ def _same(a, b):
     return np.array_equal(a, b, equal_nan=True)
 
 
-@pytest.mark.parametrize("B,N,steps", [(256, 30, 8), (100, 10, 12), (1, 30, 5)])
+@pytest.mark.parametrize("B,N,steps", [(256, 30, 8), (100, 10, 12), (1, 30, 5), (3, 4, 40), (1500, 29, 3)])
 def test_fused_closed_loop_mpc_rollout_equals_the_host_loop_bit_for_bit(oracle, B, N, steps):
     """f16_rollout_mpc (the reference's loop test_env.py:480-495 as ONE launch: (step, aircraft) pairs from a work queue, a wavefront
     builds the QP vectors, solves, writes the command and steps its pair) against the host loop of six launches per step: every
@@ -1131,6 +1131,24 @@ def test_fused_closed_loop_flagged_aircraft_nan_commands_hold_and_frozen(oracle)
     sfh, xgh, ith, cgh = out[True]
     assert np.array_equal((sfh & 128) != 0, inf) or ((sfh & 128) != 0).sum() >= inf.sum()
     assert np.isfinite(np.delete(xgh, 5, 0)).all() and not (np.delete(sfh, 5) & 32).any()   # held commands: everybody flies on
+
+
+def test_fused_closed_loop_lofi_model_and_horizon_one():
+    """The one-launch loop on the lofi Stevens-Lewis model (fi_flag = 0: the out-of-line step takes the fidelity at run time) and at
+    the shortest horizon, N = 1: identical to the host loop."""
+    from f16_mpc_oop_py_amd.workload import config4_states
+    x0, u0 = config4_states(64, seed=21)
+    x0[:, 7] = np.clip(x0[:, 7], np.deg2rad(-8.0), np.deg2rad(40.0))       # the lofi tables cover alpha -10..45 deg
+    for fi, N in ((0, 10), (1, 1)):
+        dem = (0.01, 0.0, -0.01)
+        envh = make_env(x0, u0, xcg=0.35, fi_flag=fi)
+        envh.build_ssr(); envh.prepare_MPC(N)
+        trh, ch, ih = _host_loop(envh, 6, N, dem)
+        envf = make_env(x0, u0, xcg=0.35, fi_flag=fi)
+        envf.build_ssr(); envf.prepare_MPC(N)
+        trf, info = envf.rollout_MPC(6, *dem, N, traj_every=1, return_info=True)
+        assert _same(info["cmd"], ch) and _same(info["iters"], ih) and _same(trf, trh) and _same(envf.status, envh.status)
+        assert bool(torch.isfinite(trf).all())
 
 
 def test_fused_closed_loop_argument_checks():
