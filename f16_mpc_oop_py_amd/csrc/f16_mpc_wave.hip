@@ -1632,7 +1632,7 @@ struct PairIO {
   unsigned flags;
   double xcg, dt;
   double cmd[3];                 // what calc_MPC_action returned (NaN: infeasible / not finite / no solve)
-  int iters, stw;
+  int iters, stw, stall;
 };
 enum { PAIR_SOLVE = 0, PAIR_FROZEN = 1, PAIR_NONFINITE = 2 };
 
@@ -1701,7 +1701,7 @@ __device__ __noinline__ void pair_finish(const PairIO *io, int code) {
   for (int i = 0; i < 18; ++i) x[i] = xg[i * ld + b];
 #pragma unroll
   for (int i = 0; i < 4; ++i) u[i] = ug[i * ld + b];
-  int stw = io->stw;
+  int stw = io->stw | io->stall;
   double cmd[3] = {io->cmd[0], io->cmd[1], io->cmd[2]};
   const bool live = __builtin_amdgcn_readfirstlane(code) != PAIR_FROZEN;
   if (live) {
@@ -1754,9 +1754,15 @@ __global__ __launch_bounds__(64, 1) void k_rollout_mpc(RollMpcArgs ra) {
     const long b = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ra.stride ? (unsigned)(((unsigned long long)j * ra.stride) % Bu) : j));
     // ---- wait for step t - 1 of this aircraft, then acquire what its wavefront published.  (Every lane polls the same word -- one
     // broadcast load -- and every lane publishes below: no lane-0-only region on either side of the loop's back edge.)
+    // The wait is bounded (2^24 polls, tens of seconds -- the longest legitimate wait is one 40,000-iteration solve, ~0.1 s): a wave
+    // that never sees its predecessor flags the aircraft (F16_ST_LOOP_STALL) and goes on, so that the grid drains whatever happens.
+    int stall = 0;
     if (t > 0) {
-      while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ra.progress[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < t)
+      int polls = 0;
+      while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ra.progress[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < t) {
         __builtin_amdgcn_s_sleep(16);
+        if (++polls > (1 << 24)) { stall = F16_ST_LOOP_STALL; break; }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1765,7 +1771,7 @@ __global__ __launch_bounds__(64, 1) void k_rollout_mpc(RollMpcArgs ra) {
     io.x = ra.x; io.u = ra.u; io.dem = ra.dem; io.traj = ra.traj; io.cmd_traj = ra.cmd_traj; io.iters_traj = ra.iters_traj;
     io.status = ra.status; io.tab = ra.tab; io.lofi = ra.lofi; io.exw = a.ext + (size_t)b * mpc_ext_doubles(N);
     io.ld = a.ld; io.b = b; io.t = t; io.N = N; io.every = ra.every; io.fi = ra.fi; io.flags = ra.flags; io.xcg = ra.xcg; io.dt = a.dt;
-    io.cmd[0] = NAN; io.cmd[1] = NAN; io.cmd[2] = NAN; io.iters = 0; io.stw = 0;
+    io.cmd[0] = NAN; io.cmd[1] = NAN; io.cmd[2] = NAN; io.iters = 0; io.stw = 0; io.stall = stall;
     const int code = __builtin_amdgcn_readfirstlane(pair_prepare(&io));
     if (code == PAIR_SOLVE) {
       SolveState st;

@@ -28,6 +28,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 
 F16_ST = dict(ALPHA1=1, ALPHA2=2, BETA=4, EL=8, ENVELOPE=16, NONFINITE=32, QP_MAXITER=64, QP_INFEASIBLE=128)
 F16_ST_ENV_STATE = lambda k: 1 << (8 + k)      # with ENVELOPE: state k was outside its box (env.py:117-124)
+F16_ST_LOOP_STALL = 1 << 26                    # f16_rollout_mpc gave up waiting for the aircraft's previous step (a guard; never observed)
 F16_FLAG_FIX_CLR = 1
 F16_FLAG_NO_ENVELOPE = 2
 F16_FLAG_ONE_LANE = 4          # rollouts: the one-lane-per-aircraft kernel whatever the batch size (results independent of B)

@@ -49,6 +49,8 @@ typedef struct f16_ctx f16_ctx;
 #define F16_ST_NONFINITE 32 /* a state became NaN/Inf                                         */
 #define F16_ST_QP_MAXITER 64 /* ADMM hit max_iter before meeting the OSQP termination test    */
 #define F16_ST_QP_INFEASIBLE 128 /* OSQP primal-infeasibility certificate met: command = NaN  */
+#define F16_ST_LOOP_STALL (1 << 26) /* f16_rollout_mpc: a wavefront gave up waiting (tens of seconds) for the previous step of this
+                                       aircraft and went on regardless -- a guard that lets the grid drain; never observed          */
 
 /* behaviour flags */
 #define F16_FLAG_FIX_CLR 1u      /* use the real CLr table (reference never loads it: hifi_F16_AeroData.c:964-972) */

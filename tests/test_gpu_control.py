@@ -1052,6 +1052,7 @@ def _same(a, b):
     return np.array_equal(a, b, equal_nan=True)
 
 
+@pytest.mark.timeout(300, method="thread")      # (a persistent kernel that never drains must fail the run, not hold it)
 @pytest.mark.parametrize("B,N,steps", [(256, 30, 8), (100, 10, 12), (1, 30, 5), (3, 4, 40), (1500, 29, 3)])
 def test_fused_closed_loop_mpc_rollout_equals_the_host_loop_bit_for_bit(oracle, B, N, steps):
     """f16_rollout_mpc (the reference's loop test_env.py:480-495 as ONE launch: (step, aircraft) pairs from a work queue, a wavefront
@@ -1083,6 +1084,7 @@ def test_fused_closed_loop_mpc_rollout_equals_the_host_loop_bit_for_bit(oracle, 
     assert tuple(tr2.shape) == (2, 18, B) and _same(envf._x, envh._x) and _same(tr2[-1], envf._x)
 
 
+@pytest.mark.timeout(300, method="thread")      # (a persistent kernel that never drains must fail the run, not hold it)
 def test_fused_closed_loop_flagged_aircraft_nan_commands_hold_and_frozen(oracle):
     """What a flagged aircraft does next, fused kernel = host loop = CPU loop (oracle/f16_mpc_oracle.c: f16o_mpc_closed_loop):
     an INFEASIBLE QP returns a NaN command as OSQP does (env.py:420-424); the actuator models propagate it (np.clip,
@@ -1133,6 +1135,7 @@ def test_fused_closed_loop_flagged_aircraft_nan_commands_hold_and_frozen(oracle)
     assert np.isfinite(np.delete(xgh, 5, 0)).all() and not (np.delete(sfh, 5) & 32).any()   # held commands: everybody flies on
 
 
+@pytest.mark.timeout(300, method="thread")      # (a persistent kernel that never drains must fail the run, not hold it)
 def test_fused_closed_loop_lofi_model_and_horizon_one():
     """The one-launch loop on the lofi Stevens-Lewis model (fi_flag = 0: the out-of-line step takes the fidelity at run time) and at
     the shortest horizon, N = 1: identical to the host loop."""
@@ -1151,6 +1154,7 @@ def test_fused_closed_loop_lofi_model_and_horizon_one():
         assert bool(torch.isfinite(trf).all())
 
 
+@pytest.mark.timeout(300, method="thread")      # (a persistent kernel that never drains must fail the run, not hold it)
 def test_fused_closed_loop_argument_checks():
     from f16_mpc_oop_py_amd import lib as L
     from f16_mpc_oop_py_amd.workload import config4_states
@@ -1166,6 +1170,7 @@ def test_fused_closed_loop_argument_checks():
     assert env.lib.f16_rollout_mpc(None, None, None, None, None, None, None, None, 1, 1, 0.35, 1, 0, None) == -1      # F16_EINVAL
 
 
+@pytest.mark.timeout(300, method="thread")      # (a persistent kernel that never drains must fail the run, not hold it)
 def test_config5_full_shard_through_both_loops_vs_the_cpu_chain(oracle):
     """A quarter of a config-5 shard (2,048 aircraft, N = 30, 10 closed-loop steps, reference settings, cold start) through the host
     loop AND through the one-launch loop -- identical bit for bit -- and against the same loop on the host cores (C twin with the
