@@ -145,11 +145,12 @@ def or_status(status):
 
 
 def closed_loop_mpc_rollout(env, steps, hzn, p_dem=0.0, q_dem=0.0, r_dem=0.0, traj_every=1, gather=True, use_plan=True, stats=None,
-                            fused=False, hold_command=False, one_lane=False):
+                            fused=None, hold_command=False, one_lane=False):
     """BASELINE config 5 / test_env.py:480-495 pattern on this rank's shard, then one all-gather:
     per step  cmd = calc_MPC_action(p,q,r,hzn); u.values[1:] = cmd; step(u.values).
     fused=True: the whole loop of the shard as ONE launch (F16Batch.rollout_MPC / C-ABI f16_rollout_mpc: (step, aircraft) pairs from
-    a work queue, no join per step); the host loop below is its checker (bit-identical with one_lane=True).
+    a work queue, no join per step); fused=False: the host loop below, its checker (bit-identical with one_lane=True).  Default (None):
+    the one launch wherever it applies -- a prepared plan (use_plan) with OSQP's default settings, hzn <= 30, cold start -- else the host loop.
     use_plan: the model is frozen (env.py:49-60), so the model-only part of the QP is prepared once
     (F16Batch.prepare_MPC) -- same commands bit for bit.  With the reference's solver settings (OSQP defaults) a plan saves
     the QP build only: the equilibration looks at q, i.e. at the state of the call, so it and the factorisation are redone
@@ -166,6 +167,9 @@ def closed_loop_mpc_rollout(env, steps, hzn, p_dem=0.0, q_dem=0.0, r_dem=0.0, tr
     Returns the collated trajectory [steps//traj_every, 18, B_total] (or the local shard if gather=False)."""
     from . import lib as _lib
     T = steps // traj_every
+    if fused is None:
+        plan_ok = getattr(env, "_plan", None) is None or (env._plan_hzn == int(hzn) and getattr(env, "_plan_default_settings", False))
+        fused = bool(use_plan) and int(hzn) <= 30 and plan_ok and not one_lane
     if fused:
         traj, info = env.rollout_MPC(steps, p_dem, q_dem, r_dem, hzn, traj_every=traj_every, return_info=True, hold_command=hold_command)
         if stats is not None:

@@ -420,6 +420,7 @@ class F16Batch:
                                                    ctypes.byref(w) if w else None, self.B, self.B, int(hzn), self.dt, ctypes.byref(s),
                                                    self._stream))
         self._plan, self._plan_hzn = h, int(hzn)
+        self._plan_default_settings = not settings and not warm_start       # (what f16_rollout_mpc takes: OSQP's defaults, cold start)
         if warm_start:      # OSQP's in-object default; the reference starts cold on every call (new object), so: opt-in
             self._check(self.lib.f16_mpc_plan_warm_start(h, 1))
         return self

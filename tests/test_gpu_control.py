@@ -401,8 +401,12 @@ def test_prepared_plan_is_bit_identical_and_closed_loop(N):
     ea = make_env(x0[:64], u0[:64], xcg=0.35); ea.build_ssr()
     eb = make_env(x0[:64], u0[:64], xcg=0.35); eb.build_ssr()
     ta = fdist.closed_loop_mpc_rollout(ea, steps=8, hzn=N, gather=False, use_plan=False)
-    tb = fdist.closed_loop_mpc_rollout(eb, steps=8, hzn=N, gather=False, use_plan=True)
+    tb = fdist.closed_loop_mpc_rollout(eb, steps=8, hzn=N, gather=False, use_plan=True, fused=False)      # (host loop against host loop)
     assert torch.equal(ta, tb)
+    if N <= 30:                       # the default for a plan: the ONE-launch loop (same commands; its step is the out-of-line one: ulps)
+        ec = make_env(x0[:64], u0[:64], xcg=0.35); ec.build_ssr()
+        tc = fdist.closed_loop_mpc_rollout(ec, steps=8, hzn=N, gather=False)
+        assert float(((tc - tb).abs() / tb.abs().clamp(min=1.0)).max()) < 1e-9 and float((ec._u - eb._u).abs().max()) < 1e-9
 
 
 def test_prepared_plan_beyond_the_register_resident_horizons():

@@ -11,7 +11,7 @@ x0, u0 = config4_states(B)
 for hold in (False, True):
     env = F16Batch(x0, u0, xcg=0.35); env.build_ssr(); env.prepare_MPC(N)
     stats = {}
-    fdist.closed_loop_mpc_rollout(env, T, N, gather=False, stats=stats, hold_command=hold)
+    fdist.closed_loop_mpc_rollout(env, T, N, gather=False, stats=stats, hold_command=hold, fused=False)
     f = stats["flagged_per_step"]
     print("host loop, %s: per step [infeasible, max_iter, not finite] (every 10th step)" % ("hold the previous command" if hold else "reference rule (NaN command)"))
     for k in list(range(0, T, 10)) + [T - 1]:
