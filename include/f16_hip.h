@@ -272,7 +272,8 @@ typedef struct f16_mpc_plan f16_mpc_plan;
  *     the previous command instead and the aircraft flies on.
  *   - outside the envelope at the start of a step (env.py:117-124: the reference exit()s): frozen, flagged
  *     (F16_ST_ENVELOPE | F16_ST_ENV_STATE(k)) and NOT solved for any more: cmd_traj holds NaN, iters_traj 0, u keeps its value.
- * Not capturable on its first call on a plan (allocates the ticket / progress counters). */
+ * Not capturable on its first call on a plan (allocates the ticket / progress counters).  A plan serves one call at a time (its
+ * workspace and these counters are per plan): order calls on one plan through one stream.  nsteps x B < 2^32 per call. */
 int f16_rollout_mpc(f16_mpc_plan *plan, double *x, double *u, const double *dem, double *traj, double *cmd_traj,
                     int32_t *iters_traj, int32_t *status, int nsteps, int traj_every, double xcg, int fi_flag, unsigned flags,
                     void *stream);
