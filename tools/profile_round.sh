@@ -16,7 +16,7 @@ step() { echo "== $1 ($(date +%T))"; }
 HALF=${1:-ab}
 if [[ $HALF == *a* ]]; then
 step "kernel-trace + stats of the default bench command"
-rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_stats -o st -- python3 bench.py --steps 10 --warmup 2 > $O/bench_under_rocprof.json 2> $O/prof_stats.err
+rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_stats -o st -- python3 bench.py --steps 30 --warmup 5 > $O/bench_under_rocprof.json 2> $O/prof_stats.err
 step "kernel-trace + stats of the MPC leg ALONE, headline settings only (B = 4096, N = 30, osqp defaults)"
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_stats_mpc -o stm -- python3 tools/gpu_mpc_only.py > $O/prof_stats_mpc.log 2> $O/prof_stats_mpc.err
 step "kernel-trace + stats of the config-5 closed loop ALONE as one launch (B = 8192, T = 100, N = 30: f16_rollout_mpc), then its issue counters"
