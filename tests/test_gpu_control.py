@@ -1057,7 +1057,7 @@ def _same(a, b):
 
 
 @pytest.mark.timeout(300, method="thread")      # (a persistent kernel that never drains must fail the run, not hold it)
-@pytest.mark.parametrize("B,N,steps", [(256, 30, 8), (100, 10, 12), (1, 30, 5), (3, 4, 40), (1500, 29, 3)])
+@pytest.mark.parametrize("B,N,steps", [(256, 30, 8), (100, 10, 12), (1, 30, 5), (3, 4, 40), (1500, 29, 3), (1100, 10, 30)])
 def test_fused_closed_loop_mpc_rollout_equals_the_host_loop_bit_for_bit(oracle, B, N, steps):
     """f16_rollout_mpc (the reference's loop test_env.py:480-495 as ONE launch: (step, aircraft) pairs from a work queue, a wavefront
     builds the QP vectors, solves, writes the command and steps its pair) against the host loop of six launches per step: every
