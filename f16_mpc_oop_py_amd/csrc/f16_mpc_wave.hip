@@ -1738,6 +1738,13 @@ __device__ __noinline__ void pair_finish(const PairIO *io, int code) {
   __syncthreads();
 }
 
+// Bring-up aid (-DF16_DBG_MARK; tools/gpu_fused_marks.py): phase markers as system-scope stores into the first words of cmd_traj, readable
+// by a copy on ANOTHER stream while the kernel runs -- how a kernel that never returns is located.  Compiled out of the product.
+#ifdef F16_DBG_MARK
+#define DBGM(i, v) { if (threadIdx.x == 0 && ra.cmd_traj) __hip_atomic_store(reinterpret_cast<long long *>(ra.cmd_traj) + 32 + (i), (long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+#else
+#define DBGM(i, v)
+#endif
 __global__ __launch_bounds__(64, 1) void k_rollout_mpc(RollMpcArgs ra) {
   const MpcArgs &a = ra.m;
   const int N = a.N;
@@ -1748,6 +1755,7 @@ __global__ __launch_bounds__(64, 1) void k_rollout_mpc(RollMpcArgs ra) {
     unsigned k = 0;
     if (l == 0) k = atomicAdd(ra.queue, 1u);
     k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+    DBGM(0, 1000 + k)
     if (k >= ra.total) break;
     const int t = __builtin_amdgcn_readfirstlane((int)(k / Bu));
     const unsigned j = k - (unsigned)t * Bu;
@@ -1772,7 +1780,9 @@ __global__ __launch_bounds__(64, 1) void k_rollout_mpc(RollMpcArgs ra) {
     io.status = ra.status; io.tab = ra.tab; io.lofi = ra.lofi; io.exw = a.ext + (size_t)b * mpc_ext_doubles(N);
     io.ld = a.ld; io.b = b; io.t = t; io.N = N; io.every = ra.every; io.fi = ra.fi; io.flags = ra.flags; io.xcg = ra.xcg; io.dt = a.dt;
     io.cmd[0] = NAN; io.cmd[1] = NAN; io.cmd[2] = NAN; io.iters = 0; io.stw = 0; io.stall = stall;
+    DBGM(1, 2000 + t)
     const int code = __builtin_amdgcn_readfirstlane(pair_prepare(&io));
+    DBGM(2, 3000 + code)
     if (code == PAIR_SOLVE) {
       SolveState st;
 #ifdef F16_DBG_SKIP_SOLVE      // (measurement build: what a pair costs WITHOUT its solve -- tools/gpu_config5_only.py under F16HIP_SO)
@@ -1793,11 +1803,15 @@ __global__ __launch_bounds__(64, 1) void k_rollout_mpc(RollMpcArgs ra) {
       else if (!converged || !uniform_flag(ok)) io.stw |= F16_ST_QP_MAXITER;
       wave_lds_sync();
     }
+    DBGM(3, 4000 + io.iters)
     pair_finish(&io, code);
+    DBGM(4, 5000)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&ra.progress[b], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (64 lanes, one word, one value)
+    DBGM(5, 6000 + t)
   }
+  DBGM(6, 7000)
 }
 
 }  // namespace wave
