@@ -648,7 +648,7 @@ __global__ __launch_bounds__(64, SETUP_ONLY ? 2 : 1) void k_mpc(MpcArgs a) {
     if (SETUP_ONLY && a.useq && l == 0) for (int i = 0; i < 7; ++i) { a.useq[i * a.ld + b] = (double)tB[i]; tB[i] = 0; }
 #endif
     if (SETUP_ONLY) { __syncthreads(); continue; }
-    if (nonfinite) { mpc_write_nonfinite(a, b, l, F16_WAVE); __syncthreads(); continue; }
+    if (nonfinite) { mpc_write_nonfinite(a.ucmd, a.useq, a.info, a.iters_out, a.status, a.ld, a.N, a.s.rho, b, l, F16_WAVE); __syncthreads(); continue; }
     // ---------------- the solve (the published OSQP algorithm; same coordinates as f16_mpc_solve.hip:
     // x stays unscaled, the linear system is (c P + sigma D^-2 + rho A'WA) x~ = sigma D^-2 x - c q + A' E (rho zb - yb))
     const double sigma = a.s.sigma, alpha = a.s.alpha;

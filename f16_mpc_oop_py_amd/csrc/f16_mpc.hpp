@@ -88,19 +88,23 @@ __host__ __device__ inline size_t mpc_ext_flag(int N) { return mpc_ext_model(N) 
 // max_iter (40,000 iterations, env.py:421) and hand back NaN.  Same answer here without the iterations: the build kernel raises the
 // flag, every solver asks for it first and writes NaN commands, zero iterations and F16_ST_NONFINITE.  (A NaN state is what the
 // reference's loop is left with one step after an infeasible QP: NaN command -> NaN actuator state, utils.py:308-330.)
-__device__ __forceinline__ bool mpc_job_nonfinite(const MpcArgs &a, long b) {
-  return a.ext && a.ext[(size_t)b * mpc_ext_doubles(a.N) + mpc_ext_flag(a.N)] != 0.0;
+// (Both take the few fields they need BY VALUE: handing the kernel-argument struct itself to a function -- even an inlined one with a
+//  loop over its pointers -- made the compiler keep a 1.3 KB copy of it in scratch in k_mpc_fast, and every later field access a scratch
+//  load: +26 % on the solves without equilibration until it was noticed in the bench record.)
+__device__ __forceinline__ bool mpc_job_nonfinite(const double *ext, int N, long b) {
+  return ext && ext[(size_t)b * mpc_ext_doubles(N) + mpc_ext_flag(N)] != 0.0;
 }
-__device__ __forceinline__ void mpc_write_nonfinite(const MpcArgs &a, long b, int tid, int nthreads) {
+__device__ __forceinline__ void mpc_write_nonfinite(double *ucmd, double *useq, double *info, int32_t *iters_out, int32_t *status, long ld,
+                                                    int N, double rho, long b, int tid, int nthreads) {
   const double nan_ = __builtin_nan("");
-  for (int e = tid; e < 3 * a.N; e += nthreads) {
-    if (e < 3) a.ucmd[e * a.ld + b] = nan_;
-    if (a.useq) a.useq[e * a.ld + b] = nan_;
+  for (int e = tid; e < 3 * N; e += nthreads) {
+    if (e < 3) ucmd[e * ld + b] = nan_;
+    if (useq) useq[e * ld + b] = nan_;
   }
   if (tid == 0) {
-    if (a.iters_out) a.iters_out[b] = 0;
-    if (a.info) { a.info[0 * a.ld + b] = 0.0; a.info[1 * a.ld + b] = nan_; a.info[2 * a.ld + b] = nan_; a.info[3 * a.ld + b] = a.s.rho; }
-    if (a.status) a.status[b] |= F16_ST_NONFINITE;
+    if (iters_out) iters_out[b] = 0;
+    if (info) { info[0 * ld + b] = 0.0; info[1 * ld + b] = nan_; info[2 * ld + b] = nan_; info[3 * ld + b] = rho; }
+    if (status) status[b] |= F16_ST_NONFINITE;
   }
 }
 __host__ __device__ inline size_t mpc_big_doubles(int N) {      // (see k_mpc<false, true>)

@@ -622,7 +622,7 @@ __global__ __launch_bounds__(BLK) void k_mpc_big(MpcArgs a, const SweepArgs sw) 
 #ifdef F16_EXP_STAMPG
     const unsigned long long wc0 = wall_clock64(), tjob0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (mpc_job_nonfinite(a, b)) { mpc_write_nonfinite(a, b, l, BLK); __syncthreads(); continue; }      // (workgroup-uniform)
+    if (mpc_job_nonfinite(a.ext, a.N, b)) { mpc_write_nonfinite(a.ucmd, a.useq, a.info, a.iters_out, a.status, a.ld, a.N, a.s.rho, b, l, BLK); __syncthreads(); continue; }      // (workgroup-uniform)
     const int N = a.N, n = 3 * N, np = n * (n + 1) / 2, ms = 6 * N, m = 12 * N;
     const Lds L = carve(smem, N);
     double *G = L.G, *qv = L.qv, *pred = L.pred, *wbuf = L.wbuf, *xs = L.xs, *xt = L.xt, *rhs = L.rhs, *tv = L.tv, *Dg = L.Dg,

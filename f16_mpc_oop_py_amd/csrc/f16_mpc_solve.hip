@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(FT) void k_mpc_fast(MpcArgs a) {
   // one aircraft per workgroup.  readfirstlane: the index is uniform, so every per-aircraft pointer below lives in scalar
   // registers instead of a VGPR pair each
   const long b = a.order ? (long)__builtin_amdgcn_readfirstlane(a.order[blockIdx.x]) : (long)blockIdx.x;
-  if (a.mode != 1 && a.mode != 3 && mpc_job_nonfinite(a, b)) { mpc_write_nonfinite(a, b, tid, FT); return; }      // (workgroup-uniform)
+  if (a.mode != 1 && a.mode != 3 && mpc_job_nonfinite(a.ext, a.N, b)) { mpc_write_nonfinite(a.ucmd, a.useq, a.info, a.iters_out, a.status, a.ld, a.N, a.s.rho, b, tid, FT); return; }      // (workgroup-uniform)
   double *const exw = a.ext + (size_t)b * mpc_ext_doubles(N);
   const double *Pg = a.Ppk + (size_t)b * (n * (n + 1) / 2);
   const double *Gg = exw + n, *pred = exw + n + 27 * N;

@@ -1517,8 +1517,8 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
   // B spreads any such pattern; the results do not depend on the map.
   const long b = a.order ? (long)__builtin_amdgcn_readfirstlane(a.order[job])
                          : (a.wave_stride ? (long)(((unsigned long long)job * a.wave_stride) % (unsigned long long)a.B) : job);
-  if (mpc_job_nonfinite(a, b)) {                             // (wave-uniform) no QP to solve: NaN command, zero iterations
-    mpc_write_nonfinite(a, b, l, 64);
+  if (mpc_job_nonfinite(a.ext, a.N, b)) {                             // (wave-uniform) no QP to solve: NaN command, zero iterations
+    mpc_write_nonfinite(a.ucmd, a.useq, a.info, a.iters_out, a.status, a.ld, a.N, a.s.rho, b, l, 64);
     if (!a.wave_queue) break;
     continue;
   }
