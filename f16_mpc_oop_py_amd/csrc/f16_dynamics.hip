@@ -4,6 +4,9 @@
 //   k_nlplant   C/nlplant.c:23-457 incl. accels outputs                (f16_nlplant_batch, drop-in Nlplant)
 //   k_rollout   env.py:105-130 step x nsteps, state in registers       (f16_rollout)
 //   k_xdot_na   env.py:152-193                                         (f16_xdot_na_batch)
+//   k_rollout_exact       the same step x nsteps through the out-of-line euler_step_exact: one kernel for every batch size
+//                         (F16_FLAG_ONE_LANE; the step the closed MPC loop f16_rollout_mpc takes)
+//   k_rollout_lqr_linear  test_env_mk2.py:46-62 / test_env.py:501-576: the linear-model LQR loops (f16_rollout_lqr_linear)
 //
 // Mapping: one lane = one aircraft; state-major [k][ld] arrays so a wave's 64 lanes read 512 contiguous
 // bytes per state component.  Every workgroup first copies the 112,928-byte fp64 table image from

@@ -17,6 +17,11 @@
 //     tiles in this one wavefront's accumulators; the pivot panel goes through LDS without a barrier;
 //   * Ruiz equilibration: k_mpc_fast in its scale-only mode (f16_mpc_solve.hip) leaves D, E, c in the workspace.
 // Launch: grid = B workgroups of 64 lanes, __launch_bounds__(64, 1) (512 registers), 40,960 B of static LDS.
+//
+// Two kernels share the solve (solve_aircraft):
+//   k_mpc_wave      one calc_MPC_action per aircraft (f16_mpc_batch / f16_mpc_plan_solve), aircraft from a work queue
+//   k_rollout_mpc   the reference's closed MPC loop test_env.py:480-495 as ONE launch (f16_rollout_mpc, round 5): (step, aircraft)
+//                   pairs from a ticket counter, per pair the state-dependent QP vectors, the solve, the command, one Euler step
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdlib.h>
