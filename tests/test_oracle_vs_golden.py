@@ -446,3 +446,36 @@ np.save(sys.argv[1], out); print(json.dumps({"clr": clr}))
     mine = np.array([oracle.nlplant(x, 1, 0.25) for x in g["xu_hifi"][:400]])
     cols = list(range(18)) if clr < 1e-300 else [k for k in range(18) if k not in (9, 11)]
     assert rel(mine[:, cols], ref[:, cols]) < TOL
+
+
+def test_closed_mpc_loop_of_the_checker_and_its_rules_for_flagged_aircraft(oracle):
+    """oracle.mpc_closed_loop (oracle/f16_mpc_oracle.c: f16o_mpc_closed_loop) = test_env.py:480-495 for B aircraft with a frozen model:
+    equal to the same loop written out call by call (QP of the reference's setup_OSQP, the C solve, one `step`), and the stated rules for
+    the cases the reference does not survive: outside the envelope -> frozen, flagged, not solved for; state not finite -> no QP, NaN
+    command, zero iterations; the hold rule keeps the previous command where a step has none."""
+    g = golden("g567_trim_lin_lqr.npz")
+    x = np.tile(g["trim_x_xcg35"], (3, 1))
+    u = np.copy(x[:, 12:16])
+    x[1, 13] = 26.0                                            # elevator outside its box (env.py:117-124 would exit())
+    x[2, 9] = np.nan                                           # a roll rate that is not finite
+    A_, B_, C_, D_ = oracle.linearise_na(x[0], u3=u[0, 1:], xcg=0.35)
+    Ad, Bd, Cd, _ = mo.c2d(A_, B_, C_, D_, 0.001)
+    N, T, dem = 6, 4, (0.02, -0.01, 0.0)
+    r = oracle.mpc_closed_loop(x, u, Ad, Bd, Cd, N, T, dem, store=True)
+    assert r["status"][0] == 0 and r["status"][1] == 16 | (1 << (8 + 13)) and r["status"][2] & 32
+    assert np.array_equal(r["x"][1], x[1]) and np.array_equal(r["u"][1], u[1])               # frozen: nothing moved
+    assert np.isnan(r["cmd"][:, 1:]).all() and (r["iters"][:, 1:] == 0).all()
+    assert np.isnan(r["u"][2, 1:]).all() and np.isnan(r["x"][2, 13:16]).all()                # NaN command -> NaN surface states (np.clip)
+    xs, us = x[0].copy(), u[0].copy()                          # aircraft 0, call by call
+    for t in range(T):
+        P, q, A, l, uu = oracle.mpc_qp(xs, Ad, Bd, Cd, N, 0.001, dem)             # (the C builder: the loop's own)
+        sol = oracle.admm(P, q, A, l, uu, mode=2)
+        assert sol["iters"] == r["iters"][t, 0] and np.array_equal(sol["x"][:3], r["cmd"][t, 0])
+        Pn, qn, An, ln, un = mo.mpc_qp(xs, Ad, Bd, Cd, N, 0.001, *dem)              # (... which is the restated setup_OSQP)
+        assert rel(P, Pn) < 1e-12 and rel(q, qn) < 1e-10 and np.array_equal(np.isinf(l), np.isinf(ln))
+        us[1:4] = sol["x"][:3]
+        xs = oracle.rollout(xs[None], us[None], 1, xcg=0.35, store=False)[0][0]
+        assert np.array_equal(xs, r["traj"][t, 0])
+    rh = oracle.mpc_closed_loop(x, u, Ad, Bd, Cd, N, T, dem, hold=True)
+    assert np.array_equal(rh["u"][2], u[2]) and not np.isnan(rh["x"][2, 13:16]).any()       # held: the surfaces keep their command
+    assert np.array_equal(rh["cmd"][:, 0], r["cmd"][:, 0])
