@@ -324,6 +324,16 @@ def run(args):
             "iters_mean": c["headline"]["iters_mean"], "aircraft_infeasible_at_some_step": c["headline"]["aircraft_infeasible_at_some_step"],
             "aircraft_not_finite_at_the_end": c["headline"]["aircraft_not_finite_at_the_end"],
             "one_launch_equals_host_loop_bit_for_bit": c["one_launch_equals_host_loop_bit_for_bit"]}
+        try:        # issued fp64 FLOPs of the one-launch loop, RECORDED from rocprofv3 counter passes of the same workload (tools/c5_prof_summary.py)
+            rec5 = json.load(open(os.path.join(REPO, "profiles", "config5_counters.json")))
+            if rec5.get("batch") == c["batch_per_gpu"] and rec5.get("steps") == c["steps"] and rec5.get("hzn") == c["hzn"]:
+                sec = c["batch_per_gpu"] * c["steps"] / (c["headline"]["aircraft_steps_per_s"] / world)
+                out["roofline"]["config5"].update({
+                    "bound": "fp64 vector issue of one wavefront per SIMD (the ADMM iteration)", "issued_flop_per_launch": rec5["issued_flop_per_launch"],
+                    "achieved_tflops": rec5["issued_flop_per_launch"] / sec / 1e12, "peak_tflops": 78.6,
+                    "frac_issued": rec5["issued_flop_per_launch"] / sec / 78.6e12, "counters_source": "recorded: profiles/config5_counters.json (" + str(rec5.get("source")) + ")"})
+        except Exception:
+            pass
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()

@@ -23,6 +23,8 @@ step "kernel-trace + stats of the config-5 closed loop ALONE as one launch (B = 
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_stats_c5 -o c5 -- python3 tools/gpu_config5_only.py > $O/prof_stats_c5.log 2> $O/prof_stats_c5.err
 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE \
   -d $O/prof_c5_sq -o c5 -- python3 tools/gpu_config5_only.py > $O/prof_c5_sq.log 2> $O/prof_c5_sq.err
+rocprofv3 --output-format csv --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
+  -d $O/prof_c5_fp -o c5f -- python3 tools/gpu_config5_only.py > $O/prof_c5_fp.log 2> $O/prof_c5_fp.err
 step "HBM traffic: FETCH_SIZE, WRITE_SIZE (separate passes), B = 4096 and B = 262,144 rollouts"
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/prof_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mpc --no-config5 > /dev/null 2> $O/prof_fetch.err
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/prof_write -o w -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mpc --no-config5 > /dev/null 2> $O/prof_write.err
