@@ -26,6 +26,18 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_python_constants_equal_the_header():
+    """Status bits and behaviour flags of include/f16_hip.h, as the Python binding spells them."""
+    from f16_mpc_oop_py_amd import lib
+    src = open(os.path.join(REPO, "include", "f16_hip.h")).read()
+    val = lambda name: eval(re.search(r"#define\s+%s\s+(\(?[0-9a-fx<>() u]+\)?)" % name, src).group(1).replace("u", ""))
+    for k, v in lib.F16_ST.items():
+        assert val("F16_ST_" + k) == v, k
+    assert val("F16_ST_LOOP_STALL") == lib.F16_ST_LOOP_STALL and lib.F16_ST_ENV_STATE(3) == 1 << 11
+    for k in ("FIX_CLR", "NO_ENVELOPE", "ONE_LANE", "HOLD_COMMAND"):
+        assert val("F16_FLAG_" + k) == getattr(lib, "F16_FLAG_" + k), k
+
+
 def test_no_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():
