@@ -1745,6 +1745,11 @@ __device__ __noinline__ void pair_finish(const PairIO *io, int code) {
 
 // Bring-up aid (-DF16_DBG_MARK; tools/gpu_fused_marks.py): phase markers as system-scope stores into the first words of cmd_traj, readable
 // by a copy on ANOTHER stream while the kernel runs -- how a kernel that never returns is located.  Compiled out of the product.
+#ifdef F16_DBG_PAIRSTAMP   // measurement build: cycles per phase of a pair, summed over every pair of the launch -> eight words BEHIND the command record
+#define PSTAMP(i) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && ra.cmd_traj) atomicAdd(reinterpret_cast<unsigned long long *>(ra.cmd_traj + (size_t)ra.T * 3 * a.ld) + (i), t1_ - tp0_); tp0_ = t1_; }
+#else
+#define PSTAMP(i)
+#endif
 #ifdef F16_DBG_MARK
 #define DBGM(i, v) { if (threadIdx.x == 0 && ra.cmd_traj) __hip_atomic_store(reinterpret_cast<long long *>(ra.cmd_traj) + 32 + (i), (long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 #else
@@ -1756,10 +1761,14 @@ __global__ __launch_bounds__(64, 1) void k_rollout_mpc(RollMpcArgs ra) {
   const Role R = role(N);
   const int l = R.l;
   const unsigned Bu = (unsigned)a.B;
+#ifdef F16_DBG_PAIRSTAMP
+  unsigned long long tp0_ = __builtin_amdgcn_s_memtime();
+#endif
   for (;;) {
     unsigned k = 0;
     if (l == 0) k = atomicAdd(ra.queue, 1u);
     k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+    PSTAMP(0)
     DBGM(0, 1000 + k)
     if (k >= ra.total) break;
     const int t = __builtin_amdgcn_readfirstlane((int)(k / Bu));
@@ -1777,9 +1786,11 @@ __global__ __launch_bounds__(64, 1) void k_rollout_mpc(RollMpcArgs ra) {
         if (++polls > (1 << 24)) { stall = F16_ST_LOOP_STALL; break; }
       }
     }
+    PSTAMP(1)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    PSTAMP(2)
     PairIO io;
     io.x = ra.x; io.u = ra.u; io.dem = ra.dem; io.traj = ra.traj; io.cmd_traj = ra.cmd_traj; io.iters_traj = ra.iters_traj;
     io.status = ra.status; io.tab = ra.tab; io.lofi = ra.lofi; io.exw = a.ext + (size_t)b * mpc_ext_doubles(N);
@@ -1788,6 +1799,7 @@ __global__ __launch_bounds__(64, 1) void k_rollout_mpc(RollMpcArgs ra) {
     DBGM(1, 2000 + t)
     const int code = __builtin_amdgcn_readfirstlane(pair_prepare(&io));
     DBGM(2, 3000 + code)
+    PSTAMP(3)
     if (code == PAIR_SOLVE) {
       SolveState st;
 #ifdef F16_DBG_SKIP_SOLVE      // (measurement build: what a pair costs WITHOUT its solve -- tools/gpu_config5_only.py under F16HIP_SO)
@@ -1809,11 +1821,14 @@ __global__ __launch_bounds__(64, 1) void k_rollout_mpc(RollMpcArgs ra) {
       wave_lds_sync();
     }
     DBGM(3, 4000 + io.iters)
+    PSTAMP(4)
     pair_finish(&io, code);
+    PSTAMP(5)
     DBGM(4, 5000)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&ra.progress[b], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (64 lanes, one word, one value)
+    PSTAMP(6)
     DBGM(5, 6000 + t)
   }
   DBGM(6, 7000)
