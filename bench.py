@@ -734,6 +734,7 @@ def bench_closed_loop(args, dev, rank, world, fdist, barrier):
                            ("prepared_plan_builder_rule_warm_start", True)):
         res[name] = leg(name, use_plan, short)[0]
     res["fused"] = leg("fused", True, short, fused=True)[0]
+    res["fused_warm_start"] = leg("fused_warm_start", True, short, fused=True)[0]      # (opt-in: step t starts from the solution of step t - 1)
     # the headline: config 5 as written -- reference settings (OSQP defaults, cold start per solve), all T steps -- through the ONE-
     # launch closed loop (f16_rollout_mpc); the host loop (six launches per step, a join after every solve) over the same T beside it
     r, traj, dt = leg("fused", True, T, keep_traj=True, fused=True)
@@ -770,7 +771,8 @@ def bench_closed_loop(args, dev, rank, world, fdist, barrier):
                    "`aircraft_not_finite_at_the_end` -- their steps still count as steps).  The other variants run `short_leg_steps`: "
                    "prepared_plan / one_shot / fused start every solve cold, as the reference does (a new OSQP object per call; with OSQP's "
                    "defaults a plan saves the QP build only -- the equilibration depends on q); "
-                   "warm_start is the opt-in extension (OSQP's in-object default); check5 = the same with the termination test "
+                   "warm_start is the opt-in extension (OSQP's in-object default; `fused_warm_start`: the same inside the one-launch loop, the solution handed "
+                   "from wavefront to wavefront with the state); check5 = the same with the termination test "
                    "every 5 iterations instead of OSQP's 25 (a warm-started solve needs fewer than 25); builder_rule = the opt-in "
                    "solver settings (no equilibration, start value of rho from the traces; KKT factorisation cached in the plan)")
     return res

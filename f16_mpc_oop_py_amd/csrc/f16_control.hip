@@ -1424,8 +1424,8 @@ extern "C" int f16_rollout_mpc(f16_mpc_plan *p, double *x, double *u, const doub
                                int32_t *iters_traj, int32_t *status, int nsteps, int traj_every, double xcg, int fi_flag,
                                unsigned flags, void *stream) {
   if (!p || !x || !u || !dem) return set_error(F16_EINVAL, "bad argument to f16_rollout_mpc");
-  if (p->N > WAVE_MAXN || p->s.scaling <= 0 || p->warm_on)
-    return set_error(F16_EINVAL, "f16_rollout_mpc needs a plan with hzn <= 30, equilibrated solves (scaling > 0) and no warm start; "
+  if (p->N > WAVE_MAXN || p->s.scaling <= 0)
+    return set_error(F16_EINVAL, "f16_rollout_mpc needs a plan with hzn <= 30 and equilibrated solves (scaling > 0); "
                                  "other plans run the host loop (f16_mpc_plan_solve + f16_rollout per step)");
   if (nsteps < 0 || (traj && (traj_every < 1 || nsteps % traj_every != 0)))
     return set_error(F16_EINVAL, "nsteps must be >= 0 and a multiple of traj_every >= 1 when traj is given");
@@ -1437,7 +1437,11 @@ extern "C" int f16_rollout_mpc(f16_mpc_plan *p, double *x, double *u, const doub
   RolloutMpcCall c{};
   c.x = x; c.u = u; c.dem = dem; c.traj = traj; c.cmd_traj = cmd_traj; c.iters_traj = iters_traj; c.status = status;
   c.sync = p->roll_sync; c.T = nsteps; c.every = traj ? traj_every : nsteps + 1; c.xcg = xcg; c.fi = fi_flag; c.flags = flags;
-  return mpc_wave_rollout_launch(p->ctx, p->a, c, stream);
+  c.warm = p->warm_on ? p->warm : nullptr;
+  c.warm_load = p->warm_on && p->have_prev;
+  const int rc = mpc_wave_rollout_launch(p->ctx, p->a, c, stream);
+  if (!rc) p->have_prev = p->warm_on;
+  return rc;
 }
 
 extern "C" int f16_mpc_plan_warm_start(f16_mpc_plan *p, int on) {

@@ -128,6 +128,8 @@ struct RolloutMpcCall {
   double *traj, *cmd_traj;
   int32_t *iters_traj, *status;
   void *sync;                 // [8 bytes ticket counter | B x int32 progress], zeroed by the launch
+  double *warm;               // the plan's warm-start buffer (opt-in), or null: every solve starts cold, as the reference's does
+  int warm_load;              // step 0 starts from what the plan's previous call left (later steps always start from the step before)
   int T, every;
   double xcg;
   int fi;

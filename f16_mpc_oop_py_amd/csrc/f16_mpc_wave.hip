@@ -1378,7 +1378,7 @@ __device__ __noinline__ void p_block_image(const double *Pg, double *pb, int n) 
 // ... of aircraft b by this wavefront: prologue, equilibration, factorise / iterate / test until done.  Leaves the solution in
 // `st` (lane 0 holds the first move st.x[0..2]) and, with a warm-start buffer, the solution for the next call; returns whether every
 // factorisation succeeded.  Called by k_mpc_wave (one calc_MPC_action per aircraft) and by k_rollout_mpc (one per aircraft and step).
-__device__ __forceinline__ bool solve_aircraft(const MpcArgs &a, long b, long job, const Role &R, SolveState &st
+__device__ __forceinline__ bool solve_aircraft(const MpcArgs &a, long b, long job, const Role &R, SolveState &st, int warm_load
 #ifdef F16_EXP_STAMPW
                                                , unsigned long long &tK0
 #endif
@@ -1463,7 +1463,7 @@ __device__ __forceinline__ bool solve_aircraft(const MpcArgs &a, long b, long jo
   st.rp = INFINITY; st.rd = INFINITY; st.it = 0; st.to_check = a.s.check_every > 0 ? a.s.check_every : 1;
   st.done = 0; st.converged = 0; st.infeasible = 0; st.rho = a.s.rho;
   double *const wm = a.warm ? a.warm + (size_t)b * MPC_WARM_DOUBLES + l : nullptr;      // [15][64]: x, zA, yA, zB, yB (unscaled)
-  if (wm && a.warm_load) {
+  if (wm && warm_load) {
     bool fin = true;
     double t15[15];
 #pragma unroll
@@ -1529,9 +1529,9 @@ __global__ __launch_bounds__(64, 1) void k_mpc_wave(MpcArgs a) {
   }
   SolveState st;
 #ifdef F16_EXP_STAMPW
-  const bool ok = solve_aircraft(a, b, job, R, st, tK0);
+  const bool ok = solve_aircraft(a, b, job, R, st, a.warm_load, tK0);
 #else
-  const bool ok = solve_aircraft(a, b, job, R, st);
+  const bool ok = solve_aircraft(a, b, job, R, st, a.warm_load);
 #endif
   const int kx = 3 * R.istep;
   const bool converged = st.converged != 0, infeasible = st.infeasible != 0;
@@ -1807,9 +1807,11 @@ __global__ __launch_bounds__(64, 1) void k_rollout_mpc(RollMpcArgs ra) {
       const bool ok = true;
 #elif defined(F16_EXP_STAMPW)
       unsigned long long tK0 = 0;
-      const bool ok = solve_aircraft(a, b, (long)k + 1, R, st, tK0);
+      const bool ok = solve_aircraft(a, b, (long)k + 1, R, st, (t > 0 || a.warm_load) ? 1 : 0, tK0);
 #else
-      const bool ok = solve_aircraft(a, b, (long)k + 1, R, st);
+      // (warm start, opt-in: step 0 starts from the plan's previous call if there was one, every later step from the step before --
+      //  the buffer is handed from wavefront to wavefront with the state, behind the same release / acquire)
+      const bool ok = solve_aircraft(a, b, (long)k + 1, R, st, (t > 0 || a.warm_load) ? 1 : 0);
 #endif
       const bool infeasible = __builtin_amdgcn_readfirstlane(st.infeasible) != 0;
       const bool converged = __builtin_amdgcn_readfirstlane(st.converged) != 0;
@@ -1881,7 +1883,7 @@ int mpc_wave_rollout_launch(f16_ctx *ctx, const MpcArgs &a, const RolloutMpcCall
   wave::RollMpcArgs r{};
   r.m = a;
   r.m.x = c.x; r.m.dem = c.dem; r.m.xref = nullptr; r.m.ucmd = nullptr; r.m.useq = nullptr; r.m.info = nullptr; r.m.status = nullptr;
-  r.m.mode = 0; r.m.wave_ruiz = 1; r.m.order = nullptr; r.m.iters_out = nullptr; r.m.warm = nullptr; r.m.warm_load = 0; r.m.wave_queue = nullptr;
+  r.m.mode = 0; r.m.wave_ruiz = 1; r.m.order = nullptr; r.m.iters_out = nullptr; r.m.warm = c.warm; r.m.warm_load = c.warm_load; r.m.wave_queue = nullptr;
   r.x = c.x; r.u = c.u; r.dem = c.dem; r.traj = c.traj; r.cmd_traj = c.cmd_traj; r.iters_traj = c.iters_traj; r.status = c.status;
   r.queue = reinterpret_cast<unsigned *>(c.sync);
   r.progress = reinterpret_cast<int32_t *>(c.sync) + 2;

@@ -150,7 +150,7 @@ def closed_loop_mpc_rollout(env, steps, hzn, p_dem=0.0, q_dem=0.0, r_dem=0.0, tr
     per step  cmd = calc_MPC_action(p,q,r,hzn); u.values[1:] = cmd; step(u.values).
     fused=True: the whole loop of the shard as ONE launch (F16Batch.rollout_MPC / C-ABI f16_rollout_mpc: (step, aircraft) pairs from
     a work queue, no join per step); fused=False: the host loop below, its checker (bit-identical with one_lane=True).  Default (None):
-    the one launch wherever it applies -- a prepared plan (use_plan) with OSQP's default settings, hzn <= 30, cold start -- else the host loop.
+    the one launch wherever it applies -- a prepared plan (use_plan) with equilibrated solves (OSQP's defaults), hzn <= 30 -- else the host loop.
     use_plan: the model is frozen (env.py:49-60), so the model-only part of the QP is prepared once
     (F16Batch.prepare_MPC) -- same commands bit for bit.  With the reference's solver settings (OSQP defaults) a plan saves
     the QP build only: the equilibration looks at q, i.e. at the state of the call, so it and the factorisation are redone

@@ -420,7 +420,7 @@ class F16Batch:
                                                    ctypes.byref(w) if w else None, self.B, self.B, int(hzn), self.dt, ctypes.byref(s),
                                                    self._stream))
         self._plan, self._plan_hzn = h, int(hzn)
-        self._plan_default_settings = not settings and not warm_start       # (what f16_rollout_mpc takes: OSQP's defaults, cold start)
+        self._plan_default_settings = int((settings or {}).get("scaling", 10)) > 0       # (what f16_rollout_mpc takes: equilibrated solves)
         if warm_start:      # OSQP's in-object default; the reference starts cold on every call (new object), so: opt-in
             self._check(self.lib.f16_mpc_plan_warm_start(h, 1))
         return self
@@ -527,7 +527,8 @@ class F16Batch:
     def rollout_MPC(self, nsteps, p_dem, q_dem, r_dem, hzn, traj_every=None, return_info=False, hold_command=False):
         """The reference's closed MPC loop (test_env.py:480-495; BASELINE config 5) as ONE launch (C-ABI f16_rollout_mpc): per step
         `cmd = _calc_MPC_action(p_dem, q_dem, r_dem, hzn); u.values[1:] = cmd; step(u.values)` from the frozen reduced model
-        (env.py:49-60) with OSQP's default settings.  Work items are (step, aircraft) pairs taken from one queue by one wavefront per
+        (env.py:49-60) with OSQP's default settings (every solve cold, as the reference's -- or warm from the step before when the plan was
+        prepared with warm_start=True).  Work items are (step, aircraft) pairs taken from one queue by one wavefront per
         SIMD, so no step waits for another aircraft's solve -- the host loop `dist.closed_loop_mpc_rollout` (the checker of this
         call) joins the batch after every solve.  Uses the prepared plan of horizon hzn (prepare_MPC; made here if absent).
         Returns the states after every traj_every-th step [nsteps//k, 18, B] (None without traj_every); with return_info also

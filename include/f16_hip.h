@@ -256,7 +256,8 @@ int f16_mpc_hzn_sweep(f16_ctx *ctx, const double *Ad, const double *Bd, const do
  * f16_mpc_plan_create only. */
 typedef struct f16_mpc_plan f16_mpc_plan;
 /* The reference's closed MPC loop (test_env.py:480-495; BASELINE config 5) as ONE launch on a prepared plan (hzn <= 30, OSQP's
- * default settings: scaling > 0; cold start):  per step  cmd = _calc_MPC_action(p, q, r, hzn);  u.values[1:] = cmd;  step(u.values).
+ * default settings: scaling > 0; every solve starts cold as the reference's does, unless f16_mpc_plan_warm_start switched the plan's
+ * opt-in warm start on: then step t starts from the solution of step t - 1):  per step  cmd = _calc_MPC_action(p, q, r, hzn);  u.values[1:] = cmd;  step(u.values).
  * x[18][ld] in place; u[4][ld] = u.values in place (thrust command held, u[1:4] receives every step's command and ends up
  * holding the last one, as the reference's u.values does); dem[3][ld].  traj (may be NULL) [nsteps / traj_every][18][ld]: the state
  * after every traj_every-th step; cmd_traj (may be NULL) [nsteps][3][ld]: what calc_MPC_action returned at each step; iters_traj

@@ -1139,6 +1139,28 @@ def test_fused_closed_loop_flagged_aircraft_nan_commands_hold_and_frozen(oracle)
     assert np.isfinite(np.delete(xgh, 5, 0)).all() and not (np.delete(sfh, 5) & 32).any()   # held commands: everybody flies on
 
 
+@pytest.mark.timeout(300, method="thread")
+def test_fused_closed_loop_with_the_opt_in_warm_start():
+    """f16_mpc_plan_warm_start (OSQP's in-object default; the reference starts cold) inside the one-launch loop: step t starts from the
+    solution of step t - 1, handed from wavefront to wavefront with the state -- identical to the host loop on a warm-started plan,
+    fewer iterations than the cold loop, and a second call goes on from the first one's last solution."""
+    from f16_mpc_oop_py_amd.workload import config4_states
+    B, N, steps = 300, 30, 8
+    x0, u0 = config4_states(B, seed=13)
+    dem = (0.02, 0.0, -0.01)
+    envh = make_env(x0, u0, xcg=0.35)
+    envh.build_ssr(); envh.prepare_MPC(N, warm_start=True)
+    trh, ch, ih = _host_loop(envh, steps, N, dem)
+    envf = make_env(x0, u0, xcg=0.35)
+    envf.build_ssr(); envf.prepare_MPC(N, warm_start=True)
+    trf, info = envf.rollout_MPC(steps, *dem, N, traj_every=1, return_info=True)
+    assert _same(info["cmd"], ch) and _same(info["iters"], ih) and _same(trf, trh) and _same(envf.status, envh.status)
+    assert float(info["iters"][1:].float().mean()) < 0.7 * float(info["iters"][0].float().mean())       # warm solves are shorter
+    trh2, ch2, ih2 = _host_loop(envh, 3, N, dem)
+    _, info2 = envf.rollout_MPC(3, *dem, N, return_info=True)
+    assert _same(info2["cmd"], ch2) and _same(info2["iters"], ih2) and _same(envf._x, envh._x)
+
+
 @pytest.mark.timeout(300, method="thread")      # (a persistent kernel that never drains must fail the run, not hold it)
 def test_fused_closed_loop_lofi_model_and_horizon_one():
     """The one-launch loop on the lofi Stevens-Lewis model (fi_flag = 0: the out-of-line step takes the fidelity at run time) and at
