@@ -23,6 +23,10 @@ def make_env(x, u=None, **kw):
     return F16Batch(x, u, device="cuda:0", **kw)
 
 
+def rel(a, b):
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+
+
 def soa(a, dev="cuda:0"):
     """[B, ...] -> state-major [prod(...), B] device tensor."""
     a = np.asarray(a, dtype=np.float64)
@@ -604,6 +608,32 @@ def test_relinearised_closed_loop_vs_oracle_loop(oracle):
     fr = env2._calc_MPC_action(*dem, N, settings=mode_settings("builder")).clone()
     rl = env2._calc_MPC_action(*dem, N, relinearise=True, settings=mode_settings("builder"))
     assert float((fr - rl).abs().max()) > 1e-6
+
+
+@pytest.mark.parametrize("xcg", [25, 35])
+def test_g14_per_step_relinearised_lqr_loop_on_the_device(xcg):
+    """The reference's `test_LQR_dynamic_nl` (test_env.py:625-687): per step `_calc_LQR_gain(Q = I, R = 1e4 I)` at the CURRENT state
+    (device linearise -> ZOH -> doubling DARE), cmd = -dlqr (x9 - x_ref), step -- against fixture G14 (the reference's loop run in the build
+    container, 150 steps).  The device's libm differs from glibc in the last ulp, eps = 1e-5 amplifies it 1e5 x, the gain carries it into
+    the command: 2e-5 absolute on commands up to 2.7 deg; states 1e-6."""
+    g = golden("g14_dynamic_lqr.npz")
+    env = make_env(g[f"x0_xcg{xcg}"][None], g[f"u0_xcg{xcg}"][None], xcg=xcg / 100)
+    xref = env._get_mpc_x().clone()
+    Q, R = np.eye(9), np.eye(3) * 1e4
+    worst = 0.0
+    for t in range(150):
+        K = env._calc_LQR_gain(Q=Q, R=R)                                  # [1,3,9] = -dlqr(Ad, Bd, Q, R) at the current state
+        if t in (0, 50, 149):
+            assert rel(-K[0].cpu().numpy(), g[f"K{t}_xcg{xcg}"]) < 1e-5
+        cmd = (K @ (env._get_mpc_x() - xref).unsqueeze(-1)).squeeze(-1)    # -dlqr (x9 - x_ref)
+        worst = max(worst, float((cmd[0].cpu() - torch.as_tensor(g[f"cmd_xcg{xcg}"][t])).abs().max()))
+        env._u[1:4] = cmd.t()
+        env.step()
+        if (t + 1) % 10 == 0:
+            r = g[f"x_xcg{xcg}"][(t + 1) // 10 - 1]
+            assert np.max(np.abs(env.x_values.cpu().numpy()[0] - r) / np.maximum(1.0, np.abs(r))) < 1e-6, t
+    assert worst < 2e-5, worst
+    assert int(env.status.max()) == 0
 
 
 def test_lqr_gain_on_config3_workload_sample(oracle):

@@ -479,3 +479,28 @@ def test_closed_mpc_loop_of_the_checker_and_its_rules_for_flagged_aircraft(oracl
     rh = oracle.mpc_closed_loop(x, u, Ad, Bd, Cd, N, T, dem, hold=True)
     assert np.array_equal(rh["u"][2], u[2]) and not np.isnan(rh["x"][2, 13:16]).any()       # held: the surfaces keep their command
     assert np.array_equal(rh["cmd"][:, 0], r["cmd"][:, 0])
+
+
+@pytest.mark.parametrize("xcg", [25, 35])
+def test_g14_per_step_relinearised_lqr_loop(oracle, xcg):
+    """The reference's `test_LQR_dynamic_nl` (test_env.py:625-687; SURVEY.md 8f-2's pattern), 150 steps: at EVERY step linearise at the
+    current state (env.py:294-342) -> cont2discrete -> K = dlqr(A, B, I, 1e4 I); cmd = -K (x9 - x_ref); step.  Pins the chain
+    linearise -> ZOH -> dlqr along a moving trajectory (G6 / G7 pin it at the trim point only).  Forward differences with eps = 1e-5
+    amplify last-bit differences of the plant by 1e5, the gain (entries up to 1,400) carries them into the command: 5e-6 absolute."""
+    g = golden("g14_dynamic_lqr.npz")
+    x, u = g[f"x0_xcg{xcg}"].copy(), g[f"u0_xcg{xcg}"].copy()
+    idx = [3, 4, 7, 8, 9, 10, 11, 17, 16]
+    xref, Q, R = x[idx].copy(), np.eye(9), np.eye(3) * 1e4
+    for t in range(150):
+        A_, B_, C_, D_ = oracle.linearise_na(x, u3=u[1:], xcg=xcg / 100)
+        Ad, Bd, _, _ = mo.c2d(A_, B_, C_, D_, 0.001)
+        K = mo.dlqr(Ad, Bd, Q, R)
+        if t in (0, 50, 149):
+            assert rel(K, g[f"K{t}_xcg{xcg}"]) < 1e-6
+        cmd = -K @ (x[idx] - xref)
+        assert np.abs(cmd - g[f"cmd_xcg{xcg}"][t]).max() < 5e-6, t
+        u[1:4] = cmd
+        x = oracle.rollout(x[None], u[None], 1, xcg=xcg / 100, store=False)[0][0]
+        if (t + 1) % 10 == 0:
+            assert rel(x, g[f"x_xcg{xcg}"][(t + 1) // 10 - 1]) < 1e-7
+

@@ -554,8 +554,54 @@ def g13_round5():
     print("g13_linear_loops.npz", os.path.getsize(os.path.join(OUT, "g13_linear_loops.npz")))
 
 
+def g14_dynamic_lqr(steps=150):
+    """G14: the reference's per-step RE-LINEARISED LQR loop (test_env.py:625-687 `test_LQR_dynamic_nl`; SURVEY.md 8f-2's pattern): every
+    step  A, B = linearise at the CURRENT state (env.py:294-342, reduced model) -> cont2discrete -> K = dlqr(A, B, I, 1e4 I)
+    (utils.py:219);  cmd = -K (x9 - x_ref) with x_ref = the initial x9 (no trim offset: the loop as written commands the surfaces towards
+    zero);  u.values[1:] = cmd;  step(u.values).  Both xcg builds, `steps` steps from the object's trim point: every command, every 10th
+    state, the gain of steps 0 / 50 / last.  (The eigenvalue prints and the second linearisation of the loop body do not enter the state.)"""
+    parameters, env, utils = import_reference()
+    from scipy.signal import cont2discrete
+    libs = {25: ctypes.CDLL(os.path.join(REF, "C", "nlplant_xcg25.so")),
+            35: ctypes.CDLL(os.path.join(REF, "C", "nlplant_xcg35.so"))}
+    f16 = make_f16_objects(parameters, env, libs)
+    for k in libs:
+        if not clr_reads_zero(libs[k]):
+            raise SystemExit("this process's _CLr does not read ~0 (uninitialised heap): run the script again")
+    g = {}
+    for k, f in f16.items():
+        f.reset()
+        g[f"x0_xcg{k}"], g[f"u0_xcg{k}"] = np.copy(f.x.values), np.copy(f.u.values)
+        Q, R = np.eye(9), np.eye(3) * 10000                     # test_env.py:641-642
+        x_ref = np.copy(f.x._get_mpc_x())                       # :655
+        cmds, xs, Ks = [], [], {}
+        for idx in range(steps):
+            Ac, Bc, Cc, Dc = f.linearise(f.x._get_mpc_x(), f.u._get_mpc_u(), _calc_xdot=f._calc_xdot_na, get_obs=f._get_obs_na)
+            A, B, C, D = cont2discrete((Ac, Bc, Cc, Dc), f.paras.dt)[0:4]
+            K = utils.dlqr(A, B, Q, R)
+            cmd = (- K @ (f.x._get_mpc_x() - x_ref))
+            f.u.values[1:] = cmd
+            f.step(f.u.values)
+            cmds.append(np.copy(cmd))
+            if idx in (0, 50, steps - 1):
+                Ks[idx] = np.copy(K)
+            if (idx + 1) % 10 == 0:
+                xs.append(np.copy(f.x.values))
+        g[f"cmd_xcg{k}"], g[f"x_xcg{k}"] = np.array(cmds), np.array(xs)
+        for idx, K in Ks.items():
+            g[f"K{idx}_xcg{k}"] = K
+        f.reset()
+    for k in libs:
+        if not clr_reads_zero(libs[k]):
+            raise SystemExit("_CLr stopped reading ~0 during the run: run the script again")
+    np.savez_compressed(os.path.join(OUT, "g14_dynamic_lqr.npz"), **g)
+    print("g14_dynamic_lqr.npz", os.path.getsize(os.path.join(OUT, "g14_dynamic_lqr.npz")))
+
+
 if __name__ == "__main__":
-    if "--g13" in sys.argv:
+    if "--g14" in sys.argv:
+        g14_dynamic_lqr()
+    elif "--g13" in sys.argv:
         g13_round5()
     elif "--g12" in sys.argv:
         g12_lqr_loop_and_g8b_weights()
